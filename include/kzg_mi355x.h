@@ -1,0 +1,118 @@
+/* kzg_mi355x.h -- C-ABI of libkzg_mi355x.so, the MI355X (gfx950) KZG segment prover.
+ *
+ * This is the drop-in boundary for the reference's prover seam: the reference miner talks to an external
+ * prover process through `fourier.Client` (constructed at reference base/miner.py:73-84, used at
+ * neurons/miner.py:39,48 and neurons/validator.py:59-104).  Each entry point below names the reference
+ * interface it replaces.  The Python class zkp_subnet_amd.client.Client binds these through ctypes and
+ * reproduces the Client method surface; INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every buffer; the library copies in and out.
+ *   - Fr  : 32 bytes big-endian, canonical (< r).  A non-canonical scalar fails the call (KZG_E_SCALAR).
+ *   - G1  : affine x||y, 2 x 48 bytes big-endian (96 zero bytes = infinity), or the 48-byte ZCash
+ *           compressed encoding for results.  Partial sums cross the ABI as 192 opaque bytes (XYZZ).
+ *   - return 0 on success, negative kzg_status otherwise; kzg_last_error(ctx) gives the message.
+ *     No exception or abort crosses the boundary.
+ *   - one ctx = one GPU; calls on one ctx are serialised by an internal mutex (re-entrant per ctx,
+ *     ctypes releases the GIL during a call).
+ *   - there is NO CPU fallback: every compute entry point fails with KZG_E_HIP when no gfx950 device works.
+ */
+#ifndef KZG_MI355X_H
+#define KZG_MI355X_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kzg_ctx kzg_ctx;
+
+typedef enum {
+    KZG_OK = 0,
+    KZG_E_ARG = -1,     /* bad length / index / state */
+    KZG_E_SCALAR = -2,  /* non-canonical Fr (>= r) */
+    KZG_E_POINT = -3,   /* G1 input not reduced or not on the curve */
+    KZG_E_HIP = -4,     /* HIP runtime failure or no usable device */
+    KZG_E_NOMEM = -5
+} kzg_status;
+
+/* ---- lifecycle: replaces Client(port, bin, ...) + Client.start()/stop()  (reference base/miner.py:73-84,155,181) */
+int kzg_create(int device_id, kzg_ctx** out);
+void kzg_destroy(kzg_ctx* ctx);
+const char* kzg_last_error(kzg_ctx* ctx);
+const char* kzg_version(void);
+/* window bits c for the signed-digit Pippenger tables; 0 = choose from the slice length.  Call before the SRS. */
+int kzg_set_window(kzg_ctx* ctx, int c);
+int kzg_get_window(kzg_ctx* ctx);
+
+/* ---- SRS: replaces the prover's setup / precompute file loading (reference base/miner.py:75-84,
+ *      utils/config.py:124-164).  The flat SRS holds 2^machines_scale-or-fewer worker slices of
+ *      T = 2^(scale-machines_scale) points each, slice k at points [k*T, (k+1)*T).  Points stay resident
+ *      ("cached SRS") together with their window multiples 2^(c*w) P. */
+int kzg_load_srs(kzg_ctx* ctx, const uint8_t* g1_affine_be96, uint64_t n_points, int scale, int machines_scale);
+/* synthetic SRS with known discrete logs (tests / benches; stands in for `fourier setup --generate-setup`,
+ * reference tests/conftest.py:50-65): slice k, point j = [s0_k * tau^j] G.  s0_be32: n_slices x 32 bytes. */
+int kzg_gen_srs(kzg_ctx* ctx, const uint8_t tau_be32[32], const uint8_t* s0_be32, uint32_t n_slices, int scale,
+                int machines_scale);
+uint64_t kzg_srs_points(kzg_ctx* ctx);
+/* read back resident points: window w multiple of points [first, first+count) as affine be96 */
+int kzg_srs_read(kzg_ctx* ctx, int w, uint64_t first, uint64_t count, uint8_t* out_be96);
+
+/* ---- hot path.  worker index i selects slice i of the resident SRS. */
+/* replaces Client.worker_commit(i, poly)            (reference neurons/miner.py:38-45) */
+int kzg_commit(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
+               uint8_t out_commitment48[48]);
+/* replaces Client.worker_open(i, poly, x)           (reference neurons/miner.py:47-54) */
+int kzg_open(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
+             const uint8_t alpha_be32[32], uint8_t out_eval32[32], uint8_t out_proof48[48]);
+/* fused Miner.rpc_commit_and_open (reference neurons/miner.py:56-61): one upload, one IFFT, two MSMs */
+int kzg_commit_open(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
+                    const uint8_t alpha_be32[32], uint8_t out_commitment48[48], uint8_t out_eval32[32],
+                    uint8_t out_proof48[48]);
+/* plain MSM over resident points [srs_offset, srs_offset+n): the headline kernel (BASELINE.json metric) */
+int kzg_msm(kzg_ctx* ctx, const uint8_t* scalars_be32, uint64_t n, uint64_t srs_offset, uint8_t out48[48]);
+/* replaces Client.fft(poly, left, inverse)          (reference neurons/validator.py:58-65); in place */
+int kzg_ntt(kzg_ctx* ctx, uint8_t* inout_be32, uint64_t n, int inverse);
+/* replaces Client.eval(poly, x)                     (reference neurons/validator.py:97-104) */
+int kzg_eval(kzg_ctx* ctx, const uint8_t* coeffs_be32, uint64_t n, const uint8_t x_be32[32], uint8_t out_be32[32]);
+
+/* ---- multi-GPU: each rank reduces its SRS shard to ONE partial sum; the 192-byte partials are exchanged by
+ *      the caller (RCCL all_gather over xGMI in zkp_subnet_amd.distributed) and summed on any rank. */
+int kzg_msm_partial(kzg_ctx* ctx, const uint8_t* scalars_be32, uint64_t n, uint64_t srs_offset,
+                    uint8_t out_xyzz192[192]);
+int kzg_g1_sum(kzg_ctx* ctx, const uint8_t* partials_xyzz192, uint32_t count, uint8_t out48[48]);
+
+/* ---- device-resident inputs (what a serving loop and bench.py use: inputs already in HBM when timing starts).
+ *      slot in [0, 4).  to_mont=1 stores Montgomery form (rows for commit/open), 0 canonical (MSM scalars). */
+int kzg_upload_fr(kzg_ctx* ctx, int slot, const uint8_t* be32, uint64_t n, int to_mont);
+int kzg_msm_resident(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint8_t out48[48]);
+int kzg_msm_partial_resident(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint8_t out_xyzz192[192]);
+int kzg_commit_open_resident(kzg_ctx* ctx, uint32_t i, int slot, uint64_t T, int evaluation_form,
+                             const uint8_t alpha_be32[32], uint8_t out_commitment48[48], uint8_t out_eval32[32],
+                             uint8_t out_proof48[48]);
+int kzg_ntt_resident(kzg_ctx* ctx, int slot, uint64_t n, int inverse); /* in place on the slot */
+
+/* ---- per-stage HIP-event timings of the last hot-path call (events recorded on the ctx's own stream) */
+enum {
+    KZG_T_DECODE = 0, KZG_T_NTT, KZG_T_DIGITS, KZG_T_SCAN, KZG_T_SCATTER, KZG_T_ACCUMULATE, KZG_T_FIXUP,
+    KZG_T_TREE, KZG_T_FINAL, KZG_T_POLY, KZG_T_TOTAL, KZG_T_COUNT
+};
+int kzg_set_profiling(kzg_ctx* ctx, int enable);
+int kzg_get_timings(kzg_ctx* ctx, float* out_ms, int count); /* accumulated over the last call's MSMs */
+/* fixed-size MSM plan facts for roofline bookkeeping: entries per lane, lanes, buckets, windows */
+int kzg_msm_plan(kzg_ctx* ctx, uint64_t n, int32_t out[4]);
+
+/* ---- host-side wire codec (Prove.poly is a list of 43-char unpadded base64 strings, reference
+ *      base/protocol.py:35-40).  packed: n x 43 chars, no separators.  Pure host code. */
+int kzg_b64_decode_fr(const char* packed43, uint64_t n, uint8_t* out_be32);
+int kzg_b64_encode_fr(const uint8_t* be32, uint64_t n, char* out_packed43);
+
+/* ---- unit-op hooks for the parity tests (tests/test_gpu_field.py); not part of the serving surface */
+int kzg_test_field(kzg_ctx* ctx, int field /*0 Fp,1 Fr*/, int op /*0 mul,1 add,2 sub,3 mul(plain C)*/,
+                   const uint8_t* a_be, const uint8_t* b_be, uint8_t* out_be, uint64_t n);
+int kzg_test_g1(kzg_ctx* ctx, int op /*0 a+b mixed,1 2a+b full,2 2a,3 4a*/, const uint8_t* a_be96,
+                const uint8_t* b_be96, uint8_t* out_be96, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KZG_MI355X_H */

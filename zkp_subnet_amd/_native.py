@@ -1,0 +1,80 @@
+"""ctypes binding of libkzg_mi355x.so (include/kzg_mi355x.h).  The HIP library IS the product: if it is
+missing or no gfx950 device works, everything here raises -- there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libkzg_mi355x.so")
+
+KZG_OK, KZG_E_ARG, KZG_E_SCALAR, KZG_E_POINT, KZG_E_HIP, KZG_E_NOMEM = 0, -1, -2, -3, -4, -5
+STATUS_NAMES = {0: "OK", -1: "E_ARG", -2: "E_SCALAR", -3: "E_POINT", -4: "E_HIP", -5: "E_NOMEM"}
+TIMING_NAMES = ["decode", "ntt", "digits", "scan", "scatter", "accumulate", "fixup", "tree", "final", "poly", "total"]
+
+# every symbol include/kzg_mi355x.h declares: name -> (restype, argtypes)
+_P = ctypes.c_void_p
+_B = ctypes.c_char_p
+_U64, _U32, _I = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
+SYMBOLS = {
+    "kzg_create": (_I, [_I, ctypes.POINTER(_P)]),
+    "kzg_destroy": (None, [_P]),
+    "kzg_last_error": (ctypes.c_char_p, [_P]),
+    "kzg_version": (ctypes.c_char_p, []),
+    "kzg_set_window": (_I, [_P, _I]),
+    "kzg_get_window": (_I, [_P]),
+    "kzg_load_srs": (_I, [_P, _B, _U64, _I, _I]),
+    "kzg_gen_srs": (_I, [_P, _B, _B, _U32, _I, _I]),
+    "kzg_srs_points": (_U64, [_P]),
+    "kzg_srs_read": (_I, [_P, _I, _U64, _U64, _B]),
+    "kzg_commit": (_I, [_P, _U32, _B, _U64, _I, _B]),
+    "kzg_open": (_I, [_P, _U32, _B, _U64, _I, _B, _B, _B]),
+    "kzg_commit_open": (_I, [_P, _U32, _B, _U64, _I, _B, _B, _B, _B]),
+    "kzg_msm": (_I, [_P, _B, _U64, _U64, _B]),
+    "kzg_ntt": (_I, [_P, _B, _U64, _I]),
+    "kzg_eval": (_I, [_P, _B, _U64, _B, _B]),
+    "kzg_msm_partial": (_I, [_P, _B, _U64, _U64, _B]),
+    "kzg_g1_sum": (_I, [_P, _B, _U32, _B]),
+    "kzg_upload_fr": (_I, [_P, _I, _B, _U64, _I]),
+    "kzg_msm_resident": (_I, [_P, _I, _U64, _U64, _B]),
+    "kzg_msm_partial_resident": (_I, [_P, _I, _U64, _U64, _B]),
+    "kzg_commit_open_resident": (_I, [_P, _U32, _I, _U64, _I, _B, _B, _B, _B]),
+    "kzg_ntt_resident": (_I, [_P, _I, _U64, _I]),
+    "kzg_set_profiling": (_I, [_P, _I]),
+    "kzg_get_timings": (_I, [_P, ctypes.POINTER(ctypes.c_float), _I]),
+    "kzg_msm_plan": (_I, [_P, _U64, ctypes.POINTER(ctypes.c_int32)]),
+    "kzg_b64_decode_fr": (_I, [_B, _U64, _B]),
+    "kzg_b64_encode_fr": (_I, [_B, _U64, _B]),
+    "kzg_test_field": (_I, [_P, _I, _I, _B, _B, _B, _U64]),
+    "kzg_test_g1": (_I, [_P, _I, _B, _B, _B, _U64]),
+}
+
+_lib = None
+
+
+class KzgError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"kzg_mi355x {STATUS_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+def lib_available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def load() -> ctypes.CDLL:
+    """Loads the HIP library; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m zkp_subnet_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

@@ -1,0 +1,189 @@
+"""`Client`: same method surface as the `fourier.Client` the reference miner / validator drive
+(construction: reference base/miner.py:73-84, base/validator.py:80-91; calls: neurons/miner.py:39,48 and
+neurons/validator.py:59-104), backed by the in-process HIP library instead of a spawned Rust binary over
+localhost HTTP.  Every method returns a `Response` usable exactly like the reference uses the HTTP one:
+
+    with client.worker_commit(i, poly) as response:
+        if response.status_code != 200: ...
+        response.json().get("commitment")
+
+Errors never escape as exceptions (the reference checks status_code, neurons/miner.py:40-44): bad input -> 400,
+prover failure -> 500, not implemented -> 501.
+"""
+from __future__ import annotations
+
+import os
+import secrets
+from typing import Any, Dict, List, Optional, Sequence
+
+from . import codec
+from ._native import KZG_E_ARG, KZG_E_POINT, KZG_E_SCALAR, KzgError
+
+R_MODULUS = codec.R_MODULUS
+
+
+class Response:
+    """Minimal stand-in for the HTTP response object of the reference client."""
+
+    def __init__(self, status_code: int, body: Optional[Dict[str, Any]] = None):
+        self.status_code = status_code
+        self._body = body or {}
+
+    def json(self) -> Dict[str, Any]:
+        return self._body
+
+    def __enter__(self) -> "Response":
+        return self
+
+    def __exit__(self, *exc) -> bool:
+        return False
+
+    def close(self) -> None:
+        pass
+
+
+def _guard(fn):
+    def wrapped(self, *a, **kw):
+        try:
+            if self.engine is None:
+                return Response(503, {"error": "prover not started"})
+            return Response(200, fn(self, *a, **kw))
+        except codec.CodecError as e:
+            return Response(400, {"error": str(e)})
+        except KzgError as e:
+            bad_input = e.code in (KZG_E_ARG, KZG_E_SCALAR, KZG_E_POINT)
+            return Response(400 if bad_input else 500, {"error": str(e)})
+        except NotImplementedError as e:
+            return Response(501, {"error": str(e)})
+        except Exception as e:  # never let the axon thread die (reference neurons/miner.py:133-135)
+            return Response(500, {"error": f"{type(e).__name__}: {e}"})
+
+    wrapped.__name__ = fn.__name__
+    wrapped.__doc__ = fn.__doc__
+    return wrapped
+
+
+class Client:
+    """Drop-in for fourier.Client.  `port` and `bin` are accepted and ignored (there is no child process);
+    `setup_path` names a file of uncompressed affine G1 points (x||y, 96 B each, big-endian) holding the
+    2^scale-point SRS; when it does not exist a synthetic tau-derived SRS is generated on the GPU from `seed`
+    (tests / benches -- mirrors `fourier setup --generate-setup`, reference tests/conftest.py:50-65)."""
+
+    def __init__(self, port: int = 1337, bin: str = "", uncompressed: bool = True, setup_path: str = "",
+                 precompute_path: str = "", engine: Any = None, device: int = 0, seed: Optional[int] = None,
+                 workers: Optional[Sequence[int]] = None):
+        self.port, self.bin, self.uncompressed = port, bin, uncompressed
+        self.setup_path, self.precompute_path = setup_path, precompute_path
+        self.engine = engine
+        self._own_engine = engine is None
+        self.device = device
+        self.seed = seed
+        self.workers = list(workers) if workers is not None else None
+        self.scale = self.machines_scale = 0
+
+    # ------------------------------------------------------------------ lifecycle (base/miner.py:82-84,155,181)
+    def start(self, scale: int = 18, machines_scale: int = 8) -> None:
+        if scale < machines_scale:
+            raise ValueError("scale must be >= machines_scale")
+        self.scale, self.machines_scale = scale, machines_scale
+        if self.engine is None:
+            from .engine import HipEngine  # raises loudly without the HIP library / a gfx950 device
+
+            self.engine = HipEngine(self.device)
+        if self.setup_path and os.path.exists(self.setup_path):
+            with open(self.setup_path, "rb") as f:
+                data = f.read()
+            if len(data) % 96:
+                raise ValueError("setup file must be a whole number of 96-byte affine G1 points")
+            self.engine.load_srs(data, scale, machines_scale)
+            self._slice_of = None
+        else:
+            seed = self.seed if self.seed is not None else 0
+            tau_x, tau_y = derive_taus(seed)
+            self.tau_x, self.tau_y = tau_x, tau_y
+            self.engine.gen_srs(tau_x, tau_y, scale, machines_scale, self.workers)
+            self._slice_of = {w: k for k, w in enumerate(self.workers)} if self.workers is not None else None
+
+    def stop(self) -> None:
+        if self.engine is not None and self._own_engine:
+            self.engine.close()
+        if self._own_engine:
+            self.engine = None
+
+    def _slice(self, i: int) -> int:
+        i = int(i)
+        if i < 0 or i >= (1 << self.machines_scale):
+            raise codec.CodecError(f"worker index {i} outside [0, 2^{self.machines_scale})")
+        if self._slice_of is not None:
+            if i not in self._slice_of:
+                raise codec.CodecError(f"worker index {i} has no resident SRS slice")
+            return self._slice_of[i]
+        return i
+
+    # ------------------------------------------------------------------ miner side (neurons/miner.py:38-61)
+    @_guard
+    def worker_commit(self, i: int, poly: Sequence[str]):
+        row = codec.fr_list_to_be32(poly)
+        return {"commitment": codec.g1_to_b64(self.engine.commit(self._slice(i), row, True))}
+
+    @_guard
+    def worker_open(self, i: int, poly: Sequence[str], x: str):
+        row = codec.fr_list_to_be32(poly)
+        ev, pf = self.engine.open(self._slice(i), row, codec.fr_to_be32(x), True)
+        return {"eval": codec.be32_to_fr(ev), "proof": codec.g1_to_b64(pf)}
+
+    @_guard
+    def worker_commit_and_open(self, i: int, poly: Sequence[str], x: str):
+        """Fused extension (one upload, one IFFT): what Miner.rpc_commit_and_open needs (neurons/miner.py:56-61)."""
+        row = codec.fr_list_to_be32(poly)
+        c, ev, pf = self.engine.commit_open(self._slice(i), row, codec.fr_to_be32(x), True)
+        return {"commitment": codec.g1_to_b64(c), "eval": codec.be32_to_fr(ev), "proof": codec.g1_to_b64(pf)}
+
+    # ------------------------------------------------------------------ validator side (neurons/validator.py:58-104)
+    @_guard
+    def worker_verify(self, i: int, proof: str, alpha: str, eval: str, commitment: str):
+        verify = getattr(self.engine, "verify", None)
+        if verify is None:
+            raise NotImplementedError("worker_verify (pairing check) is not built yet: SURVEY 8f rank 1")
+        ok = verify(self._slice(i), codec.g1_from_b64(proof), codec.fr_to_be32(alpha), codec.fr_to_be32(eval),
+                    codec.g1_from_b64(commitment))
+        return {"valid": bool(ok)}
+
+    @_guard
+    def fft(self, poly: Sequence[str], left: bool = True, inverse: bool = False):
+        n = len(poly)
+        want = 1 << (self.scale - self.machines_scale) if left else 1 << self.machines_scale
+        if self.scale and n != want:
+            raise codec.CodecError(f"fft(left={left}) expects {want} elements, got {n}")
+        out = self.engine.ntt(codec.fr_list_to_be32(poly), bool(inverse))
+        return {"poly": codec.be32_to_fr_list(out)}
+
+    @_guard
+    def eval(self, poly: Sequence[str], x: str):
+        y = self.engine.eval(codec.fr_list_to_be32(poly), codec.fr_to_be32(x))
+        return {"y": codec.be32_to_fr(y)}
+
+    @_guard
+    def random_poly(self):
+        """Bivariate polynomial as 2^machines_scale rows of 2^(scale-machines_scale) Fr (neurons/validator.py:67-75)."""
+        rows, T = 1 << self.machines_scale, 1 << (self.scale - self.machines_scale)
+        return {"poly": [[codec.be32_to_fr(_random_fr()) for _ in range(T)] for _ in range(rows)]}
+
+    @_guard
+    def random_point(self):
+        return {"point": codec.be32_to_fr(_random_fr())}
+
+
+def _random_fr() -> bytes:
+    return (secrets.randbelow(R_MODULUS)).to_bytes(32, "big")
+
+
+def derive_taus(seed: int):
+    """Deterministic (tau_x, tau_y) for synthetic SRS generation: SHA-256 counter stream reduced mod r."""
+    import hashlib
+
+    def h(tag: bytes) -> int:
+        v = int.from_bytes(hashlib.sha256(b"kzg-mi355x-srs" + tag + seed.to_bytes(8, "big")).digest(), "big")
+        return v % (R_MODULUS - 2) + 2
+
+    return h(b"x"), h(b"y")

@@ -1,0 +1,908 @@
+// C-ABI of libkzg_mi355x.so (declared in include/kzg_mi355x.h): context, resident SRS + window tables,
+// workspace, and the host-side sequencing of the HIP kernels.  The seam it fills is the prover client of the
+// reference miner (reference base/miner.py:73-84 lifecycle; neurons/miner.py:38-61 commit / open).
+// No CPU arithmetic fallback exists here: if HIP fails, the call fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/kzg_mi355x.h"
+#include "fr_kernels.cuh"
+#include "msm.cuh"
+
+#define KZG_VERSION "kzg_mi355x 0.1 (gfx950)"
+#define N_SLOTS 4
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + (bytes >> 3) + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            e = hipMalloc(&p, bytes);
+            want = bytes;
+        }
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct StageSpan {
+    int stage;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct kzg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err;
+    int c_user = 0, c = 0, nwin = 0;
+    uint32_t nbuckets = 0;
+    // resident SRS + window tables: table[w*stride + j] = 2^(c*w) P_j
+    DevBuf table;
+    uint64_t stride = 0, T = 0;
+    int scale = 0, mscale = 0;
+    // workspace
+    DevBuf in_be, scal, rank, sorted, hist, offsets, bufA, bufB, carries, carry_key, res, coeffA, coeffB, qbuf, hbuf,
+        hnext, small, out_be;
+    DevBuf slot[N_SLOTS];
+    uint64_t slot_n[N_SLOTS] = {0, 0, 0, 0};
+    int slot_mont[N_SLOTS] = {0, 0, 0, 0};
+    std::map<int, DevBuf> tw_fwd, tw_inv, inv_n;
+    uint32_t* flags = nullptr;   // device: [0] bad scalar, [1] bad point
+    uint8_t* host_pin = nullptr; // pinned staging for small results
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<StageSpan> spans;
+    float tms[KZG_T_COUNT] = {0};
+};
+
+namespace {
+
+int fail(kzg_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+#define HIPCHK(ctx, expr)                                                                                   \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess)                                                                               \
+            return fail(ctx, _e == hipErrorOutOfMemory ? KZG_E_NOMEM : KZG_E_HIP,                           \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                                 \
+    } while (0)
+
+hipEvent_t prof_event(kzg_ctx* c) {
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        c->ev_pool.push_back(e);
+    }
+    return c->ev_pool[c->ev_used++];
+}
+struct Span {
+    kzg_ctx* ctx;
+    int idx = -1;
+    Span(kzg_ctx* c, int stage) : ctx(c) {
+        if (!c->profiling) return;
+        StageSpan s{stage, prof_event(c), prof_event(c)};
+        (void)hipEventRecord(s.a, c->stream);
+        c->spans.push_back(s);
+        idx = (int)c->spans.size() - 1;
+    }
+    ~Span() {
+        if (idx >= 0) (void)hipEventRecord(ctx->spans[idx].b, ctx->stream);
+    }
+};
+// opens the KZG_T_TOTAL span; finish() closes it just before the final synchronise
+void prof_begin(kzg_ctx* ctx) {
+    ctx->spans.clear();
+    ctx->ev_used = 0;
+    for (float& t : ctx->tms) t = 0.f;
+    if (!ctx->profiling) return;
+    StageSpan s{KZG_T_TOTAL, prof_event(ctx), prof_event(ctx)};
+    (void)hipEventRecord(s.a, ctx->stream);
+    ctx->spans.push_back(s);
+}
+void prof_end(kzg_ctx* ctx) {  // stream already synchronised
+    if (!ctx->profiling) return;
+    for (auto& s : ctx->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) ctx->tms[s.stage] += ms;
+    }
+}
+
+int choose_window(uint64_t T) {
+    int lg = 0;
+    while (((uint64_t)1 << (lg + 1)) <= T) lg++;
+    if (lg <= 9) return 8;
+    if (lg <= 12) return 10;
+    if (lg <= 15) return 12;
+    if (lg <= 18) return 14;
+    if (lg <= 22) return 16;
+    return 18;
+}
+void set_window(kzg_ctx* ctx, int c) {
+    ctx->c = c;
+    ctx->nwin = (256 + c - 1) / c;
+    ctx->nbuckets = 1u << (c - 1);
+}
+int pick_chunk(uint64_t entries) {
+    uint64_t k = (entries + 131071) / 131072;  // ~2 waves per SIMD on 256 CUs
+    if (k < 8) k = 8;
+    if (k > 512) k = 512;
+    return (int)k;
+}
+int ilog2_exact(uint64_t n) {
+    if (!n || (n & (n - 1))) return -1;
+    int l = 0;
+    while (((uint64_t)1 << l) < n) l++;
+    return l;
+}
+
+// ---- the MSM pipeline on device-resident scalars -> one XYZZ point at out_xyzz (device)
+int msm_core(kzg_ctx* ctx, const uint32_t* scalars, int mont, uint64_t n, uint64_t srs_offset, g1_xyzz_t* out_xyzz) {
+    hipStream_t s = ctx->stream;
+    if (n == 0) {
+        HIPCHK(ctx, hipMemsetAsync(out_xyzz, 0, sizeof(g1_xyzz_t), s));
+        return KZG_OK;
+    }
+    if (srs_offset + n > ctx->stride) return fail(ctx, KZG_E_ARG, "MSM range exceeds the resident SRS");
+    const uint64_t entries = n * (uint64_t)ctx->nwin;
+    if (entries >= ((uint64_t)1 << 32)) return fail(ctx, KZG_E_ARG, "MSM too large for 32-bit entry indices");
+    MsmShape sh;
+    sh.c = ctx->c; sh.nwin = ctx->nwin; sh.nbuckets = ctx->nbuckets; sh.n = n;
+    sh.srs_offset = srs_offset; sh.srs_stride = ctx->stride; sh.chunk = pick_chunk(entries);
+    const uint32_t nchunks = (uint32_t)((entries + sh.chunk - 1) / sh.chunk);
+    const size_t B = ctx->nbuckets;
+    HIPCHK(ctx, ctx->rank.ensure(entries * 4));
+    HIPCHK(ctx, ctx->sorted.ensure(entries * 4));
+    HIPCHK(ctx, ctx->hist.ensure(B * 4));
+    HIPCHK(ctx, ctx->offsets.ensure((B + 1) * 4));
+    HIPCHK(ctx, ctx->bufA.ensure(B * sizeof(g1_xyzz_t)));
+    HIPCHK(ctx, ctx->bufB.ensure(B * sizeof(g1_xyzz_t)));
+    HIPCHK(ctx, ctx->carries.ensure((size_t)nchunks * sizeof(g1_xyzz_t)));
+    HIPCHK(ctx, ctx->carry_key.ensure((size_t)nchunks * 4));
+    {
+        Span sp(ctx, KZG_T_DIGITS);
+        HIPCHK(ctx, hipMemsetAsync(ctx->hist.p, 0, B * 4, s));
+        HIPCHK(ctx, hipMemsetAsync(ctx->bufA.p, 0, B * sizeof(g1_xyzz_t), s));
+        launch_msm_digits_hist(s, sh, scalars, mont, ctx->hist.as<uint32_t>(), ctx->rank.as<uint32_t>());
+    }
+    {
+        Span sp(ctx, KZG_T_SCAN);
+        launch_msm_scan(s, sh, ctx->hist.as<uint32_t>(), ctx->offsets.as<uint32_t>());
+    }
+    {
+        Span sp(ctx, KZG_T_SCATTER);
+        launch_msm_scatter(s, sh, scalars, mont, ctx->offsets.as<uint32_t>(), ctx->rank.as<uint32_t>(),
+                           ctx->sorted.as<uint32_t>());
+    }
+    {
+        Span sp(ctx, KZG_T_ACCUMULATE);
+        launch_msm_accumulate(s, sh, ctx->table.as<g1_affine_t>(), ctx->offsets.as<uint32_t>(),
+                              ctx->sorted.as<uint32_t>(), ctx->bufA.as<g1_xyzz_t>(), ctx->carries.as<g1_xyzz_t>(),
+                              ctx->carry_key.as<uint32_t>(), nchunks);
+    }
+    {
+        Span sp(ctx, KZG_T_FIXUP);
+        launch_msm_fixup(s, ctx->bufA.as<g1_xyzz_t>(), ctx->carries.as<g1_xyzz_t>(), ctx->carry_key.as<uint32_t>(),
+                         nchunks);
+    }
+    g1_xyzz_t* in = ctx->bufA.as<g1_xyzz_t>();
+    g1_xyzz_t* out = ctx->bufB.as<g1_xyzz_t>();
+    {
+        Span sp(ctx, KZG_T_TREE);
+        uint32_t n_in = ctx->nbuckets;
+        for (int level = 0; n_in > 1; level++, n_in >>= 1) {
+            launch_msm_tree_level(s, in, out, n_in, level);
+            std::swap(in, out);
+        }
+    }
+    {
+        Span sp(ctx, KZG_T_FINAL);
+        launch_msm_final(s, in, ctx->c - 1, out_xyzz);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return KZG_OK;
+}
+
+int need_srs(kzg_ctx* ctx) {
+    if (!ctx->table.p || !ctx->stride) return fail(ctx, KZG_E_ARG, "no SRS resident: call kzg_load_srs / kzg_gen_srs");
+    return KZG_OK;
+}
+int clear_flags(kzg_ctx* ctx) {
+    HIPCHK(ctx, hipMemsetAsync(ctx->flags, 0, 16, ctx->stream));
+    return KZG_OK;
+}
+// results staged in host_pin: [0..16) flags, then payload
+int finish(kzg_ctx* ctx) {
+    if (ctx->profiling && !ctx->spans.empty() && ctx->spans[0].stage == KZG_T_TOTAL)
+        (void)hipEventRecord(ctx->spans[0].b, ctx->stream);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin, ctx->flags, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    prof_end(ctx);
+    const uint32_t* f = reinterpret_cast<const uint32_t*>(ctx->host_pin);
+    if (f[0]) return fail(ctx, KZG_E_SCALAR, "non-canonical Fr scalar (>= r)");
+    if (f[1]) return fail(ctx, KZG_E_POINT, "G1 input not reduced or not on the curve");
+    return KZG_OK;
+}
+int ensure_twiddles(kzg_ctx* ctx, int log_n, int inverse, uint32_t** tw, uint32_t** invn) {
+    auto& m = inverse ? ctx->tw_inv : ctx->tw_fwd;
+    if (log_n >= 1 && !m.count(log_n)) {
+        DevBuf b;
+        HIPCHK(ctx, b.ensure(((size_t)1 << (log_n - 1)) * 32));
+        launch_fr_twiddles(ctx->stream, b.as<uint32_t>(), log_n, inverse);
+        m[log_n] = b;
+    }
+    *tw = log_n >= 1 ? m[log_n].as<uint32_t>() : nullptr;
+    if (invn) {
+        if (!ctx->inv_n.count(log_n)) {
+            DevBuf b;
+            HIPCHK(ctx, b.ensure(32));
+            launch_fr_inv_pow2(ctx->stream, b.as<uint32_t>(), log_n);
+            ctx->inv_n[log_n] = b;
+        }
+        *invn = ctx->inv_n[log_n].as<uint32_t>();
+    }
+    return KZG_OK;
+}
+// coefficients (Montgomery) of the row; returns pointer in *coeffs.  row_dev: Montgomery-form row.
+int row_to_coeffs(kzg_ctx* ctx, const uint32_t* row_dev, uint64_t T, int evaluation_form, const uint32_t** coeffs) {
+    if (!evaluation_form || T == 1) {
+        *coeffs = row_dev;
+        return KZG_OK;
+    }
+    int lg = ilog2_exact(T);
+    if (lg < 0) return fail(ctx, KZG_E_ARG, "evaluation-form row length must be a power of two");
+    uint32_t *tw, *invn;
+    int rc = ensure_twiddles(ctx, lg, 1, &tw, &invn);
+    if (rc) return rc;
+    HIPCHK(ctx, ctx->coeffB.ensure(T * 32));
+    Span sp(ctx, KZG_T_NTT);
+    launch_fr_ntt(ctx->stream, row_dev, ctx->coeffB.as<uint32_t>(), lg, tw, invn);
+    *coeffs = ctx->coeffB.as<uint32_t>();
+    return KZG_OK;
+}
+int check_worker(kzg_ctx* ctx, uint32_t i, uint64_t T) {
+    int rc = need_srs(ctx);
+    if (rc) return rc;
+    if (T == 0) return fail(ctx, KZG_E_ARG, "empty polynomial");
+    if (T > ctx->T) return fail(ctx, KZG_E_ARG, "polynomial longer than the worker's SRS slice");
+    if ((uint64_t)i * ctx->T + ctx->T > ctx->stride) return fail(ctx, KZG_E_ARG, "worker index outside the resident SRS");
+    return KZG_OK;
+}
+// upload BE scalars to `dst` (device limbs); dst must hold n*32 bytes
+int upload_fr(kzg_ctx* ctx, const uint8_t* be32, uint64_t n, uint32_t* dst, int to_mont) {
+    if (!n) return KZG_OK;
+    HIPCHK(ctx, ctx->in_be.ensure(n * 32));
+    Span sp(ctx, KZG_T_DECODE);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->in_be.p, be32, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    launch_fr_from_be(ctx->stream, ctx->in_be.as<uint8_t>(), dst, n, to_mont, ctx->flags);
+    return KZG_OK;
+}
+
+// commit and/or open on a device-resident Montgomery row
+int commit_open_dev(kzg_ctx* ctx, uint32_t i, const uint32_t* row_dev, uint64_t T, int evaluation_form,
+                    const uint8_t* alpha_be32, uint8_t* out_c48, uint8_t* out_eval32, uint8_t* out_p48) {
+    hipStream_t s = ctx->stream;
+    const uint32_t* coeffs = nullptr;
+    int rc = row_to_coeffs(ctx, row_dev, T, evaluation_form, &coeffs);
+    if (rc) return rc;
+    HIPCHK(ctx, ctx->res.ensure(4 * sizeof(g1_xyzz_t)));
+    HIPCHK(ctx, ctx->small.ensure(1024));
+    uint8_t* small = ctx->small.as<uint8_t>();  // [0,48) commitment [64,112) proof [128,160) eval be [192..) alpha/y limbs
+    const uint64_t offset = (uint64_t)i * ctx->T;
+    if (out_c48) {
+        rc = msm_core(ctx, coeffs, 1, T, offset, ctx->res.as<g1_xyzz_t>());
+        if (rc) return rc;
+        Span sp(ctx, KZG_T_FINAL);
+        launch_g1_compress(s, ctx->res.as<g1_xyzz_t>(), small);
+    }
+    if (out_p48) {
+        uint32_t* alpha_m = reinterpret_cast<uint32_t*>(small + 192);
+        uint32_t* y_m = reinterpret_cast<uint32_t*>(small + 256);
+        HIPCHK(ctx, hipMemcpyAsync(small + 320, alpha_be32, 32, hipMemcpyHostToDevice, s));
+        launch_fr_from_be(s, small + 320, alpha_m, 1, 1, ctx->flags);
+        const uint64_t nchunks = (T + 63) / 64;
+        HIPCHK(ctx, ctx->hbuf.ensure(nchunks * 32));
+        HIPCHK(ctx, ctx->hnext.ensure(nchunks * 32));
+        HIPCHK(ctx, ctx->qbuf.ensure(T * 32));
+        {
+            Span sp(ctx, KZG_T_POLY);
+            launch_poly_open(s, coeffs, T, alpha_m, ctx->hbuf.as<uint32_t>(), ctx->hnext.as<uint32_t>(), y_m,
+                             ctx->qbuf.as<uint32_t>());
+            launch_fr_to_be(s, y_m, small + 128, 1, 1);
+        }
+        rc = msm_core(ctx, ctx->qbuf.as<uint32_t>(), 0, T - 1, offset, ctx->res.as<g1_xyzz_t>() + 1);
+        if (rc) return rc;
+        Span sp(ctx, KZG_T_FINAL);
+        launch_g1_compress(s, ctx->res.as<g1_xyzz_t>() + 1, small + 64);
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, small, 192, hipMemcpyDeviceToHost, s));
+    rc = finish(ctx);
+    if (rc) return rc;
+    if (out_c48) memcpy(out_c48, ctx->host_pin + 64, 48);
+    if (out_p48) {
+        memcpy(out_p48, ctx->host_pin + 64 + 64, 48);
+        memcpy(out_eval32, ctx->host_pin + 64 + 128, 32);
+    }
+    return KZG_OK;
+}
+
+int alloc_table(kzg_ctx* ctx, uint64_t n_points, int scale, int mscale) {
+    if (mscale < 0 || scale < mscale || scale - mscale > 30) return fail(ctx, KZG_E_ARG, "bad scale / machines_scale");
+    const uint64_t T = (uint64_t)1 << (scale - mscale);
+    if (n_points == 0 || n_points % T) return fail(ctx, KZG_E_ARG, "SRS length must be a whole number of worker slices");
+    set_window(ctx, ctx->c_user ? ctx->c_user : choose_window(T));
+    if ((uint64_t)ctx->nwin * n_points >= ((uint64_t)1 << 31))
+        return fail(ctx, KZG_E_ARG, "SRS x windows exceeds 2^31 table entries");
+    ctx->table.release();
+    HIPCHK(ctx, ctx->table.ensure((size_t)ctx->nwin * n_points * sizeof(g1_affine_t)));
+    ctx->stride = n_points; ctx->T = T; ctx->scale = scale; ctx->mscale = mscale;
+    return KZG_OK;
+}
+int precompute_tables(kzg_ctx* ctx) {
+    const uint64_t tile = ctx->stride < ((uint64_t)1 << 20) ? ctx->stride : ((uint64_t)1 << 20);
+    DevBuf tmp;
+    HIPCHK(ctx, tmp.ensure((size_t)(ctx->nwin - 1) * tile * sizeof(g1_xyzz_t) + 256));
+    for (uint64_t first = 0; first < ctx->stride; first += tile) {
+        uint64_t cnt = ctx->stride - first < tile ? ctx->stride - first : tile;
+        launch_srs_precompute(ctx->stream, ctx->table.as<g1_affine_t>(), ctx->stride, first, cnt, ctx->c, ctx->nwin,
+                              tmp.as<g1_xyzz_t>());
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    tmp.release();
+    HIPCHK(ctx, e);
+    HIPCHK(ctx, hipGetLastError());
+    return KZG_OK;
+}
+
+// ---- unit-op test kernels
+template <class P>
+__global__ void __launch_bounds__(256) k_test_field(int op, const uint8_t* a_be, const uint8_t* b_be, uint8_t* out_be,
+                                                     uint64_t n) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    constexpr int N = P::N;
+    field_t<P> a, b, r;
+    limbs_from_be<N>(a.l, a_be + 4 * N * j);
+    limbs_from_be<N>(b.l, b_be + 4 * N * j);
+    f_to_mont(a, a);
+    f_to_mont(b, b);
+    if (op == 0) f_mul(r, a, b);
+    else if (op == 1) f_add(r, a, b);
+    else if (op == 2) f_sub(r, a, b);
+    else f_mul_inline(r, a, b);
+    f_from_mont(r, r);
+    limbs_to_be<N>(out_be + 4 * N * j, r.l);
+}
+__global__ void __launch_bounds__(256) k_test_g1(int op, const uint8_t* a_be, const uint8_t* b_be, uint8_t* out_be,
+                                                  uint64_t n) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    g1_affine_t a, b, o;
+    limbs_from_be<12>(a.x.l, a_be + 96 * j); limbs_from_be<12>(a.y.l, a_be + 96 * j + 48);
+    limbs_from_be<12>(b.x.l, b_be + 96 * j); limbs_from_be<12>(b.y.l, b_be + 96 * j + 48);
+    f_to_mont(a.x, a.x); f_to_mont(a.y, a.y); f_to_mont(b.x, b.x); f_to_mont(b.y, b.y);
+    g1_xyzz_t pa, pb, r, t;
+    g1_from_affine(pa, a);
+    g1_from_affine(pb, b);
+    if (op == 0) { r = pa; g1_madd_checked(r, b); }
+    else if (op == 1) { g1_dbl(t, pa); g1_add(r, t, pb); }
+    else if (op == 2) { g1_dbl(r, pa); }
+    else { g1_dbl(t, pa); g1_dbl(r, t); }
+    g1_to_affine(o, r);
+    fp_t x, y;
+    f_from_mont(x, o.x); f_from_mont(y, o.y);
+    limbs_to_be<12>(out_be + 96 * j, x.l); limbs_to_be<12>(out_be + 96 * j + 48, y.l);
+}
+
+const char B64[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+int8_t b64_rev[256];
+bool b64_init_done = false;
+void b64_init() {
+    if (b64_init_done) return;
+    memset(b64_rev, -1, sizeof(b64_rev));
+    for (int i = 0; i < 64; i++) b64_rev[(uint8_t)B64[i]] = (int8_t)i;
+    b64_init_done = true;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+const char* kzg_version(void) { return KZG_VERSION; }
+
+int kzg_create(int device_id, kzg_ctx** out) {
+    if (!out) return KZG_E_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count) return KZG_E_HIP;
+    if (hipSetDevice(device_id) != hipSuccess) return KZG_E_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return KZG_E_HIP;
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) return KZG_E_HIP;  // built for gfx950 only
+    kzg_ctx* ctx = new kzg_ctx();
+    ctx->device = device_id;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&ctx->flags, 16) != hipSuccess ||
+        hipHostMalloc((void**)&ctx->host_pin, 4096, hipHostMallocDefault) != hipSuccess) {
+        delete ctx;
+        return KZG_E_HIP;
+    }
+    *out = ctx;
+    return KZG_OK;
+}
+
+void kzg_destroy(kzg_ctx* ctx) {
+    if (!ctx) return;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        DevBuf* bufs[] = {&ctx->table, &ctx->in_be, &ctx->scal, &ctx->rank, &ctx->sorted, &ctx->hist, &ctx->offsets,
+                          &ctx->bufA, &ctx->bufB, &ctx->carries, &ctx->carry_key, &ctx->res, &ctx->coeffA,
+                          &ctx->coeffB, &ctx->qbuf, &ctx->hbuf, &ctx->hnext, &ctx->small, &ctx->out_be};
+        for (DevBuf* b : bufs) b->release();
+        for (auto& b : ctx->slot) b.release();
+        for (auto* m : {&ctx->tw_fwd, &ctx->tw_inv, &ctx->inv_n})
+            for (auto& kv : *m) kv.second.release();
+        for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+        if (ctx->flags) (void)hipFree(ctx->flags);
+        if (ctx->host_pin) (void)hipHostFree(ctx->host_pin);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+}
+
+const char* kzg_last_error(kzg_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int kzg_set_window(kzg_ctx* ctx, int c) {
+    if (!ctx) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (c != 0 && (c < 4 || c > 22)) return fail(ctx, KZG_E_ARG, "window bits must be 0 (auto) or in [4, 22]");
+    if (ctx->table.p) return fail(ctx, KZG_E_ARG, "window must be set before the SRS is loaded");
+    ctx->c_user = c;
+    return KZG_OK;
+}
+int kzg_get_window(kzg_ctx* ctx) { return ctx ? ctx->c : 0; }
+uint64_t kzg_srs_points(kzg_ctx* ctx) { return ctx ? ctx->stride : 0; }
+
+int kzg_load_srs(kzg_ctx* ctx, const uint8_t* g1_affine_be96, uint64_t n_points, int scale, int machines_scale) {
+    if (!ctx || !g1_affine_be96) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = alloc_table(ctx, n_points, scale, machines_scale);
+    if (rc) return rc;
+    rc = clear_flags(ctx);
+    if (rc) return rc;
+    const uint64_t tile = (uint64_t)1 << 20;
+    HIPCHK(ctx, ctx->in_be.ensure((n_points < tile ? n_points : tile) * 96));
+    for (uint64_t first = 0; first < n_points; first += tile) {
+        uint64_t cnt = n_points - first < tile ? n_points - first : tile;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->in_be.p, g1_affine_be96 + 96 * first, cnt * 96, hipMemcpyHostToDevice,
+                                   ctx->stream));
+        launch_srs_from_be96(ctx->stream, ctx->in_be.as<uint8_t>(), ctx->table.as<g1_affine_t>() + first, cnt,
+                             ctx->flags + 1);
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    rc = finish(ctx);
+    if (rc) {
+        ctx->table.release();
+        ctx->stride = 0;
+        return rc;
+    }
+    return precompute_tables(ctx);
+}
+
+int kzg_gen_srs(kzg_ctx* ctx, const uint8_t tau_be32[32], const uint8_t* s0_be32, uint32_t n_slices, int scale,
+                int machines_scale) {
+    if (!ctx || !tau_be32 || !s0_be32 || !n_slices) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (machines_scale < 0 || scale < machines_scale || scale - machines_scale > 30)
+        return fail(ctx, KZG_E_ARG, "bad scale / machines_scale");
+    const uint64_t T = (uint64_t)1 << (scale - machines_scale);
+    int rc = alloc_table(ctx, (uint64_t)n_slices * T, scale, machines_scale);
+    if (rc) return rc;
+    rc = clear_flags(ctx);
+    if (rc) return rc;
+    DevBuf gtab, tmp, sc;
+    HIPCHK(ctx, gtab.ensure(32 * 255 * sizeof(g1_affine_t)));
+    const uint64_t tile = T < ((uint64_t)1 << 20) ? T : ((uint64_t)1 << 20);
+    HIPCHK(ctx, tmp.ensure(tile * (sizeof(g1_xyzz_t) + 32) + 256));
+    HIPCHK(ctx, sc.ensure(((size_t)n_slices + 1) * 32 + 64));
+    // tau and the per-slice factors, Montgomery form, on device
+    uint32_t* tau_m = sc.as<uint32_t>();
+    HIPCHK(ctx, ctx->in_be.ensure(((size_t)n_slices + 1) * 32));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->in_be.p, tau_be32, 32, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->in_be.as<uint8_t>() + 32, s0_be32, (size_t)n_slices * 32, hipMemcpyHostToDevice,
+                               ctx->stream));
+    launch_fr_from_be(ctx->stream, ctx->in_be.as<uint8_t>(), tau_m, (uint64_t)n_slices + 1, 1, ctx->flags);
+    for (uint32_t k = 0; k < n_slices; k++) {
+        for (uint64_t first = 0; first < T; first += tile) {
+            uint64_t cnt = T - first < tile ? T - first : tile;
+            launch_srs_generate(ctx->stream, ctx->table.as<g1_affine_t>() + (uint64_t)k * T + first, cnt, first, tau_m,
+                                tau_m + 8 * (1 + (uint64_t)k), gtab.as<g1_affine_t>(), tmp.as<g1_xyzz_t>(),
+                                k == 0 && first == 0);
+        }
+    }
+    rc = finish(ctx);
+    gtab.release(); tmp.release(); sc.release();
+    if (rc) return rc;
+    HIPCHK(ctx, hipGetLastError());
+    return precompute_tables(ctx);
+}
+
+int kzg_srs_read(kzg_ctx* ctx, int w, uint64_t first, uint64_t count, uint8_t* out_be96) {
+    if (!ctx || !out_be96) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = need_srs(ctx);
+    if (rc) return rc;
+    if (w < 0 || w >= ctx->nwin || first + count > ctx->stride) return fail(ctx, KZG_E_ARG, "srs_read out of range");
+    if (!count) return KZG_OK;
+    HIPCHK(ctx, ctx->out_be.ensure(count * 96));
+    launch_srs_to_be96(ctx->stream, ctx->table.as<g1_affine_t>() + (uint64_t)w * ctx->stride + first,
+                       ctx->out_be.as<uint8_t>(), count);
+    HIPCHK(ctx, hipMemcpyAsync(out_be96, ctx->out_be.p, count * 96, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return KZG_OK;
+}
+
+static int msm_host_common(kzg_ctx* ctx, const uint8_t* scalars_be32, uint64_t n, uint64_t srs_offset, uint8_t* out,
+                           bool partial) {
+    if (!ctx || !out || (n && !scalars_be32)) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = need_srs(ctx);
+    if (rc) return rc;
+    prof_begin(ctx);
+    rc = clear_flags(ctx);
+    if (rc) return rc;
+    HIPCHK(ctx, ctx->scal.ensure(n * 32 + 32));
+    HIPCHK(ctx, ctx->res.ensure(4 * sizeof(g1_xyzz_t)));
+    HIPCHK(ctx, ctx->small.ensure(1024));
+    rc = upload_fr(ctx, scalars_be32, n, ctx->scal.as<uint32_t>(), 0);
+    if (rc) return rc;
+    rc = msm_core(ctx, ctx->scal.as<uint32_t>(), 0, n, srs_offset, ctx->res.as<g1_xyzz_t>());
+    if (rc) return rc;
+    if (partial) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, ctx->res.p, 192, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        launch_g1_compress(ctx->stream, ctx->res.as<g1_xyzz_t>(), ctx->small.as<uint8_t>());
+        HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, ctx->small.p, 48, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    rc = finish(ctx);
+    if (rc) return rc;
+    memcpy(out, ctx->host_pin + 64, partial ? 192 : 48);
+    return KZG_OK;
+}
+int kzg_msm(kzg_ctx* ctx, const uint8_t* scalars_be32, uint64_t n, uint64_t srs_offset, uint8_t out48[48]) {
+    return msm_host_common(ctx, scalars_be32, n, srs_offset, out48, false);
+}
+int kzg_msm_partial(kzg_ctx* ctx, const uint8_t* scalars_be32, uint64_t n, uint64_t srs_offset,
+                    uint8_t out_xyzz192[192]) {
+    return msm_host_common(ctx, scalars_be32, n, srs_offset, out_xyzz192, true);
+}
+
+int kzg_g1_sum(kzg_ctx* ctx, const uint8_t* partials_xyzz192, uint32_t count, uint8_t out48[48]) {
+    if (!ctx || !out48 || (count && !partials_xyzz192)) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, ctx->in_be.ensure((size_t)count * 192 + 192));
+    HIPCHK(ctx, ctx->res.ensure(4 * sizeof(g1_xyzz_t)));
+    HIPCHK(ctx, ctx->small.ensure(1024));
+    int rc = clear_flags(ctx);
+    if (rc) return rc;
+    if (count) HIPCHK(ctx, hipMemcpyAsync(ctx->in_be.p, partials_xyzz192, (size_t)count * 192, hipMemcpyHostToDevice,
+                                          ctx->stream));
+    launch_g1_sum(ctx->stream, ctx->in_be.as<g1_xyzz_t>(), count, ctx->res.as<g1_xyzz_t>());
+    launch_g1_compress(ctx->stream, ctx->res.as<g1_xyzz_t>(), ctx->small.as<uint8_t>());
+    HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, ctx->small.p, 48, hipMemcpyDeviceToHost, ctx->stream));
+    rc = finish(ctx);
+    if (rc) return rc;
+    memcpy(out48, ctx->host_pin + 64, 48);
+    return KZG_OK;
+}
+
+static int commit_open_host(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
+                            const uint8_t* alpha, uint8_t* c48, uint8_t* e32, uint8_t* p48) {
+    if (!ctx || !row_be32 || (p48 && (!alpha || !e32))) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = check_worker(ctx, i, T);
+    if (rc) return rc;
+    prof_begin(ctx);
+    rc = clear_flags(ctx);
+    if (rc) return rc;
+    HIPCHK(ctx, ctx->coeffA.ensure(T * 32));
+    rc = upload_fr(ctx, row_be32, T, ctx->coeffA.as<uint32_t>(), 1);
+    if (rc) return rc;
+    return commit_open_dev(ctx, i, ctx->coeffA.as<uint32_t>(), T, evaluation_form, alpha, c48, e32, p48);
+}
+int kzg_commit(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
+               uint8_t out_commitment48[48]) {
+    if (!out_commitment48) return KZG_E_ARG;
+    return commit_open_host(ctx, i, row_be32, T, evaluation_form, nullptr, out_commitment48, nullptr, nullptr);
+}
+int kzg_open(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
+             const uint8_t alpha_be32[32], uint8_t out_eval32[32], uint8_t out_proof48[48]) {
+    if (!out_proof48) return KZG_E_ARG;
+    return commit_open_host(ctx, i, row_be32, T, evaluation_form, alpha_be32, nullptr, out_eval32, out_proof48);
+}
+int kzg_commit_open(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
+                    const uint8_t alpha_be32[32], uint8_t out_commitment48[48], uint8_t out_eval32[32],
+                    uint8_t out_proof48[48]) {
+    if (!out_commitment48 || !out_proof48) return KZG_E_ARG;
+    return commit_open_host(ctx, i, row_be32, T, evaluation_form, alpha_be32, out_commitment48, out_eval32,
+                            out_proof48);
+}
+
+static int ntt_dev(kzg_ctx* ctx, uint32_t* data, uint64_t n, int inverse) {  // in place via coeffB
+    int lg = ilog2_exact(n);
+    if (lg < 0) return fail(ctx, KZG_E_ARG, "NTT length must be a power of two");
+    uint32_t *tw = nullptr, *invn = nullptr;
+    int rc = ensure_twiddles(ctx, lg, inverse, &tw, inverse ? &invn : nullptr);
+    if (rc) return rc;
+    HIPCHK(ctx, ctx->coeffB.ensure(n * 32));
+    {
+        Span sp(ctx, KZG_T_NTT);
+        launch_fr_ntt(ctx->stream, data, ctx->coeffB.as<uint32_t>(), lg, tw, inverse ? invn : nullptr);
+        HIPCHK(ctx, hipMemcpyAsync(data, ctx->coeffB.p, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return KZG_OK;
+}
+int kzg_ntt(kzg_ctx* ctx, uint8_t* inout_be32, uint64_t n, int inverse) {
+    if (!ctx || !inout_be32 || !n) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    prof_begin(ctx);
+    int rc = clear_flags(ctx);
+    if (rc) return rc;
+    HIPCHK(ctx, ctx->coeffA.ensure(n * 32));
+    HIPCHK(ctx, ctx->out_be.ensure(n * 32));
+    rc = upload_fr(ctx, inout_be32, n, ctx->coeffA.as<uint32_t>(), 1);
+    if (rc) return rc;
+    rc = ntt_dev(ctx, ctx->coeffA.as<uint32_t>(), n, inverse);
+    if (rc) return rc;
+    launch_fr_to_be(ctx->stream, ctx->coeffA.as<uint32_t>(), ctx->out_be.as<uint8_t>(), n, 1);
+    rc = finish(ctx);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpy(inout_be32, ctx->out_be.p, n * 32, hipMemcpyDeviceToHost));
+    return KZG_OK;
+}
+int kzg_eval(kzg_ctx* ctx, const uint8_t* coeffs_be32, uint64_t n, const uint8_t x_be32[32], uint8_t out_be32[32]) {
+    if (!ctx || !x_be32 || !out_be32 || (n && !coeffs_be32)) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (n == 0) {
+        memset(out_be32, 0, 32);
+        return KZG_OK;
+    }
+    prof_begin(ctx);
+    int rc = clear_flags(ctx);
+    if (rc) return rc;
+    HIPCHK(ctx, ctx->coeffA.ensure(n * 32));
+    HIPCHK(ctx, ctx->small.ensure(1024));
+    const uint64_t nchunks = (n + 63) / 64;
+    HIPCHK(ctx, ctx->hbuf.ensure(nchunks * 32));
+    HIPCHK(ctx, ctx->hnext.ensure(nchunks * 32));
+    rc = upload_fr(ctx, coeffs_be32, n, ctx->coeffA.as<uint32_t>(), 1);
+    if (rc) return rc;
+    uint8_t* small = ctx->small.as<uint8_t>();
+    uint32_t* x_m = reinterpret_cast<uint32_t*>(small + 192);
+    uint32_t* y_m = reinterpret_cast<uint32_t*>(small + 256);
+    HIPCHK(ctx, hipMemcpyAsync(small + 320, x_be32, 32, hipMemcpyHostToDevice, ctx->stream));
+    launch_fr_from_be(ctx->stream, small + 320, x_m, 1, 1, ctx->flags);
+    launch_poly_open(ctx->stream, ctx->coeffA.as<uint32_t>(), n, x_m, ctx->hbuf.as<uint32_t>(),
+                     ctx->hnext.as<uint32_t>(), y_m, nullptr);
+    launch_fr_to_be(ctx->stream, y_m, small + 128, 1, 1);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, small + 128, 32, hipMemcpyDeviceToHost, ctx->stream));
+    rc = finish(ctx);
+    if (rc) return rc;
+    memcpy(out_be32, ctx->host_pin + 64, 32);
+    return KZG_OK;
+}
+
+int kzg_upload_fr(kzg_ctx* ctx, int slot, const uint8_t* be32, uint64_t n, int to_mont) {
+    if (!ctx || slot < 0 || slot >= N_SLOTS || (n && !be32)) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    prof_begin(ctx);
+    int rc = clear_flags(ctx);
+    if (rc) return rc;
+    HIPCHK(ctx, ctx->slot[slot].ensure(n * 32 + 32));
+    rc = upload_fr(ctx, be32, n, ctx->slot[slot].as<uint32_t>(), to_mont);
+    if (rc) return rc;
+    rc = finish(ctx);
+    if (rc) return rc;
+    ctx->slot_n[slot] = n;
+    ctx->slot_mont[slot] = to_mont ? 1 : 0;
+    return KZG_OK;
+}
+static int msm_resident_common(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint8_t* out, bool partial) {
+    if (!ctx || !out || slot < 0 || slot >= N_SLOTS) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = need_srs(ctx);
+    if (rc) return rc;
+    if (n > ctx->slot_n[slot]) return fail(ctx, KZG_E_ARG, "slot holds fewer scalars than requested");
+    prof_begin(ctx);
+    rc = clear_flags(ctx);
+    if (rc) return rc;
+    HIPCHK(ctx, ctx->res.ensure(4 * sizeof(g1_xyzz_t)));
+    HIPCHK(ctx, ctx->small.ensure(1024));
+    rc = msm_core(ctx, ctx->slot[slot].as<uint32_t>(), ctx->slot_mont[slot], n, srs_offset, ctx->res.as<g1_xyzz_t>());
+    if (rc) return rc;
+    if (partial) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, ctx->res.p, 192, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        Span sp(ctx, KZG_T_FINAL);
+        launch_g1_compress(ctx->stream, ctx->res.as<g1_xyzz_t>(), ctx->small.as<uint8_t>());
+        HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, ctx->small.p, 48, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    rc = finish(ctx);
+    if (rc) return rc;
+    memcpy(out, ctx->host_pin + 64, partial ? 192 : 48);
+    return KZG_OK;
+}
+int kzg_msm_resident(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint8_t out48[48]) {
+    return msm_resident_common(ctx, slot, n, srs_offset, out48, false);
+}
+int kzg_msm_partial_resident(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint8_t out_xyzz192[192]) {
+    return msm_resident_common(ctx, slot, n, srs_offset, out_xyzz192, true);
+}
+int kzg_commit_open_resident(kzg_ctx* ctx, uint32_t i, int slot, uint64_t T, int evaluation_form,
+                             const uint8_t alpha_be32[32], uint8_t out_commitment48[48], uint8_t out_eval32[32],
+                             uint8_t out_proof48[48]) {
+    if (!ctx || slot < 0 || slot >= N_SLOTS || !alpha_be32 || !out_commitment48 || !out_eval32 || !out_proof48)
+        return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = check_worker(ctx, i, T);
+    if (rc) return rc;
+    if (T > ctx->slot_n[slot] || !ctx->slot_mont[slot])
+        return fail(ctx, KZG_E_ARG, "slot must hold >= T Montgomery-form elements (kzg_upload_fr(.., to_mont=1))");
+    prof_begin(ctx);
+    rc = clear_flags(ctx);
+    if (rc) return rc;
+    return commit_open_dev(ctx, i, ctx->slot[slot].as<uint32_t>(), T, evaluation_form, alpha_be32, out_commitment48,
+                           out_eval32, out_proof48);
+}
+int kzg_ntt_resident(kzg_ctx* ctx, int slot, uint64_t n, int inverse) {
+    if (!ctx || slot < 0 || slot >= N_SLOTS || !n) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (n > ctx->slot_n[slot] || !ctx->slot_mont[slot]) return fail(ctx, KZG_E_ARG, "slot must hold >= n Montgomery elements");
+    prof_begin(ctx);
+    int rc = clear_flags(ctx);
+    if (rc) return rc;
+    rc = ntt_dev(ctx, ctx->slot[slot].as<uint32_t>(), n, inverse);
+    if (rc) return rc;
+    return finish(ctx);
+}
+
+int kzg_set_profiling(kzg_ctx* ctx, int enable) {
+    if (!ctx) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->profiling = enable != 0;
+    return KZG_OK;
+}
+int kzg_get_timings(kzg_ctx* ctx, float* out_ms, int count) {
+    if (!ctx || !out_ms) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (int i = 0; i < count && i < KZG_T_COUNT; i++) out_ms[i] = ctx->tms[i];
+    return KZG_OK;
+}
+int kzg_msm_plan(kzg_ctx* ctx, uint64_t n, int32_t out[4]) {
+    if (!ctx || !out || !ctx->c) return KZG_E_ARG;
+    const uint64_t entries = n * (uint64_t)ctx->nwin;
+    const int chunk = pick_chunk(entries);
+    out[0] = chunk;
+    out[1] = (int32_t)((entries + chunk - 1) / chunk);
+    out[2] = (int32_t)ctx->nbuckets;
+    out[3] = ctx->nwin;
+    return KZG_OK;
+}
+
+int kzg_b64_decode_fr(const char* packed43, uint64_t n, uint8_t* out_be32) {
+    if ((n && !packed43) || (n && !out_be32)) return KZG_E_ARG;
+    b64_init();
+    for (uint64_t k = 0; k < n; k++) {
+        const uint8_t* s = reinterpret_cast<const uint8_t*>(packed43) + 43 * k;
+        uint8_t* o = out_be32 + 32 * k;
+        int bad = 0;
+        for (int g = 0; g < 10; g++) {
+            int a = b64_rev[s[4 * g]], b = b64_rev[s[4 * g + 1]], c = b64_rev[s[4 * g + 2]], d = b64_rev[s[4 * g + 3]];
+            bad |= (a | b | c | d) < 0;
+            uint32_t v = ((uint32_t)a << 18) | ((uint32_t)b << 12) | ((uint32_t)c << 6) | (uint32_t)d;
+            o[3 * g] = (uint8_t)(v >> 16); o[3 * g + 1] = (uint8_t)(v >> 8); o[3 * g + 2] = (uint8_t)v;
+        }
+        int a = b64_rev[s[40]], b = b64_rev[s[41]], c = b64_rev[s[42]];
+        bad |= (a | b | c) < 0;
+        uint32_t v = ((uint32_t)a << 12) | ((uint32_t)b << 6) | (uint32_t)c;  // 18 bits, low 2 must be zero
+        bad |= (v & 3u) != 0;
+        o[30] = (uint8_t)(v >> 10); o[31] = (uint8_t)(v >> 2);
+        if (bad) return KZG_E_SCALAR;
+    }
+    return KZG_OK;
+}
+int kzg_b64_encode_fr(const uint8_t* be32, uint64_t n, char* out_packed43) {
+    if ((n && !be32) || (n && !out_packed43)) return KZG_E_ARG;
+    for (uint64_t k = 0; k < n; k++) {
+        const uint8_t* i = be32 + 32 * k;
+        char* o = out_packed43 + 43 * k;
+        for (int g = 0; g < 10; g++) {
+            uint32_t v = ((uint32_t)i[3 * g] << 16) | ((uint32_t)i[3 * g + 1] << 8) | i[3 * g + 2];
+            o[4 * g] = B64[v >> 18]; o[4 * g + 1] = B64[(v >> 12) & 63]; o[4 * g + 2] = B64[(v >> 6) & 63];
+            o[4 * g + 3] = B64[v & 63];
+        }
+        uint32_t v = (((uint32_t)i[30] << 8) | i[31]) << 2;
+        o[40] = B64[v >> 12]; o[41] = B64[(v >> 6) & 63]; o[42] = B64[v & 63];
+    }
+    return KZG_OK;
+}
+
+int kzg_test_field(kzg_ctx* ctx, int field, int op, const uint8_t* a_be, const uint8_t* b_be, uint8_t* out_be,
+                   uint64_t n) {
+    if (!ctx || !a_be || !b_be || !out_be || !n) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t w = field == 0 ? 48 : 32;
+    HIPCHK(ctx, ctx->in_be.ensure(2 * n * w));
+    HIPCHK(ctx, ctx->out_be.ensure(n * w));
+    uint8_t* da = ctx->in_be.as<uint8_t>();
+    uint8_t* db = da + n * w;
+    HIPCHK(ctx, hipMemcpyAsync(da, a_be, n * w, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(db, b_be, n * w, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t blocks = (uint32_t)((n + 255) / 256);
+    if (field == 0) k_test_field<FpParams><<<blocks, 256, 0, ctx->stream>>>(op, da, db, ctx->out_be.as<uint8_t>(), n);
+    else k_test_field<FrParams><<<blocks, 256, 0, ctx->stream>>>(op, da, db, ctx->out_be.as<uint8_t>(), n);
+    HIPCHK(ctx, hipMemcpyAsync(out_be, ctx->out_be.p, n * w, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipGetLastError());
+    return KZG_OK;
+}
+int kzg_test_g1(kzg_ctx* ctx, int op, const uint8_t* a_be96, const uint8_t* b_be96, uint8_t* out_be96, uint64_t n) {
+    if (!ctx || !a_be96 || !b_be96 || !out_be96 || !n) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, ctx->in_be.ensure(2 * n * 96));
+    HIPCHK(ctx, ctx->out_be.ensure(n * 96));
+    uint8_t* da = ctx->in_be.as<uint8_t>();
+    uint8_t* db = da + n * 96;
+    HIPCHK(ctx, hipMemcpyAsync(da, a_be96, n * 96, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(db, b_be96, n * 96, hipMemcpyHostToDevice, ctx->stream));
+    k_test_g1<<<(uint32_t)((n + 255) / 256), 256, 0, ctx->stream>>>(op, da, db, ctx->out_be.as<uint8_t>(), n);
+    HIPCHK(ctx, hipMemcpyAsync(out_be96, ctx->out_be.p, n * 96, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipGetLastError());
+    return KZG_OK;
+}
+
+}  // extern "C"

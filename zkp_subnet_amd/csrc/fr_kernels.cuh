@@ -1,0 +1,17 @@
+// Fr-side kernel launchers (fr_kernels.hip): wire codec, NTT, opening evaluation + quotient.
+#pragma once
+#include "g1.cuh"
+
+void launch_fr_from_be(hipStream_t s, const uint8_t* be, uint32_t* out, uint64_t n, int to_mont, uint32_t* bad);
+void launch_fr_to_be(hipStream_t s, const uint32_t* in, uint8_t* be, uint64_t n, int from_mont);
+void launch_fr_from_mont(hipStream_t s, const uint32_t* in, uint32_t* out, uint64_t n);
+// tw: 2^(log_n-1) Montgomery-form powers of w_n (inverse: of w_n^-1)
+void launch_fr_twiddles(hipStream_t s, uint32_t* tw, int log_n, int inverse);
+void launch_fr_inv_pow2(hipStream_t s, uint32_t* out, int log_n);
+// out-of-place natural-order NTT of 2^log_n Montgomery-form elements; scale (1/n, Montgomery) applied if given
+void launch_fr_ntt(hipStream_t s, const uint32_t* in, uint32_t* out, int log_n, const uint32_t* tw,
+                   const uint32_t* scale_or_null);
+// y = f(alpha) (Montgomery) and, if q is given, the n-1 canonical coefficients of (f - y)/(X - alpha)
+// h, hnext: ceil(n/64) Fr scratch each
+void launch_poly_open(hipStream_t s, const uint32_t* f_mont, uint64_t n, const uint32_t* alpha_mont, uint32_t* h,
+                      uint32_t* hnext, uint32_t* y_mont, uint32_t* q_canon_or_null);

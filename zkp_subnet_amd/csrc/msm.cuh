@@ -1,0 +1,56 @@
+// Pippenger G1 MSM for gfx950 -- kernel declarations shared by msm.hip and api.hip.
+//
+// Design (DESIGN.md "MSM"): the SRS is fixed, so every point P_j is stored with its window multiples
+// 2^(c*w) P_j (table[w][j], affine, Montgomery; sized for 288 GB HBM).  All nwin signed c-bit digits of all
+// scalars then fall into ONE set of B = 2^(c-1) buckets:
+//   1. msm_digits_hist   scalar -> signed digits, per-bucket histogram (global atomics), rank of each entry
+//   2. msm_scan          exclusive prefix sum of the histogram -> bucket offsets
+//   3. msm_scatter       counting-sort scatter: sorted[offset[key] + rank] = table index | sign
+//   4. msm_accumulate    HOT: every lane sums a fixed-size chunk of the sorted entries with mixed XYZZ adds
+//                        (perfect load balance for any scalar distribution); bucket runs that span chunks
+//                        leave "carry" partial sums
+//   5. msm_fixup         folds the carries into their buckets
+//   6. msm_tree_level    log2(B) pairwise-merge levels producing P = sum B_k and T_i = sum_{bit i of k} B_k
+//   7. msm_final         sum = P + sum_i 2^i T_i  (-> XYZZ, optionally affine + 48-byte compression)
+#pragma once
+#include "g1.cuh"
+
+struct MsmShape {
+    int c;               // window bits
+    int nwin;            // ceil(256 / c) signed windows
+    uint32_t nbuckets;   // 2^(c-1)
+    uint64_t n;          // number of (scalar, point) pairs in this MSM
+    uint64_t srs_offset; // first point of the slice inside the resident SRS
+    uint64_t srs_stride; // points per window table (= total resident SRS points)
+    int chunk;           // sorted entries per lane in msm_accumulate
+};
+
+void launch_msm_digits_hist(hipStream_t s, const MsmShape& sh, const uint32_t* scalars, int scalars_mont,
+                            uint32_t* hist, uint32_t* rank);
+void launch_msm_scan(hipStream_t s, const MsmShape& sh, const uint32_t* hist, uint32_t* offsets);
+void launch_msm_scatter(hipStream_t s, const MsmShape& sh, const uint32_t* scalars, int scalars_mont,
+                        const uint32_t* offsets, const uint32_t* rank, uint32_t* sorted);
+void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t* table, const uint32_t* offsets,
+                           const uint32_t* sorted, g1_xyzz_t* buckets, g1_xyzz_t* carries, uint32_t* carry_key,
+                           uint32_t nchunks);
+void launch_msm_fixup(hipStream_t s, g1_xyzz_t* buckets, const g1_xyzz_t* carries, const uint32_t* carry_key,
+                      uint32_t nchunks);
+// level i: in = nodes of (i+1) points, component-major; out = nodes of (i+2) points
+void launch_msm_tree_level(hipStream_t s, const g1_xyzz_t* in, g1_xyzz_t* out, uint32_t n_in_nodes, int level);
+// node = [P, T_0 .. T_{nbits-1}] ; out_xyzz = P + sum 2^i T_i
+void launch_msm_final(hipStream_t s, const g1_xyzz_t* node, int nbits, g1_xyzz_t* out_xyzz);
+// sum `count` XYZZ points (count <= 1024) into out_xyzz[0]
+void launch_g1_sum(hipStream_t s, const g1_xyzz_t* in, uint32_t count, g1_xyzz_t* out_xyzz);
+// affine + ZCash compression of one point
+void launch_g1_compress(hipStream_t s, const g1_xyzz_t* in, uint8_t* out48);
+
+// SRS plumbing
+void launch_srs_from_be96(hipStream_t s, const uint8_t* be96, g1_affine_t* out, uint64_t n, uint32_t* bad_flag);
+void launch_srs_to_be96(hipStream_t s, const g1_affine_t* in, uint8_t* be96, uint64_t n);
+// window tables for points [first, first+count): tmp holds (nwin-1)*count XYZZ values
+void launch_srs_precompute(hipStream_t s, g1_affine_t* table, uint64_t stride, uint64_t first, uint64_t count,
+                           int c, int nwin, g1_xyzz_t* tmp);
+// synthetic SRS: out[j] = [s0 * tau^(j_base+j)] G for j < count (discrete logs known -> tests / benches only)
+// (global index j_base + j); gtab: 32*255 affine scratch (built when build_gtab); tmp: count XYZZ + count*32 B
+void launch_srs_generate(hipStream_t s, g1_affine_t* out, uint64_t count, uint64_t j_base, const uint32_t* tau_mont,
+                         const uint32_t* s0_mont, g1_affine_t* gtab, g1_xyzz_t* tmp, bool build_gtab);

@@ -1,0 +1,568 @@
+// Pippenger G1 MSM kernels for gfx950 (see msm.cuh for the pipeline).  No reference source exists for this
+// path (reference neurons/miner.py:39,48 only calls the external prover); the algorithm is restated from the
+// published bucket method and checked bit-for-bit against oracle/ in tests/test_gpu_*.py.
+#include "msm.cuh"
+
+#define NONE_KEY 0xffffffffu
+
+// ------------------------------------------------------------------------------------------------ digits
+KZG_DEV uint32_t limb_at(const uint32_t* s, int i) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r = (i == k) ? s[k] : r;
+    return r;
+}
+KZG_DEV uint32_t window_bits(const uint32_t* s, int lo, int c) {
+    if (lo >= 256) return 0;
+    int wi = lo >> 5, b = lo & 31;
+    uint64_t v = limb_at(s, wi) | ((uint64_t)limb_at(s, wi + 1) << 32);  // limb_at(.., 8) == 0
+    return (uint32_t)(v >> b) & ((1u << c) - 1u);
+}
+KZG_DEV void load_scalar(uint32_t* s, const uint32_t* scalars, uint64_t j, int mont) {
+    const uint4* p = reinterpret_cast<const uint4*>(scalars + 8 * j);
+    uint4 a = p[0], b = p[1];
+    fr_t v;
+    v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w;
+    v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
+    if (mont) f_from_mont(v, v);
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[i] = v.l[i];
+}
+// signed-digit recoding: digit in [-2^(c-1)+1, 2^(c-1)]; returns magnitude (0 = skip), sets neg, updates carry
+KZG_DEV uint32_t signed_digit(const uint32_t* s, int w, int c, uint32_t& carry, uint32_t& neg) {
+    uint32_t d = window_bits(s, w * c, c) + carry;
+    const uint32_t half = 1u << (c - 1);
+    neg = d > half;
+    carry = neg;
+    return neg ? (1u << c) - d : d;
+}
+
+__global__ void __launch_bounds__(256) k_msm_digits_hist(const uint32_t* __restrict__ scalars, uint64_t n, int c,
+                                                          int nwin, int mont, uint32_t* __restrict__ hist,
+                                                          uint32_t* __restrict__ rank) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t s[8];
+    load_scalar(s, scalars, j, mont);
+    uint32_t carry = 0, neg;
+    for (int w = 0; w < nwin; w++) {
+        uint32_t mag = signed_digit(s, w, c, carry, neg);
+        if (mag) rank[(uint64_t)w * n + j] = atomicAdd(&hist[mag - 1], 1u);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_msm_scatter(const uint32_t* __restrict__ scalars, uint64_t n, int c,
+                                                      int nwin, int mont, uint64_t srs_offset, uint64_t srs_stride,
+                                                      const uint32_t* __restrict__ offsets,
+                                                      const uint32_t* __restrict__ rank,
+                                                      uint32_t* __restrict__ sorted) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t s[8];
+    load_scalar(s, scalars, j, mont);
+    uint32_t carry = 0, neg;
+    for (int w = 0; w < nwin; w++) {
+        uint32_t mag = signed_digit(s, w, c, carry, neg);
+        if (mag) {
+            uint32_t pos = offsets[mag - 1] + rank[(uint64_t)w * n + j];
+            sorted[pos] = (uint32_t)((uint64_t)w * srs_stride + srs_offset + j) | (neg << 31);
+        }
+    }
+}
+
+// exclusive scan of hist[0..nb) into offsets[0..nb]; one 1024-thread block (nb <= 2^22 -> <= 4096 per lane)
+__global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __restrict__ hist, uint32_t nb,
+                                                    uint32_t* __restrict__ offsets) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (nb + 1023u) / 1024u;
+    const uint32_t lo = t * per, hi = min(lo + per, nb);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += hist[i];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
+        uint32_t v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (uint32_t i = lo; i < hi; i++) {
+        offsets[i] = run;
+        run += hist[i];
+    }
+    if (t == 1023) offsets[nb] = part[1023];
+}
+
+// ------------------------------------------------------------------------------------------------ accumulate
+KZG_DEV void load_affine(g1_affine_t& p, const g1_affine_t* src) {
+    const uint4* q = reinterpret_cast<const uint4*>(src);
+    uint4 v[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) v[i] = q[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        p.x.l[4 * i] = v[i].x; p.x.l[4 * i + 1] = v[i].y; p.x.l[4 * i + 2] = v[i].z; p.x.l[4 * i + 3] = v[i].w;
+        p.y.l[4 * i] = v[3 + i].x; p.y.l[4 * i + 1] = v[3 + i].y; p.y.l[4 * i + 2] = v[3 + i].z;
+        p.y.l[4 * i + 3] = v[3 + i].w;
+    }
+}
+KZG_DEV void store_xyzz(g1_xyzz_t* dst, const g1_xyzz_t& p) {
+    uint4* q = reinterpret_cast<uint4*>(dst);
+    const fp_t* f[4] = {&p.x, &p.y, &p.zz, &p.zzz};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            q[3 * k + i] = make_uint4(f[k]->l[4 * i], f[k]->l[4 * i + 1], f[k]->l[4 * i + 2], f[k]->l[4 * i + 3]);
+}
+KZG_DEV void load_xyzz(g1_xyzz_t& p, const g1_xyzz_t* src) {
+    const uint4* q = reinterpret_cast<const uint4*>(src);
+    fp_t* f[4] = {&p.x, &p.y, &p.zz, &p.zzz};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            uint4 v = q[3 * k + i];
+            f[k]->l[4 * i] = v.x; f[k]->l[4 * i + 1] = v.y; f[k]->l[4 * i + 2] = v.z; f[k]->l[4 * i + 3] = v.w;
+        }
+}
+
+// Each lane owns sorted entries [t*K, (t+1)*K).  A bucket run that began in an earlier chunk is summed into
+// carries[t] (at most one per chunk: only the FIRST run of a chunk can have begun earlier); every run that
+// begins inside the chunk is stored straight to its bucket -- the lane that sees a run begin is its only writer.
+__global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t* __restrict__ table,
+                                                         const uint32_t* __restrict__ offsets,
+                                                         const uint32_t* __restrict__ sorted, uint32_t nbuckets,
+                                                         uint32_t chunk, uint32_t nchunks,
+                                                         g1_xyzz_t* __restrict__ buckets,
+                                                         g1_xyzz_t* __restrict__ carries,
+                                                         uint32_t* __restrict__ carry_key) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    const uint32_t total = offsets[nbuckets];
+    const uint32_t lo = t * chunk;
+    if (lo >= total) {  // zero digits were dropped: fewer entries than the host-side bound
+        carry_key[t] = NONE_KEY;
+        return;
+    }
+    const uint32_t hi = min(lo + chunk, total);
+    // largest b with offsets[b] <= lo  (then offsets[b+1] > lo: b is non-empty and contains entry lo)
+    uint32_t b_lo = 0, b_hi = nbuckets - 1;
+    while (b_lo < b_hi) {
+        uint32_t mid = (b_lo + b_hi + 1) >> 1;
+        if (offsets[mid] <= lo) b_lo = mid; else b_hi = mid - 1;
+    }
+    uint32_t cur = b_lo;
+    uint32_t boundary = offsets[cur + 1];
+    bool pending_carry = offsets[cur] < lo;  // first run began in an earlier chunk
+    uint32_t my_carry_key = NONE_KEY;
+    g1_xyzz_t acc;
+    g1_set_inf(acc);
+    for (uint32_t e = lo; e < hi; e++) {
+        while (e == boundary) {  // run of `cur` is complete (also steps over empty buckets)
+            if (pending_carry) {
+                store_xyzz(&carries[t], acc);
+                my_carry_key = cur;
+                pending_carry = false;
+            } else {
+                store_xyzz(&buckets[cur], acc);
+            }
+            g1_set_inf(acc);
+            cur++;
+            boundary = offsets[cur + 1];
+        }
+        const uint32_t v = sorted[e];
+        g1_affine_t p;
+        load_affine(p, table + (v & 0x7fffffffu));
+        g1_neg_affine(p, p, v >> 31);
+        g1_madd_checked(acc, p);
+    }
+    if (pending_carry) {
+        store_xyzz(&carries[t], acc);
+        my_carry_key = cur;
+    } else {
+        store_xyzz(&buckets[cur], acc);
+    }
+    carry_key[t] = my_carry_key;
+}
+
+// Carries of one bucket are contiguous in chunk order; the first lane of each run folds the run into the bucket.
+__global__ void __launch_bounds__(256) k_msm_fixup(g1_xyzz_t* __restrict__ buckets,
+                                                    const g1_xyzz_t* __restrict__ carries,
+                                                    const uint32_t* __restrict__ carry_key, uint32_t nchunks) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    const uint32_t key = carry_key[t];
+    if (key == NONE_KEY) return;
+    if (t > 0 && carry_key[t - 1] == key) return;
+    g1_xyzz_t acc, q, r;
+    load_xyzz(acc, &buckets[key]);
+    for (uint32_t u = t; u < nchunks && carry_key[u] == key; u++) {
+        load_xyzz(q, &carries[u]);
+        g1_add(r, acc, q);
+        acc = r;
+    }
+    store_xyzz(&buckets[key], acc);
+}
+
+// ------------------------------------------------------------------------------------------------ bucket tree
+// Node at level L covers 2^L consecutive buckets and holds [P, T_0 .. T_{L-1}] (component-major arrays):
+//   P = sum of its buckets, T_k = sum of its buckets whose index has bit k set.
+// Merging left (bit L = 0) and right (bit L = 1): P = P_l + P_r, T_k = T_k_l + T_k_r, T_L = P_r.
+// Every add of a level is independent, so the serial depth of the whole reduction is log2(B) point adds,
+// and sum_k (k+1) B_k = P + sum_i 2^i T_i at the root.
+__global__ void __launch_bounds__(256) k_msm_tree_level(const g1_xyzz_t* __restrict__ in,
+                                                         g1_xyzz_t* __restrict__ out, uint32_t n_in, int level) {
+    const uint32_t n_out = n_in >> 1;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_out * (uint32_t)(level + 2)) return;
+    const uint32_t k = gid / n_out, m = gid - k * n_out;
+    g1_xyzz_t a, b, r;
+    if (k == (uint32_t)(level + 1)) {
+        load_xyzz(r, &in[2 * m + 1]);
+    } else {
+        load_xyzz(a, &in[(uint64_t)k * n_in + 2 * m]);
+        load_xyzz(b, &in[(uint64_t)k * n_in + 2 * m + 1]);
+        g1_add(r, a, b);
+    }
+    store_xyzz(&out[(uint64_t)k * n_out + m], r);
+}
+
+KZG_DEV void lds_tree_sum(g1_xyzz_t* sm, g1_xyzz_t& mine, uint32_t tid, uint32_t nthreads) {
+    store_xyzz(&sm[tid], mine);
+    __syncthreads();
+    for (uint32_t d = nthreads >> 1; d >= 1; d >>= 1) {
+        if (tid < d) {
+            g1_xyzz_t a, b, r;
+            load_xyzz(a, &sm[tid]);
+            load_xyzz(b, &sm[tid + d]);
+            g1_add(r, a, b);
+            store_xyzz(&sm[tid], r);
+        }
+        __syncthreads();
+    }
+    load_xyzz(mine, &sm[0]);
+}
+
+// node = [P, T_0..T_{nbits-1}]; lane i doubles T_i i times, then one 64-wide LDS tree sum.
+__global__ void __launch_bounds__(64) k_msm_final(const g1_xyzz_t* __restrict__ node, int nbits,
+                                                   g1_xyzz_t* __restrict__ out) {
+    __shared__ g1_xyzz_t sm[64];
+    const uint32_t tid = threadIdx.x;
+    g1_xyzz_t v;
+    g1_set_inf(v);
+    if ((int)tid < nbits) {
+        load_xyzz(v, &node[1 + tid]);
+        for (uint32_t i = 0; i < tid; i++) {
+            g1_xyzz_t r;
+            g1_dbl(r, v);
+            v = r;
+        }
+    } else if ((int)tid == nbits) {
+        load_xyzz(v, &node[0]);
+    }
+    lds_tree_sum(sm, v, tid, 64);
+    if (tid == 0) store_xyzz(out, v);
+}
+
+__global__ void __launch_bounds__(64) k_g1_sum(const g1_xyzz_t* __restrict__ in, uint32_t count,
+                                                g1_xyzz_t* __restrict__ out) {
+    __shared__ g1_xyzz_t sm[64];
+    const uint32_t tid = threadIdx.x;
+    g1_xyzz_t acc, q, r;
+    g1_set_inf(acc);
+    for (uint32_t i = tid; i < count; i += 64) {
+        load_xyzz(q, &in[i]);
+        g1_add(r, acc, q);
+        acc = r;
+    }
+    lds_tree_sum(sm, acc, tid, 64);
+    if (tid == 0) store_xyzz(out, acc);
+}
+
+__global__ void __launch_bounds__(64) k_g1_compress(const g1_xyzz_t* __restrict__ in, uint8_t* __restrict__ out48) {
+    if (threadIdx.x != 0) return;
+    g1_xyzz_t p;
+    load_xyzz(p, in);
+    g1_affine_t a;
+    g1_to_affine(a, p);
+    g1_compress(out48, a);
+}
+
+// ------------------------------------------------------------------------------------------------ SRS plumbing
+__global__ void __launch_bounds__(256) k_srs_from_be96(const uint8_t* __restrict__ be, g1_affine_t* __restrict__ out,
+                                                        uint64_t n, uint32_t* __restrict__ bad) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    g1_affine_t p;
+    limbs_from_be<12>(p.x.l, be + 96 * j);
+    limbs_from_be<12>(p.y.l, be + 96 * j + 48);
+    if (g1_affine_is_inf(p)) {
+        out[j] = p;
+        return;
+    }
+    uint32_t pm[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) pm[i] = FpParams::mod(i);
+    if (bi_ge<12>(p.x.l, pm) || bi_ge<12>(p.y.l, pm)) atomicOr(bad, 1u);
+    f_to_mont(p.x, p.x);
+    f_to_mont(p.y, p.y);
+    // on-curve: y^2 == x^3 + 4
+    fp_t y2, x3, four, t;
+    fp_sqr(y2, p.y);
+    fp_sqr(x3, p.x); fp_mul(x3, x3, p.x);
+    f_one(four); fp_dbl(four, four); fp_dbl(four, four);
+    fp_add(t, x3, four);
+    if (!f_eq(y2, t)) atomicOr(bad, 2u);
+    out[j] = p;
+}
+__global__ void __launch_bounds__(256) k_srs_to_be96(const g1_affine_t* __restrict__ in, uint8_t* __restrict__ be,
+                                                      uint64_t n) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    g1_affine_t p = in[j];
+    fp_t x, y;
+    f_from_mont(x, p.x);
+    f_from_mont(y, p.y);
+    limbs_to_be<12>(be + 96 * j, x.l);
+    limbs_to_be<12>(be + 96 * j + 48, y.l);
+}
+
+// window tables: tmp[(w-1)*count + j] = 2^(c*w) P_{first+j} in XYZZ
+__global__ void __launch_bounds__(256) k_precomp_dbl(const g1_affine_t* __restrict__ table, uint64_t first,
+                                                      uint64_t count, int c, int nwin, g1_xyzz_t* __restrict__ tmp) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    g1_affine_t p;
+    load_affine(p, table + first + j);
+    g1_xyzz_t cur, r;
+    g1_from_affine(cur, p);
+    for (int w = 1; w < nwin; w++) {
+        for (int k = 0; k < c; k++) {
+            g1_dbl(r, cur);
+            cur = r;
+        }
+        store_xyzz(&tmp[(uint64_t)(w - 1) * count + j], cur);
+    }
+}
+// per-lane Montgomery batch inversion over the lane's nwin-1 window points; prefix products are parked in
+// the destination slots' x field
+__global__ void __launch_bounds__(256) k_precomp_norm(g1_affine_t* __restrict__ table, uint64_t stride,
+                                                       uint64_t first, uint64_t count, int nwin,
+                                                       const g1_xyzz_t* __restrict__ tmp) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    fp_t acc, d, one;
+    f_one(one);
+    acc = one;
+    for (int w = 1; w < nwin; w++) {
+        g1_xyzz_t p;
+        load_xyzz(p, &tmp[(uint64_t)(w - 1) * count + j]);
+        table[(uint64_t)w * stride + first + j].x = acc;
+        if (!g1_is_inf(p)) {
+            fp_mul(d, p.zz, p.zzz);
+            fp_mul(acc, acc, d);
+        }
+    }
+    fp_t inv;
+    fp_inv(inv, acc);
+    for (int w = nwin - 1; w >= 1; w--) {
+        g1_xyzz_t p;
+        load_xyzz(p, &tmp[(uint64_t)(w - 1) * count + j]);
+        g1_affine_t* dst = &table[(uint64_t)w * stride + first + j];
+        g1_affine_t o;
+        if (g1_is_inf(p)) {
+            f_zero(o.x); f_zero(o.y);
+        } else {
+            fp_t pre = dst->x, iw, t;
+            fp_mul(d, p.zz, p.zzz);
+            fp_mul(iw, inv, pre);   // 1 / (zz*zzz)
+            fp_mul(inv, inv, d);
+            fp_mul(t, iw, p.zzz);   // 1 / zz
+            fp_mul(o.x, p.x, t);
+            fp_mul(t, iw, p.zz);    // 1 / zzz
+            fp_mul(o.y, p.y, t);
+        }
+        *dst = o;
+    }
+}
+
+// ---- synthetic SRS (tests / benches): out[j] = [s0 tau^j] G via an 8-bit fixed-base table of G
+KZG_DEV void g1_generator(g1_affine_t& g) {
+    constexpr uint32_t gx[12] = {0xdb22c6bbu, 0xfb3af00au, 0xf97a1aefu, 0x6c55e83fu, 0x171bac58u, 0xa14e3a3fu,
+                                 0x9774b905u, 0xc3688c4fu, 0x4fa9ac0fu, 0x2695638cu, 0x3197d794u, 0x17f1d3a7u};
+    constexpr uint32_t gy[12] = {0x46c5e7e1u, 0x0caa2329u, 0xa2888ae4u, 0xd03cc744u, 0x2c04b3edu, 0x00db18cbu,
+                                 0xd5d00af6u, 0xfcf5e095u, 0x741d8ae4u, 0xa09e30edu, 0xe3aaa0f1u, 0x08b3f481u};
+#pragma unroll
+    for (int i = 0; i < 12; i++) { g.x.l[i] = gx[i]; g.y.l[i] = gy[i]; }
+    f_to_mont(g.x, g.x);
+    f_to_mont(g.y, g.y);
+}
+// gtab[w*255 + d] = (d+1) * 2^(8w) * G, affine
+__global__ void __launch_bounds__(256) k_gen_gtab(g1_affine_t* __restrict__ gtab) {
+    uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= 32 * 255) return;
+    uint32_t w = gid / 255, d = gid % 255 + 1;
+    g1_affine_t g;
+    g1_generator(g);
+    g1_xyzz_t base, r, acc;
+    g1_from_affine(base, g);
+    for (uint32_t k = 0; k < 8 * w; k++) { g1_dbl(r, base); base = r; }
+    g1_set_inf(acc);
+    for (int b = 7; b >= 0; b--) {
+        g1_dbl(r, acc); acc = r;
+        if ((d >> b) & 1u) { g1_add(r, acc, base); acc = r; }
+    }
+    g1_affine_t o;
+    g1_to_affine(o, acc);
+    gtab[gid] = o;
+}
+// scal[j] = s0 * tau^j (canonical limbs); 64 consecutive j per lane
+__global__ void __launch_bounds__(256) k_srs_scalars(uint32_t* __restrict__ scal, uint64_t count, uint64_t j_base,
+                                                      const uint32_t* __restrict__ tau_mont,
+                                                      const uint32_t* __restrict__ s0_mont) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t j0 = t * 64;
+    if (j0 >= count) return;
+    fr_t tau, cur, pw;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { tau.l[i] = tau_mont[i]; cur.l[i] = s0_mont[i]; }
+    pw = tau;  // cur *= tau^(j_base + j0)
+    for (uint64_t e = j_base + j0; e; e >>= 1) {
+        if (e & 1) f_mul(cur, cur, pw);
+        f_mul(pw, pw, pw);
+    }
+    for (uint64_t j = j0; j < j0 + 64 && j < count; j++) {
+        fr_t c;
+        f_from_mont(c, cur);
+        uint4* o = reinterpret_cast<uint4*>(scal + 8 * j);
+        o[0] = make_uint4(c.l[0], c.l[1], c.l[2], c.l[3]);
+        o[1] = make_uint4(c.l[4], c.l[5], c.l[6], c.l[7]);
+        f_mul(cur, cur, tau);
+    }
+}
+__global__ void __launch_bounds__(256) k_srs_fixed_mul(const uint32_t* __restrict__ scal, uint64_t count,
+                                                        const g1_affine_t* __restrict__ gtab,
+                                                        g1_xyzz_t* __restrict__ tmp) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    uint32_t s[8];
+    load_scalar(s, scal, j, 0);
+    g1_xyzz_t acc;
+    g1_set_inf(acc);
+    for (int w = 0; w < 32; w++) {
+        uint32_t d = (limb_at(s, w >> 2) >> (8 * (w & 3))) & 0xffu;
+        if (d) {
+            g1_affine_t p;
+            load_affine(p, gtab + w * 255 + d - 1);
+            g1_madd(acc, p.x, p.y);
+        }
+    }
+    store_xyzz(&tmp[j], acc);
+}
+// XYZZ -> affine for `count` points, 16 consecutive points per lane share one inversion
+__global__ void __launch_bounds__(256) k_batch_affine(const g1_xyzz_t* __restrict__ tmp, g1_affine_t* __restrict__ out,
+                                                       uint64_t count) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t j0 = t * 16;
+    if (j0 >= count) return;
+    uint64_t j1 = min(j0 + 16, count);
+    fp_t acc, d, inv;
+    f_one(acc);
+    for (uint64_t j = j0; j < j1; j++) {
+        g1_xyzz_t p;
+        load_xyzz(p, &tmp[j]);
+        out[j].x = acc;
+        if (!g1_is_inf(p)) {
+            fp_mul(d, p.zz, p.zzz);
+            fp_mul(acc, acc, d);
+        }
+    }
+    fp_inv(inv, acc);
+    for (uint64_t j = j1; j-- > j0;) {
+        g1_xyzz_t p;
+        load_xyzz(p, &tmp[j]);
+        g1_affine_t o;
+        if (g1_is_inf(p)) {
+            f_zero(o.x); f_zero(o.y);
+        } else {
+            fp_t pre = out[j].x, iw, tt;
+            fp_mul(d, p.zz, p.zzz);
+            fp_mul(iw, inv, pre);
+            fp_mul(inv, inv, d);
+            fp_mul(tt, iw, p.zzz);
+            fp_mul(o.x, p.x, tt);
+            fp_mul(tt, iw, p.zz);
+            fp_mul(o.y, p.y, tt);
+        }
+        out[j] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+static inline uint32_t nblk(uint64_t n, uint32_t b) { return (uint32_t)((n + b - 1) / b); }
+
+void launch_msm_digits_hist(hipStream_t s, const MsmShape& sh, const uint32_t* scalars, int scalars_mont,
+                            uint32_t* hist, uint32_t* rank) {
+    if (!sh.n) return;
+    k_msm_digits_hist<<<nblk(sh.n, 256), 256, 0, s>>>(scalars, sh.n, sh.c, sh.nwin, scalars_mont, hist, rank);
+}
+void launch_msm_scan(hipStream_t s, const MsmShape& sh, const uint32_t* hist, uint32_t* offsets) {
+    k_msm_scan<<<1, 1024, 0, s>>>(hist, sh.nbuckets, offsets);
+}
+void launch_msm_scatter(hipStream_t s, const MsmShape& sh, const uint32_t* scalars, int scalars_mont,
+                        const uint32_t* offsets, const uint32_t* rank, uint32_t* sorted) {
+    if (!sh.n) return;
+    k_msm_scatter<<<nblk(sh.n, 256), 256, 0, s>>>(scalars, sh.n, sh.c, sh.nwin, scalars_mont, sh.srs_offset,
+                                                  sh.srs_stride, offsets, rank, sorted);
+}
+void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t* table, const uint32_t* offsets,
+                           const uint32_t* sorted, g1_xyzz_t* buckets, g1_xyzz_t* carries, uint32_t* carry_key,
+                           uint32_t nchunks) {
+    if (!nchunks) return;
+    k_msm_accumulate<<<nblk(nchunks, 256), 256, 0, s>>>(table, offsets, sorted, sh.nbuckets, (uint32_t)sh.chunk,
+                                                        nchunks, buckets, carries, carry_key);
+}
+void launch_msm_fixup(hipStream_t s, g1_xyzz_t* buckets, const g1_xyzz_t* carries, const uint32_t* carry_key,
+                      uint32_t nchunks) {
+    if (!nchunks) return;
+    k_msm_fixup<<<nblk(nchunks, 256), 256, 0, s>>>(buckets, carries, carry_key, nchunks);
+}
+void launch_msm_tree_level(hipStream_t s, const g1_xyzz_t* in, g1_xyzz_t* out, uint32_t n_in_nodes, int level) {
+    uint32_t threads = (n_in_nodes >> 1) * (uint32_t)(level + 2);
+    k_msm_tree_level<<<nblk(threads, 256), 256, 0, s>>>(in, out, n_in_nodes, level);
+}
+void launch_msm_final(hipStream_t s, const g1_xyzz_t* node, int nbits, g1_xyzz_t* out_xyzz) {
+    k_msm_final<<<1, 64, 0, s>>>(node, nbits, out_xyzz);
+}
+void launch_g1_sum(hipStream_t s, const g1_xyzz_t* in, uint32_t count, g1_xyzz_t* out_xyzz) {
+    k_g1_sum<<<1, 64, 0, s>>>(in, count, out_xyzz);
+}
+void launch_g1_compress(hipStream_t s, const g1_xyzz_t* in, uint8_t* out48) {
+    k_g1_compress<<<1, 64, 0, s>>>(in, out48);
+}
+void launch_srs_from_be96(hipStream_t s, const uint8_t* be96, g1_affine_t* out, uint64_t n, uint32_t* bad_flag) {
+    if (!n) return;
+    k_srs_from_be96<<<nblk(n, 256), 256, 0, s>>>(be96, out, n, bad_flag);
+}
+void launch_srs_to_be96(hipStream_t s, const g1_affine_t* in, uint8_t* be96, uint64_t n) {
+    if (!n) return;
+    k_srs_to_be96<<<nblk(n, 256), 256, 0, s>>>(in, be96, n);
+}
+void launch_srs_precompute(hipStream_t s, g1_affine_t* table, uint64_t stride, uint64_t first, uint64_t count,
+                           int c, int nwin, g1_xyzz_t* tmp) {
+    if (!count || nwin < 2) return;
+    k_precomp_dbl<<<nblk(count, 256), 256, 0, s>>>(table, first, count, c, nwin, tmp);
+    k_precomp_norm<<<nblk(count, 256), 256, 0, s>>>(table, stride, first, count, nwin, tmp);
+}
+void launch_srs_generate(hipStream_t s, g1_affine_t* out, uint64_t count, uint64_t j_base, const uint32_t* tau_mont,
+                         const uint32_t* s0_mont, g1_affine_t* gtab, g1_xyzz_t* tmp, bool build_gtab) {
+    if (!count) return;
+    if (build_gtab) k_gen_gtab<<<nblk(32 * 255, 256), 256, 0, s>>>(gtab);
+    uint32_t* sbuf = reinterpret_cast<uint32_t*>(tmp + count);  // scalars staged behind the XYZZ scratch
+    k_srs_scalars<<<nblk((count + 63) / 64, 256), 256, 0, s>>>(sbuf, count, j_base, tau_mont, s0_mont);
+    k_srs_fixed_mul<<<nblk(count, 256), 256, 0, s>>>(sbuf, count, gtab, tmp);
+    k_batch_affine<<<nblk((count + 15) / 16, 256), 256, 0, s>>>(tmp, out, count);
+}

@@ -1,0 +1,187 @@
+"""Thin object wrapper over the C-ABI: one HipEngine = one kzg_ctx = one MI355X.
+
+All arguments and results are bytes in the wire layouts of include/kzg_mi355x.h (Fr 32 B big-endian, G1 affine
+96 B / compressed 48 B).  This is the object `Client` drives; tests inject an oracle-backed stand-in with the same
+methods to exercise the host logic on machines without a GPU."""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence, Tuple
+
+from . import _native
+from ._native import KzgError
+
+R_MODULUS = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+
+
+def _root_of_unity(n: int) -> int:
+    return pow(7, (R_MODULUS - 1) // n, R_MODULUS)
+
+
+def lagrange_factor(i: int, machines_scale: int, tau_y: int) -> int:
+    """L_i(tau_y) over the 2^machines_scale-point Y domain: the per-worker factor of the Pianist SRS slice
+    U_{i,j} = tau_x^j L_i(tau_y) G.  Setup-time host arithmetic only."""
+    m = 1 << machines_scale
+    if m == 1:
+        return 1
+    wi = pow(_root_of_unity(m), i, R_MODULUS)
+    if (tau_y - wi) % R_MODULUS == 0:
+        return 1
+    num = (pow(tau_y, m, R_MODULUS) - 1) % R_MODULUS
+    inv = lambda v: pow(v % R_MODULUS, R_MODULUS - 2, R_MODULUS)  # noqa: E731
+    return wi * inv(m) % R_MODULUS * num % R_MODULUS * inv(tau_y - wi) % R_MODULUS
+
+
+class HipEngine:
+    def __init__(self, device: int = 0, window: int = 0):
+        self._lib = _native.load()
+        h = ctypes.c_void_p()
+        rc = self._lib.kzg_create(device, ctypes.byref(h))
+        if rc != 0:
+            raise KzgError(rc, "kzg_create failed: no usable gfx950 device (this build has no CPU fallback)")
+        self._h = h
+        self.device = device
+        self.scale = self.machines_scale = 0
+        if window:
+            self._chk(self._lib.kzg_set_window(self._h, window))
+
+    # ------------------------------------------------------------------ plumbing
+    def _chk(self, rc: int) -> None:
+        if rc != 0:
+            raise KzgError(rc, self._lib.kzg_last_error(self._h).decode(errors="replace"))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.kzg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def window(self) -> int:
+        return self._lib.kzg_get_window(self._h)
+
+    @property
+    def srs_points(self) -> int:
+        return self._lib.kzg_srs_points(self._h)
+
+    @property
+    def slice_len(self) -> int:
+        return 1 << (self.scale - self.machines_scale)
+
+    # ------------------------------------------------------------------ SRS
+    def load_srs(self, g1_be96: bytes, scale: int, machines_scale: int) -> None:
+        self._chk(self._lib.kzg_load_srs(self._h, g1_be96, len(g1_be96) // 96, scale, machines_scale))
+        self.scale, self.machines_scale = scale, machines_scale
+
+    def gen_srs(self, tau_x: int, tau_y: int, scale: int, machines_scale: int,
+                workers: Optional[Sequence[int]] = None) -> None:
+        """Synthetic tau-derived SRS for the listed worker indices (default: all 2^machines_scale), slice k of
+        the resident SRS = worker workers[k].  NOTE: resident slice index == position in `workers`."""
+        if workers is None:
+            workers = range(1 << machines_scale)
+        s0 = b"".join(lagrange_factor(i, machines_scale, tau_y).to_bytes(32, "big") for i in workers)
+        self._chk(self._lib.kzg_gen_srs(self._h, (tau_x % R_MODULUS).to_bytes(32, "big"), s0, len(s0) // 32, scale,
+                                        machines_scale))
+        self.scale, self.machines_scale = scale, machines_scale
+
+    def srs_read(self, first: int, count: int, window: int = 0) -> bytes:
+        out = ctypes.create_string_buffer(96 * count)
+        self._chk(self._lib.kzg_srs_read(self._h, window, first, count, out))
+        return out.raw
+
+    # ------------------------------------------------------------------ hot path
+    def commit(self, i: int, row_be32: bytes, evaluation_form: bool = True) -> bytes:
+        out = ctypes.create_string_buffer(48)
+        self._chk(self._lib.kzg_commit(self._h, i, row_be32, len(row_be32) // 32, int(evaluation_form), out))
+        return out.raw
+
+    def open(self, i: int, row_be32: bytes, alpha_be32: bytes, evaluation_form: bool = True) -> Tuple[bytes, bytes]:
+        ev, pf = ctypes.create_string_buffer(32), ctypes.create_string_buffer(48)
+        self._chk(self._lib.kzg_open(self._h, i, row_be32, len(row_be32) // 32, int(evaluation_form), alpha_be32, ev, pf))
+        return ev.raw, pf.raw
+
+    def commit_open(self, i: int, row_be32: bytes, alpha_be32: bytes,
+                    evaluation_form: bool = True) -> Tuple[bytes, bytes, bytes]:
+        c, ev, pf = ctypes.create_string_buffer(48), ctypes.create_string_buffer(32), ctypes.create_string_buffer(48)
+        self._chk(self._lib.kzg_commit_open(self._h, i, row_be32, len(row_be32) // 32, int(evaluation_form),
+                                            alpha_be32, c, ev, pf))
+        return c.raw, ev.raw, pf.raw
+
+    def msm(self, scalars_be32: bytes, srs_offset: int = 0) -> bytes:
+        out = ctypes.create_string_buffer(48)
+        self._chk(self._lib.kzg_msm(self._h, scalars_be32, len(scalars_be32) // 32, srs_offset, out))
+        return out.raw
+
+    def msm_partial(self, scalars_be32: bytes, srs_offset: int = 0) -> bytes:
+        out = ctypes.create_string_buffer(192)
+        self._chk(self._lib.kzg_msm_partial(self._h, scalars_be32, len(scalars_be32) // 32, srs_offset, out))
+        return out.raw
+
+    def g1_sum(self, partials_xyzz192: bytes) -> bytes:
+        out = ctypes.create_string_buffer(48)
+        self._chk(self._lib.kzg_g1_sum(self._h, partials_xyzz192, len(partials_xyzz192) // 192, out))
+        return out.raw
+
+    def ntt(self, vals_be32: bytes, inverse: bool) -> bytes:
+        buf = ctypes.create_string_buffer(vals_be32, len(vals_be32))
+        self._chk(self._lib.kzg_ntt(self._h, buf, len(vals_be32) // 32, int(inverse)))
+        return buf.raw
+
+    def eval(self, coeffs_be32: bytes, x_be32: bytes) -> bytes:
+        out = ctypes.create_string_buffer(32)
+        self._chk(self._lib.kzg_eval(self._h, coeffs_be32, len(coeffs_be32) // 32, x_be32, out))
+        return out.raw
+
+    # ------------------------------------------------------------------ device-resident inputs
+    def upload_fr(self, slot: int, be32: bytes, to_mont: bool) -> None:
+        self._chk(self._lib.kzg_upload_fr(self._h, slot, be32, len(be32) // 32, int(to_mont)))
+
+    def msm_resident(self, slot: int, n: int, srs_offset: int = 0) -> bytes:
+        out = ctypes.create_string_buffer(48)
+        self._chk(self._lib.kzg_msm_resident(self._h, slot, n, srs_offset, out))
+        return out.raw
+
+    def msm_partial_resident(self, slot: int, n: int, srs_offset: int = 0) -> bytes:
+        out = ctypes.create_string_buffer(192)
+        self._chk(self._lib.kzg_msm_partial_resident(self._h, slot, n, srs_offset, out))
+        return out.raw
+
+    def commit_open_resident(self, i: int, slot: int, T: int, alpha_be32: bytes,
+                             evaluation_form: bool = True) -> Tuple[bytes, bytes, bytes]:
+        c, ev, pf = ctypes.create_string_buffer(48), ctypes.create_string_buffer(32), ctypes.create_string_buffer(48)
+        self._chk(self._lib.kzg_commit_open_resident(self._h, i, slot, T, int(evaluation_form), alpha_be32, c, ev, pf))
+        return c.raw, ev.raw, pf.raw
+
+    def ntt_resident(self, slot: int, n: int, inverse: bool) -> None:
+        self._chk(self._lib.kzg_ntt_resident(self._h, slot, n, int(inverse)))
+
+    # ------------------------------------------------------------------ measurement
+    def set_profiling(self, enable: bool) -> None:
+        self._chk(self._lib.kzg_set_profiling(self._h, int(enable)))
+
+    def timings(self) -> Dict[str, float]:
+        arr = (ctypes.c_float * len(_native.TIMING_NAMES))()
+        self._chk(self._lib.kzg_get_timings(self._h, arr, len(arr)))
+        return {k: float(v) for k, v in zip(_native.TIMING_NAMES, arr)}
+
+    def msm_plan(self, n: int) -> Dict[str, int]:
+        arr = (ctypes.c_int32 * 4)()
+        self._chk(self._lib.kzg_msm_plan(self._h, n, arr))
+        return {"chunk": arr[0], "lanes": arr[1], "buckets": arr[2], "windows": arr[3]}
+
+    # ------------------------------------------------------------------ unit-op hooks (parity tests)
+    def test_field(self, field: int, op: int, a_be: bytes, b_be: bytes) -> bytes:
+        w = 48 if field == 0 else 32
+        out = ctypes.create_string_buffer(len(a_be))
+        self._chk(self._lib.kzg_test_field(self._h, field, op, a_be, b_be, out, len(a_be) // w))
+        return out.raw
+
+    def test_g1(self, op: int, a_be96: bytes, b_be96: bytes) -> bytes:
+        out = ctypes.create_string_buffer(len(a_be96))
+        self._chk(self._lib.kzg_test_g1(self._h, op, a_be96, b_be96, out, len(a_be96) // 96))
+        return out.raw
