@@ -43,11 +43,13 @@ const char* kzg_version(void);
 /* window bits c for the signed-digit Pippenger tables; 0 = choose from the slice length.  Call before the SRS. */
 int kzg_set_window(kzg_ctx* ctx, int c);
 int kzg_get_window(kzg_ctx* ctx);
+/* bit offsets of the windows actually in use: out[w] = first bit of window w, out[nwin] = 256; returns nwin */
+int kzg_get_window_layout(kzg_ctx* ctx, int32_t* out_offsets, int max);
 
 /* ---- SRS: replaces the prover's setup / precompute file loading (reference base/miner.py:75-84,
  *      utils/config.py:124-164).  The flat SRS holds 2^machines_scale-or-fewer worker slices of
  *      T = 2^(scale-machines_scale) points each, slice k at points [k*T, (k+1)*T).  Points stay resident
- *      ("cached SRS") together with their window multiples 2^(c*w) P. */
+ *      ("cached SRS") together with their window multiples 2^off[w] P. */
 int kzg_load_srs(kzg_ctx* ctx, const uint8_t* g1_affine_be96, uint64_t n_points, int scale, int machines_scale);
 /* synthetic SRS with known discrete logs (tests / benches; stands in for `fourier setup --generate-setup`,
  * reference tests/conftest.py:50-65): slice k, point j = [s0_k * tau^j] G.  s0_be32: n_slices x 32 bytes. */

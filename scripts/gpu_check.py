@@ -80,12 +80,13 @@ if want("srs"):
         exp = b"".join(oc.srs_gen(tx.to_bytes(32, "big"), ty.to_bytes(32, "big"), 6, 2, i) for i in range(4))
         say("srs points", "OK" if got == exp else "MISMATCH")
         cw = eng.window
-        nwin = (256 + cw - 1) // cw
+        offs = eng.window_offsets
+        nwin = len(offs) - 1
         okw = True
         for w in (1, nwin - 1):
             tabw = eng.srs_read(0, 4, window=w)
             for j in range(4):
-                e = o.g1_mul(o.g1_from_be96(exp[96 * j:96 * j + 96]), pow(2, cw * w, o.R))
+                e = o.g1_mul(o.g1_from_be96(exp[96 * j:96 * j + 96]), pow(2, offs[w], o.R))
                 okw &= tabw[96 * j:96 * j + 96] == o.g1_to_be96(e)
         say("window tables", "OK" if okw else "MISMATCH")
         # msm over slice 1

@@ -1,0 +1,353 @@
+"""GPU parity tests proper (`-m gpu`): every result of the HIP path, obtained through the C-ABI, is compared
+bit-for-bit with the CPU oracle on the same seeded inputs, with the committed golden fixtures, and -- at
+BASELINE.json's full sizes -- through size-independent properties (trapdoor identity [f(tau)]G, linearity,
+NTT round trip).  All arithmetic is integer: the bar is bit-exact, no tolerance anywhere."""
+import base64
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import bls12_381 as o
+from oracle import cpu as oc
+
+pytestmark = pytest.mark.gpu
+H = bytes.fromhex
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from zkp_subnet_amd import HipEngine
+
+    engines = []
+
+    def make(window=0):
+        e = HipEngine(0, window=window)   # raises if the HIP library is missing or no gfx950 device works
+        engines.append(e)
+        return e
+
+    yield make
+    for e in engines:
+        e.close()
+
+
+def rand_scalars_bytes(n, seed):
+    raw = np.random.default_rng(seed).integers(0, 256, size=(n, 32), dtype=np.uint8)
+    raw[:, 0] &= 0x3F                       # < 2^254 < r: canonical
+    return raw.tobytes()
+
+
+def ints(b):
+    return [int.from_bytes(b[i:i + 32], "big") for i in range(0, len(b), 32)]
+
+
+# ------------------------------------------------------------------ unit ops
+@pytest.mark.parametrize("field,mod,w", [(0, o.P, 48), (1, o.R, 32)])
+def test_field_ops_bit_exact(hip, field, mod, w):
+    eng = hip()
+    rnd = random.Random(100 + field)
+    edge = [0, 1, 2, mod - 1, mod - 2, (mod + 1) // 2, (1 << (8 * w - 3)) % mod, 0xFFFFFFFF, (1 << 32), mod >> 1]
+    va = [rnd.randrange(mod) for _ in range(100000)] + [x for x in edge for _ in edge]
+    vb = [rnd.randrange(mod) for _ in range(100000)] + [y for _ in edge for y in edge]
+    a = b"".join(v.to_bytes(w, "big") for v in va)
+    b = b"".join(v.to_bytes(w, "big") for v in vb)
+    for op, fn in ((0, lambda x, y: x * y % mod), (1, lambda x, y: (x + y) % mod), (2, lambda x, y: (x - y) % mod),
+                   (3, lambda x, y: x * y % mod)):
+        out = eng.test_field(field, op, a, b)
+        exp = b"".join(fn(x, y).to_bytes(w, "big") for x, y in zip(va, vb))
+        assert out == exp, f"field {field} op {op}"
+
+
+def test_g1_ops_bit_exact_including_exceptional_cases(hip):
+    eng = hip()
+    rnd = random.Random(5)
+    tb = o.g1_table()
+    pa = [tb.mul(rnd.randrange(1, o.R)) for _ in range(200)]
+    pb = [tb.mul(rnd.randrange(1, o.R)) for _ in range(200)]
+    pb[0] = pa[0]                 # P + P inside the mixed add
+    pb[1] = o.g1_neg(pa[1])       # P + (-P) = infinity
+    pb[2] = None
+    pa[3] = None
+    pa[4] = pb[4] = None
+    a = b"".join(o.g1_to_be96(p) for p in pa)
+    b = b"".join(o.g1_to_be96(p) for p in pb)
+    exp = {0: lambda x, y: o.g1_add(x, y), 1: lambda x, y: o.g1_add(o.g1_add(x, x), y),
+           2: lambda x, y: o.g1_add(x, x), 3: lambda x, y: o.g1_mul(x, 4) if x else None}
+    for op in range(4):
+        out = eng.test_g1(op, a, b)
+        assert out == b"".join(o.g1_to_be96(exp[op](x, y)) for x, y in zip(pa, pb)), f"g1 op {op}"
+
+
+# ------------------------------------------------------------------ SRS + window tables
+@pytest.mark.parametrize("window", [0, 4, 7, 13])
+def test_srs_generation_and_window_tables(hip, window):
+    eng = hip(window)
+    tx, ty = 0x1234567 + window, 0xABCDEF1
+    eng.gen_srs(tx, ty, 6, 2)
+    exp = b"".join(oc.srs_gen(tx.to_bytes(32, "big"), ty.to_bytes(32, "big"), 6, 2, i) for i in range(4))
+    assert eng.srs_read(0, 64) == exp
+    offs = eng.window_offsets
+    assert offs[0] == 0 and offs[-1] == 256 and max(b - a for a, b in zip(offs, offs[1:])) == eng.window
+    for w in (1, len(offs) // 2, len(offs) - 2):
+        tab = eng.srs_read(5, 3, window=w)
+        for j in range(3):
+            pt = o.g1_from_be96(exp[96 * (5 + j):96 * (6 + j)])
+            assert tab[96 * j:96 * j + 96] == o.g1_to_be96(o.g1_mul(pt, pow(2, offs[w], o.R)))
+
+
+def test_load_srs_roundtrip_and_rejects_bad_points(hip):
+    from zkp_subnet_amd import KzgError
+
+    eng = hip()
+    srs = oc.srs_gen((77).to_bytes(32, "big"), (1).to_bytes(32, "big"), 4, 0, 0)
+    eng.load_srs(srs, 4, 0)
+    assert eng.srs_read(0, 16) == srs
+    bad = bytearray(srs)
+    bad[95] ^= 1                                              # y off the curve
+    with pytest.raises(KzgError):
+        hip().load_srs(bytes(bad), 4, 0)
+    with pytest.raises(KzgError):
+        hip().load_srs(o.P.to_bytes(48, "big") * 2 + srs[96:], 4, 0)   # unreduced coordinate
+
+
+# ------------------------------------------------------------------ MSM
+def test_msm_golden_edge_cases(hip, golden_msm):
+    for window in (5, 9):
+        for case in golden_msm:
+            n = len(case["points"])
+            if n == 0:
+                continue
+            npad = 1 << max(0, (n - 1).bit_length())
+            eng = hip(window)
+            eng.load_srs(b"".join(H(p) for p in case["points"]) + bytes(96 * (npad - n)), npad.bit_length() - 1, 0)
+            got = eng.msm(b"".join(H(s) for s in case["scalars"]), 0)
+            assert got.hex() == case["result"], (case["name"], window)
+            eng.close()
+
+
+def test_msm_empty_is_infinity(hip):
+    eng = hip()
+    eng.gen_srs(3, 1, 4, 0)
+    assert eng.msm(b"", 0) == bytes([0xC0]) + bytes(47)
+
+
+def test_msm_rejects_non_canonical_scalar(hip):
+    from zkp_subnet_amd import KzgError
+
+    eng = hip()
+    eng.gen_srs(3, 1, 4, 0)
+    with pytest.raises(KzgError) as ei:
+        eng.msm(o.R.to_bytes(32, "big") + bytes(32), 0)
+    assert ei.value.code == -2
+    with pytest.raises(KzgError):
+        eng.msm(bytes(32) * 17, 0)                            # longer than the resident SRS
+
+
+@pytest.mark.parametrize("lg,window", [(4, 0), (9, 0), (10, 6), (12, 0), (13, 11), (14, 0)])
+def test_msm_matches_c_oracle(hip, lg, window):
+    eng = hip(window)
+    tx = 0xC0FFEE + lg
+    eng.gen_srs(tx, 1, lg, 0)
+    n = 1 << lg
+    sc = rand_scalars_bytes(n, lg)
+    srs = eng.srs_read(0, n)
+    assert srs == oc.srs_gen(tx.to_bytes(32, "big"), (1).to_bytes(32, "big"), lg, 0, 0)
+    got = eng.msm(sc, 0)
+    assert got == oc.msm(srs, sc, threads=8)
+    assert got == oc.g1_mul_gen(o.poly_eval(ints(sc), tx).to_bytes(32, "big"))        # trapdoor route
+    # ragged length and an offset window into the SRS
+    m, off = n - 3, 2
+    assert eng.msm(sc[: 32 * m], off) == oc.msm(srs[96 * off:96 * (off + m)], sc[: 32 * m], threads=8)
+
+
+@pytest.mark.parametrize("dist", ["all_equal", "small_32bit", "all_r_minus_1", "one_hot", "two_values"])
+def test_msm_adversarial_scalar_distributions(hip, dist):
+    """Structured scalars pile every digit on a few buckets: the chunked accumulate + log-depth fold must stay
+    exact (and finite) for them."""
+    lg, n = 14, 1 << 14
+    eng = hip()
+    tx = 0xBADC0DE
+    eng.gen_srs(tx, 1, lg, 0)
+    rnd = random.Random(3)
+    if dist == "all_equal":
+        sc = [0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF % o.R] * n
+    elif dist == "small_32bit":
+        sc = [rnd.randrange(1 << 32) for _ in range(n)]
+    elif dist == "all_r_minus_1":
+        sc = [o.R - 1] * n
+    elif dist == "one_hot":
+        sc = [0] * n
+        sc[n // 3] = rnd.randrange(o.R)
+    else:
+        sc = [(1 << 200) + 5 if i % 2 else (1 << 13) for i in range(n)]
+    got = eng.msm(o.fr_to_be32(sc), 0)
+    assert got == oc.g1_mul_gen(o.poly_eval(sc, tx).to_bytes(32, "big"))
+
+
+def test_msm_2_20_full_size_trapdoor_and_linearity(hip):
+    """BASELINE.json configs[1]: 2^20-point MSM, random scalars, cached SRS.  Bit-exact against [f(tau)]G, which the
+    oracle computes without any MSM; plus MSM(s) + MSM(t) == MSM(s + t) through the partial-sum ABI."""
+    lg, n = 20, 1 << 20
+    eng = hip()
+    tx = 0x5EED5EED5EED
+    eng.gen_srs(tx, 1, lg, 0)
+    s_b, t_b = rand_scalars_bytes(n, 1), rand_scalars_bytes(n, 2)
+    s, t = ints(s_b), ints(t_b)
+    eng.upload_fr(0, s_b, False)
+    got = eng.msm_resident(0, n, 0)
+    assert got == oc.g1_mul_gen(o.poly_eval(s, tx).to_bytes(32, "big"))
+    assert got == eng.msm(s_b, 0)
+    # spot-check resident points against the oracle's independent fixed-base multiplication
+    for j in (0, 1, 12345, n - 1):
+        assert eng.srs_read(j, 1) == o.g1_to_be96(o.g1_table().mul(pow(tx, j, o.R)))
+    u_b = o.fr_to_be32([(a + b) % o.R for a, b in zip(s, t)])
+    parts = eng.msm_partial(s_b, 0) + eng.msm_partial(t_b, 0)
+    assert eng.g1_sum(parts) == eng.msm(u_b, 0)
+    # SRS-segment sharding as bench.py --gpus N does it: 4 shards, 4 partials, one sum
+    quarter = n // 4
+    shards = b"".join(eng.msm_partial(s_b[32 * k * quarter:32 * (k + 1) * quarter], k * quarter) for k in range(4))
+    assert eng.g1_sum(shards) == got
+
+
+# ------------------------------------------------------------------ NTT / eval
+def test_ntt_golden_and_roundtrip(hip, golden_ntt):
+    eng = hip()
+    for case in golden_ntt:
+        a = b"".join(H(v) for v in case["input"])
+        assert eng.ntt(a, False) == b"".join(H(v) for v in case["forward"])
+        assert eng.ntt(a, True) == b"".join(H(v) for v in case["inverse"])
+
+
+@pytest.mark.parametrize("lg", [1, 3, 10, 11, 13, 16])
+def test_ntt_matches_c_oracle(hip, lg):
+    eng = hip()
+    a = rand_scalars_bytes(1 << lg, 40 + lg)
+    f = eng.ntt(a, False)
+    assert f == oc.fr_ntt(a, False)
+    assert eng.ntt(a, True) == oc.fr_ntt(a, True)
+    assert eng.ntt(f, True) == a
+
+
+def test_ntt_2_22_roundtrip_and_linearity(hip):
+    eng = hip()
+    n = 1 << 22
+    a_b, b_b = rand_scalars_bytes(n, 8), rand_scalars_bytes(n, 9)
+    fa = eng.ntt(a_b, False)
+    assert eng.ntt(fa, True) == a_b
+    # sum of the outputs == n * a_0 ... cheap closed forms: X_0 = sum a_j ; sum_i X_i = n * a_0
+    a = np.frombuffer(a_b, dtype=">u8").reshape(n, 4)
+    x0 = sum(int.from_bytes(a_b[32 * j:32 * j + 32], "big") for j in range(0, n, 1 << 10)) if False else None
+    assert int.from_bytes(fa[:32], "big") == sum(ints(a_b)) % o.R
+    fb = eng.ntt(b_b, False)
+    c_b = o.fr_to_be32([(x + y) % o.R for x, y in zip(ints(a_b[: 32 * 4096]), ints(b_b[: 32 * 4096]))])
+    # linearity on a 2^12 prefix domain (full-size linearity would need 4M Python big-int adds twice)
+    assert eng.ntt(c_b, False) == o.fr_to_be32(
+        [(x + y) % o.R for x, y in zip(ints(eng.ntt(a_b[: 32 * 4096], False)), ints(eng.ntt(b_b[: 32 * 4096], False)))])
+    del a, x0, fb
+
+
+def test_eval_reference_kat_on_gpu(hip, fr_kat):
+    """The reference's only arithmetic known-answer vector (tests/test_miner.py:33-55), through the HIP path."""
+    from zkp_subnet_amd import codec
+
+    eng = hip()
+    y = eng.eval(codec.fr_list_to_be32(fr_kat["poly"]), codec.fr_to_be32(fr_kat["point"]))
+    assert codec.be32_to_fr(y) == fr_kat["eval"]
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 4096, 70001])
+def test_eval_ragged_lengths(hip, n):
+    eng = hip()
+    c = rand_scalars_bytes(n, n)
+    x = rand_scalars_bytes(1, n + 1)
+    assert eng.eval(c, x) == oc.fr_eval(c, x)
+    assert eng.eval(c, bytes(32)) == c[:32]                      # alpha = 0
+
+
+# ------------------------------------------------------------------ KZG commit / open
+def test_kzg_golden_vectors(hip, golden_kzg):
+    tx, ty = int(golden_kzg["tau_x"], 16), int(golden_kzg["tau_y"], 16)
+    for case in golden_kzg["cases"]:
+        eng = hip()
+        eng.gen_srs(tx, ty, case["scale"], case["machines_scale"], [case["i"]])
+        row, alpha, ef = b"".join(H(v) for v in case["row"]), H(case["alpha"]), case["evaluation_form"]
+        c = eng.commit(0, row, ef)
+        ev, pf = eng.open(0, row, alpha, ef)
+        assert (c.hex(), ev.hex(), pf.hex()) == (case["commitment"], case["eval"], case["proof"]), case["name"]
+        assert eng.commit_open(0, row, alpha, ef) == (c, ev, pf), case["name"]
+        eng.close()
+
+
+@pytest.mark.parametrize("scale,ms,i", [(10, 2, 3), (12, 0, 0), (16, 4, 9), (14, 0, 0)])
+def test_kzg_commit_open_matches_c_oracle(hip, scale, ms, i):
+    eng = hip()
+    tx, ty = 0xFEEDFACE + scale, 0xDEADBEEF
+    eng.gen_srs(tx, ty, scale, ms, [i])
+    T = 1 << (scale - ms)
+    row, alpha = rand_scalars_bytes(T, scale), rand_scalars_bytes(1, 99)
+    srs = oc.srs_gen(tx.to_bytes(32, "big"), ty.to_bytes(32, "big"), scale, ms, i)
+    assert eng.srs_read(0, T) == srs
+    c, ev, pf = eng.commit_open(0, row, alpha, True)
+    assert c == oc.commit(srs, row, True, threads=8)
+    assert (ev, pf) == oc.open_(srs, row, alpha, True, threads=8)
+    assert o.verify_trapdoor(tx, ty, ms, i, o.g1_decompress(c), o.g1_decompress(pf), int.from_bytes(alpha, "big"),
+                             int.from_bytes(ev, "big"))
+
+
+def test_kzg_2_22_commit_open_bit_exact(hip):
+    """BASELINE.json configs[2]: degree-2^22 commit+open (Fr NTT + G1 MSM) on one GPU, bit-exact vs the CPU path:
+    coefficients from the C oracle's INTT, group elements through the trapdoor identities."""
+    lg, T = 22, 1 << 22
+    eng = hip()
+    tx = 0x7A0D007
+    eng.gen_srs(tx, 1, lg, 0)
+    row, alpha_b = rand_scalars_bytes(T, 22), rand_scalars_bytes(1, 23)
+    alpha = int.from_bytes(alpha_b, "big")
+    eng.upload_fr(1, row, True)
+    c, ev, pf = eng.commit_open_resident(0, 1, T, alpha_b, True)
+    coeffs_b = oc.fr_ntt(row, True)
+    y = oc.fr_eval(coeffs_b, alpha_b)
+    ft = int.from_bytes(oc.fr_eval(coeffs_b, tx.to_bytes(32, "big")), "big")
+    assert ev == y
+    assert c == oc.g1_mul_gen(ft.to_bytes(32, "big"))
+    qt = (ft - int.from_bytes(y, "big")) * o.fr_inv(tx - alpha) % o.R
+    assert pf == oc.g1_mul_gen(qt.to_bytes(32, "big"))
+    assert eng.commit_open(0, row, alpha_b, True) == (c, ev, pf)        # host-buffer entry point agrees
+
+
+def test_client_and_miner_on_hip_engine(hip, fr_kat):
+    """The reference miner test (tests/test_miner.py:62-121) on the HIP engine: 16-coefficient TEST_POLY at
+    scale 6 / machines_scale 2; forward() returns the client's commitment and proof; oracle agrees bit for bit."""
+    from zkp_subnet_amd import codec
+    from zkp_subnet_amd.client import Client, derive_taus
+    from zkp_subnet_amd.miner import Miner, default_config
+    from zkp_subnet_amd.protocol import Prove
+
+    client = Client(port=1337, bin="./test_prover", setup_path="test_setup.compressed",
+                    precompute_path="test_precompute.compressed", seed=6)
+    miner = Miner(default_config(scale=6, machines_scale=2, seed=6), client=client)
+    syn = Prove(index=0, poly=fr_kat["poly"], alpha=fr_kat["point"], eval=fr_kat["eval"])
+    with miner.client.worker_commit(i=0, poly=syn.poly) as r:
+        assert r.status_code == 200
+        commitment = r.json()["commitment"]
+    with miner.client.worker_open(i=0, poly=syn.poly, x=syn.alpha) as r:
+        assert r.status_code == 200
+        ev, proof = r.json()["eval"], r.json()["proof"]
+    ret = miner.forward(syn)
+    assert (ret.commitment, ret.proof, ret.eval) == (commitment, proof, ev)
+    tx, ty = derive_taus(6)
+    srs = oc.srs_gen(tx.to_bytes(32, "big"), ty.to_bytes(32, "big"), 6, 2, 0)
+    row = codec.fr_list_to_be32(syn.poly)
+    assert codec.g1_from_b64(commitment) == oc.commit(srs, row, True)
+    assert (codec.fr_to_be32(ev), codec.g1_from_b64(proof)) == oc.open_(srs, row, codec.fr_to_be32(syn.alpha), True)
+    assert miner.client.worker_commit(i=0, poly=["bad"]).status_code == 400
+    too_big = base64.b64encode((o.R + 5).to_bytes(32, "big")).decode().rstrip("=")
+    assert miner.client.worker_commit(i=0, poly=[too_big] * 16).status_code == 400                 # Fr >= r
+    with miner.client.fft(syn.poly, left=True, inverse=True) as r:
+        coeffs = r.json()["poly"]
+    with miner.client.eval(coeffs, syn.alpha) as r:
+        assert r.json()["y"] == ev
+    miner.stop()

@@ -1,0 +1,151 @@
+"""CPU-only tests of the host side above the C-ABI: the Client method surface / status mapping, the miner and
+validator mirrors, and the config-1 plumbing loop (degree-2^12 commit through the CPU prover under a mock
+miner/validator loop, BASELINE.json configs[0]).  The engine is the oracle-backed stand-in (tests/oracle_engine.py);
+the same tests run against the HIP engine in tests/test_gpu_kzg.py."""
+import base64
+import random
+
+import pytest
+
+from oracle import bls12_381 as o
+from tests.oracle_engine import OracleEngine
+from zkp_subnet_amd import codec
+from zkp_subnet_amd.client import Client, derive_taus
+from zkp_subnet_amd.miner import Miner, default_config
+from zkp_subnet_amd.protocol import Prove
+from zkp_subnet_amd.validator import Challenge, generate_challenge, reward
+
+H = bytes.fromhex
+
+
+def make_client(scale, ms, workers=None, seed=3):
+    c = Client(port=1337, bin="./prover", uncompressed=False, setup_path="", precompute_path="",
+               engine=OracleEngine(), seed=seed, workers=workers)
+    c.start(scale=scale, machines_scale=ms)
+    return c
+
+
+def test_client_surface_matches_reference_call_sites():
+    # keyword names used by reference tests/test_miner.py:88-107
+    c = make_client(6, 2)
+    rnd = random.Random(1)
+    poly = [o.fr_to_b64(rnd.randrange(o.R)) for _ in range(16)]
+    x = o.fr_to_b64(rnd.randrange(o.R))
+    with c.worker_commit(i=0, poly=poly) as resp:
+        assert resp.status_code == 200
+        commitment = resp.json().get("commitment")
+    with c.worker_open(i=0, poly=poly, x=x) as resp:
+        assert resp.status_code == 200
+        ev, proof = resp.json().get("eval"), resp.json().get("proof")
+    with c.worker_verify(i=0, proof=proof, alpha=x, eval=ev, commitment=commitment) as resp:
+        assert resp.status_code == 200 and resp.json().get("valid") is True
+    assert len(commitment) == 64 and len(proof) == 64 and len(ev) == 43
+    # fused extension agrees with the two-call path
+    with c.worker_commit_and_open(0, poly, x) as resp:
+        assert resp.json() == {"commitment": commitment, "eval": ev, "proof": proof}
+    # P3: eval == eval(fft(poly, left=True, inverse=True), x)   (reference neurons/validator.py:115-118)
+    with c.fft(poly, left=True, inverse=True) as resp:
+        coeffs = resp.json().get("poly")
+    with c.eval(coeffs, x) as resp:
+        assert resp.json().get("y") == ev
+    with c.random_poly() as resp:
+        rows = resp.json().get("poly")
+        assert len(rows) == 4 and all(len(r) == 16 for r in rows)
+    with c.random_point() as resp:
+        assert len(resp.json().get("point")) == 43
+    c.stop()
+
+
+def test_client_golden_vectors(golden_kzg):
+    tx, ty = int(golden_kzg["tau_x"], 16), int(golden_kzg["tau_y"], 16)
+    for case in golden_kzg["cases"]:
+        if not case["evaluation_form"]:
+            continue
+        eng = OracleEngine()
+        eng.gen_srs(tx, ty, case["scale"], case["machines_scale"], [case["i"]])
+        c = Client(engine=eng)
+        c.scale, c.machines_scale, c._slice_of = case["scale"], case["machines_scale"], {case["i"]: 0}
+        poly = [o.fr_to_b64(int(v, 16)) for v in case["row"]]
+        with c.worker_commit(case["i"], poly) as r:
+            assert base64.b64decode(r.json()["commitment"]).hex() == case["commitment"], case["name"]
+        with c.worker_open(case["i"], poly, o.fr_to_b64(int(case["alpha"], 16))) as r:
+            assert o.fr_from_b64(r.json()["eval"]) == int(case["eval"], 16)
+            assert base64.b64decode(r.json()["proof"]).hex() == case["proof"]
+
+
+def test_client_error_statuses_never_raise():
+    c = make_client(6, 2, workers=[1])
+    good = [o.fr_to_b64(5)] * 16
+    assert c.worker_commit(1, good).status_code == 200
+    assert c.worker_commit(0, good).status_code == 400          # no resident slice for worker 0
+    assert c.worker_commit(7, good).status_code == 400          # index >= 2^machines_scale
+    assert c.worker_commit(1, ["@@@"]).status_code == 400       # not base64
+    assert c.worker_open(1, good, "short").status_code == 400
+    not_started = Client(engine=None)
+    not_started.engine = None
+    assert not_started.worker_commit(0, good).status_code == 503
+
+
+def test_miner_forward_matches_client_and_swallows_errors():
+    """Reference tests/test_miner.py:62-121: forward() returns exactly the client's commitment / proof; any failure
+    echoes the request (neurons/miner.py:133-135)."""
+    cfg = default_config(scale=6, machines_scale=2, seed=11)
+    client = Client(engine=OracleEngine(), seed=11)
+    rnd = random.Random(2)
+    poly = [o.fr_to_b64(rnd.randrange(o.R)) for _ in range(16)]
+    alpha = o.fr_to_b64(rnd.randrange(o.R))
+    for fused in (False, True):
+        cfg.fused = fused
+        miner = Miner(cfg, client=client)
+        syn = Prove(index=2, poly=poly, alpha=alpha)
+        with miner.client.worker_commit(i=2, poly=poly) as r:
+            commitment = r.json()["commitment"]
+        with miner.client.worker_open(i=2, poly=poly, x=alpha) as r:
+            ev, proof = r.json()["eval"], r.json()["proof"]
+        ret = miner.forward(syn)
+        assert (ret.commitment, ret.eval, ret.proof) == (commitment, ev, proof)
+        assert ret.poly == [] and ret.alpha is None and ret.index == 2
+        bad = Prove(index=2, poly=poly, alpha=None)   # include_point=False branch of the reference test
+        assert miner.forward(bad) is bad
+        bad2 = Prove(index=9, poly=poly, alpha=alpha)
+        assert miner.forward(bad2) is bad2
+
+
+def test_validator_reward_table():
+    """Reference tests/test_validator.py:60-121: ok / missing / late / bit-flipped proof / half-time."""
+    c = make_client(6, 2, seed=5)
+    miner = Miner(default_config(scale=6, machines_scale=2), client=c)
+    ch = generate_challenge(c, 2)
+    assert isinstance(ch, Challenge) and len(ch.evals) == 2
+    responses = [miner.forward(ch.to_synapse(i)) for i in range(2)]
+    assert [reward(c, ch, responses[i], i, 0.0) for i in range(2)] == [1.0, 1.0]
+    assert reward(c, ch, None, 0, 0.0) == 0.0
+    assert reward(c, ch, responses[0], 0, 31.0) == 0.0
+    assert reward(c, ch, responses[0], 0, 15.0) == 0.5
+    raw = base64.b64decode(responses[0].proof)                     # reference test_validator.py:79-86
+    bumped = base64.b64encode((int.from_bytes(raw, "big") + 1).to_bytes(len(raw), "big")).decode()
+    corrupt = responses[0].model_copy(update={"proof": bumped})
+    assert reward(c, ch, corrupt, 0, 0.0) == 0.0
+    # the miner's eval equals the validator's independently computed one
+    assert responses[1].eval == ch.evals[1]
+
+
+def test_config1_plumbing_degree_4096_commit_under_mock_loop():
+    """BASELINE.json configs[0]: degree-2^12 random polynomial (scale 20 / machines_scale 8 shape) through the CPU
+    prover under the miner/validator loop.  Trapdoor cross-check keeps it independent of the prover's own MSM."""
+    seed = 7
+    c = make_client(20 - 8 + 1, 1, workers=[1], seed=seed)      # T = 2^12, one resident worker slice
+    miner = Miner(default_config(scale=13, machines_scale=1), client=c)
+    rnd = random.Random(0)
+    row = [rnd.randrange(o.R) for _ in range(1 << 12)]
+    alpha = rnd.randrange(o.R)
+    syn = Prove(index=1, poly=[o.fr_to_b64(v) for v in row], alpha=o.fr_to_b64(alpha))
+    ret = miner.forward(syn)
+    assert ret.commitment is not None and ret.proof is not None
+    tx, ty = derive_taus(seed)
+    coeffs = o.ntt(row, inverse=True)
+    assert codec.g1_from_b64(ret.commitment) == o.g1_compress(o.trapdoor_commit(tx, ty, 1, 1, coeffs))
+    y, pi = o.trapdoor_open(tx, ty, 1, 1, coeffs, alpha)
+    assert o.fr_from_b64(ret.eval) == y and codec.g1_from_b64(ret.proof) == o.g1_compress(pi)
+    with c.worker_verify(1, ret.proof, syn.alpha, ret.eval, ret.commitment) as r:
+        assert r.json()["valid"] is True

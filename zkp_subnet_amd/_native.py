@@ -23,6 +23,7 @@ SYMBOLS = {
     "kzg_version": (ctypes.c_char_p, []),
     "kzg_set_window": (_I, [_P, _I]),
     "kzg_get_window": (_I, [_P]),
+    "kzg_get_window_layout": (_I, [_P, ctypes.POINTER(ctypes.c_int32), _I]),
     "kzg_load_srs": (_I, [_P, _B, _U64, _I, _I]),
     "kzg_gen_srs": (_I, [_P, _B, _B, _U32, _I, _I]),
     "kzg_srs_points": (_U64, [_P]),

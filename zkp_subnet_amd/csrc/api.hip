@@ -59,6 +59,7 @@ struct kzg_ctx {
     std::mutex mu;
     std::string err;
     int c_user = 0, c = 0, nwin = 0;
+    WinLayout lay;
     uint32_t nbuckets = 0;
     // resident SRS + window tables: table[w*stride + j] = 2^(c*w) P_j
     DevBuf table;
@@ -144,10 +145,18 @@ int choose_window(uint64_t T) {
     if (lg <= 22) return 16;
     return 18;
 }
+// nwin = ceil(256/c) windows of width base or base+1 (256 = nwin*base + extra): the widest is <= c bits
 void set_window(kzg_ctx* ctx, int c) {
-    ctx->c = c;
-    ctx->nwin = (256 + c - 1) / c;
-    ctx->nbuckets = 1u << (c - 1);
+    const int nwin = (256 + c - 1) / c, base = 256 / nwin, extra = 256 % nwin;
+    ctx->nwin = ctx->lay.nwin = nwin;
+    int off = 0;
+    for (int w = 0; w < nwin; w++) {
+        ctx->lay.off[w] = (uint16_t)off;
+        off += base + (w < extra ? 1 : 0);
+    }
+    ctx->lay.off[nwin] = 256;
+    ctx->c = base + (extra ? 1 : 0);
+    ctx->nbuckets = 1u << (ctx->c - 1);
 }
 int pick_chunk(uint64_t entries) {
     uint64_t k = (entries + 131071) / 131072;  // ~2 waves per SIMD on 256 CUs
@@ -173,7 +182,7 @@ int msm_core(kzg_ctx* ctx, const uint32_t* scalars, int mont, uint64_t n, uint64
     const uint64_t entries = n * (uint64_t)ctx->nwin;
     if (entries >= ((uint64_t)1 << 32)) return fail(ctx, KZG_E_ARG, "MSM too large for 32-bit entry indices");
     MsmShape sh;
-    sh.c = ctx->c; sh.nwin = ctx->nwin; sh.nbuckets = ctx->nbuckets; sh.n = n;
+    sh.c = ctx->c; sh.nwin = ctx->nwin; sh.lay = ctx->lay; sh.nbuckets = ctx->nbuckets; sh.n = n;
     sh.srs_offset = srs_offset; sh.srs_stride = ctx->stride; sh.chunk = pick_chunk(entries);
     const uint32_t nchunks = (uint32_t)((entries + sh.chunk - 1) / sh.chunk);
     const size_t B = ctx->nbuckets;
@@ -183,8 +192,9 @@ int msm_core(kzg_ctx* ctx, const uint32_t* scalars, int mont, uint64_t n, uint64
     HIPCHK(ctx, ctx->offsets.ensure((B + 1) * 4));
     HIPCHK(ctx, ctx->bufA.ensure(B * sizeof(g1_xyzz_t)));
     HIPCHK(ctx, ctx->bufB.ensure(B * sizeof(g1_xyzz_t)));
-    HIPCHK(ctx, ctx->carries.ensure((size_t)nchunks * sizeof(g1_xyzz_t)));
-    HIPCHK(ctx, ctx->carry_key.ensure((size_t)nchunks * 4));
+    const size_t nfold = ((size_t)nchunks + MSM_FOLD_K - 1) / MSM_FOLD_K;  // ping-pong: level 0 | levels 1..
+    HIPCHK(ctx, ctx->carries.ensure(((size_t)nchunks + nfold) * sizeof(g1_xyzz_t)));
+    HIPCHK(ctx, ctx->carry_key.ensure(((size_t)nchunks + nfold) * 4));
     {
         Span sp(ctx, KZG_T_DIGITS);
         HIPCHK(ctx, hipMemsetAsync(ctx->hist.p, 0, B * 4, s));
@@ -208,8 +218,17 @@ int msm_core(kzg_ctx* ctx, const uint32_t* scalars, int mont, uint64_t n, uint64
     }
     {
         Span sp(ctx, KZG_T_FIXUP);
-        launch_msm_fixup(s, ctx->bufA.as<g1_xyzz_t>(), ctx->carries.as<g1_xyzz_t>(), ctx->carry_key.as<uint32_t>(),
-                         nchunks);
+        g1_xyzz_t* pt_a = ctx->carries.as<g1_xyzz_t>();
+        uint32_t* key_a = ctx->carry_key.as<uint32_t>();
+        g1_xyzz_t* pt_b = pt_a + nchunks;
+        uint32_t* key_b = key_a + nchunks;
+        for (uint32_t cnt = nchunks; cnt;) {  // last level: one lane, nothing precedes it -> no output record
+            launch_msm_fold(s, ctx->bufA.as<g1_xyzz_t>(), pt_a, key_a, cnt, pt_b, key_b);
+            if (cnt <= MSM_FOLD_K) break;
+            cnt = (cnt + MSM_FOLD_K - 1) / MSM_FOLD_K;
+            std::swap(pt_a, pt_b);
+            std::swap(key_a, key_b);
+        }
     }
     g1_xyzz_t* in = ctx->bufA.as<g1_xyzz_t>();
     g1_xyzz_t* out = ctx->bufB.as<g1_xyzz_t>();
@@ -370,7 +389,7 @@ int precompute_tables(kzg_ctx* ctx) {
     HIPCHK(ctx, tmp.ensure((size_t)(ctx->nwin - 1) * tile * sizeof(g1_xyzz_t) + 256));
     for (uint64_t first = 0; first < ctx->stride; first += tile) {
         uint64_t cnt = ctx->stride - first < tile ? ctx->stride - first : tile;
-        launch_srs_precompute(ctx->stream, ctx->table.as<g1_affine_t>(), ctx->stride, first, cnt, ctx->c, ctx->nwin,
+        launch_srs_precompute(ctx->stream, ctx->table.as<g1_affine_t>(), ctx->stride, first, cnt, ctx->lay,
                               tmp.as<g1_xyzz_t>());
     }
     hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -490,6 +509,11 @@ int kzg_set_window(kzg_ctx* ctx, int c) {
     return KZG_OK;
 }
 int kzg_get_window(kzg_ctx* ctx) { return ctx ? ctx->c : 0; }
+int kzg_get_window_layout(kzg_ctx* ctx, int32_t* out_offsets, int max) {
+    if (!ctx || !out_offsets || !ctx->c) return KZG_E_ARG;
+    for (int w = 0; w <= ctx->nwin && w < max; w++) out_offsets[w] = ctx->lay.off[w];
+    return ctx->nwin;
+}
 uint64_t kzg_srs_points(kzg_ctx* ctx) { return ctx ? ctx->stride : 0; }
 
 int kzg_load_srs(kzg_ctx* ctx, const uint8_t* g1_affine_be96, uint64_t n_points, int scale, int machines_scale) {

@@ -168,12 +168,61 @@ KZG_DEV void g1_add(g1_xyzz_t& r, const g1_xyzz_t& p, const g1_xyzz_t& q) {
     fp_mul(t, p.zzz, q.zzz); fp_mul(r.zzz, t, PPP);
 }
 
-// ---- Fp inversion a^(p-2) (Fermat).  Only used O(1) times per MSM / in amortised batch inversions.
+// ---- Fp inversion.  One lane's Fermat ladder (381 squarings) costs > 1 ms of pure latency on a GPU, so the
+// single inversion that ends every MSM uses the binary extended Euclid instead: only shifts, adds and compares on
+// 12 limbs, ~760 halvings + ~380 subtractions.  Invariants x1*A = u*k, x2*A = v*k (mod p) with k = R^2, so for a
+// Montgomery-form input A = aR the result x1 = R^2/A = a^-1 R is the Montgomery form of the inverse directly.
+template <int N>
+KZG_DEV void bi_shr1(uint32_t* a) {
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) a[i] = __builtin_amdgcn_alignbit(a[i + 1], a[i], 1);
+    a[N - 1] >>= 1;
+}
+KZG_DEV void fp_half(uint32_t* x) {  // x/2 mod p for x in [0, p)
+    const uint32_t mask = 0u - (x[0] & 1u);
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) x[i] = __builtin_addc(x[i], FpParams::mod(i) & mask, c, &c);  // < 2^382: no carry out
+    bi_shr1<12>(x);
+}
+KZG_DEV bool bi_is_one12(const uint32_t* a) {
+    uint32_t t = a[0] ^ 1u;
+#pragma unroll
+    for (int i = 1; i < 12; i++) t |= a[i];
+    return t == 0;
+}
+KZG_DEV void fp_inv(fp_t& r, const fp_t& a) {
+    if (f_is_zero(a)) { f_zero(r); return; }
+    uint32_t u[12], v[12];
+    fp_t x1, x2;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        u[i] = a.l[i];
+        v[i] = FpParams::mod(i);
+        x1.l[i] = FpParams::r2(i);
+        x2.l[i] = 0;
+    }
+    for (int guard = 0; guard < 2000 && !bi_is_one12(u) && !bi_is_one12(v); guard++) {  // bounded: never hangs
+        while (!(u[0] & 1u)) { bi_shr1<12>(u); fp_half(x1.l); }
+        while (!(v[0] & 1u)) { bi_shr1<12>(v); fp_half(x2.l); }
+        if (bi_ge<12>(u, v)) {
+            bi_sub<12>(u, u, v);
+            f_sub(x1, x1, x2);
+            if (bi_is_zero<12>(u)) break;  // u == v == 1 before the subtraction
+        } else {
+            bi_sub<12>(v, v, u);
+            f_sub(x2, x2, x1);
+        }
+    }
+    const bool take_x1 = bi_is_one12(u);
+    bi_select<12>(r.l, x2.l, x1.l, take_x1);
+}
+// Fermat ladder a^(p-2): used where thousands of lanes invert at once (throughput-bound batch normalisation)
 struct FpInvExp {
     static constexpr int BITS = 381;
     __device__ static constexpr uint32_t limb(int i) { return i == 0 ? FpParams::mod(0) - 2u : FpParams::mod(i); }
 };
-KZG_DEV void fp_inv(fp_t& r, const fp_t& a) {
+KZG_DEV void fp_inv_fermat(fp_t& r, const fp_t& a) {
     fp_t acc;
     f_one(acc);
     for (int i = FpInvExp::BITS - 1; i >= 0; i--) {

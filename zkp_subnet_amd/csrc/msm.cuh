@@ -9,15 +9,22 @@
 //   4. msm_accumulate    HOT: every lane sums a fixed-size chunk of the sorted entries with mixed XYZZ adds
 //                        (perfect load balance for any scalar distribution); bucket runs that span chunks
 //                        leave "carry" partial sums
-//   5. msm_fixup         folds the carries into their buckets
+//   5. msm_fold          folds the carries into their buckets, MSM_FOLD_K-ary, log depth for ANY distribution
 //   6. msm_tree_level    log2(B) pairwise-merge levels producing P = sum B_k and T_i = sum_{bit i of k} B_k
 //   7. msm_final         sum = P + sum_i 2^i T_i  (-> XYZZ, optionally affine + 48-byte compression)
 #pragma once
 #include "g1.cuh"
 
+// Window w covers scalar bits [off[w], off[w+1]); off[nwin] = 256.  Widths differ by at most one bit
+// (256 = nwin*base + extra), so no window is a short "top" window that would pile its digits on a few buckets.
+struct WinLayout {
+    int nwin;
+    uint16_t off[66];
+};
 struct MsmShape {
-    int c;               // window bits
-    int nwin;            // ceil(256 / c) signed windows
+    int c;               // widest window, bits
+    int nwin;            // signed windows
+    WinLayout lay;
     uint32_t nbuckets;   // 2^(c-1)
     uint64_t n;          // number of (scalar, point) pairs in this MSM
     uint64_t srs_offset; // first point of the slice inside the resident SRS
@@ -33,8 +40,12 @@ void launch_msm_scatter(hipStream_t s, const MsmShape& sh, const uint32_t* scala
 void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t* table, const uint32_t* offsets,
                            const uint32_t* sorted, g1_xyzz_t* buckets, g1_xyzz_t* carries, uint32_t* carry_key,
                            uint32_t nchunks);
-void launch_msm_fixup(hipStream_t s, g1_xyzz_t* buckets, const g1_xyzz_t* carries, const uint32_t* carry_key,
-                      uint32_t nchunks);
+// one fold level: records (key, point) sorted by key, NONE_KEY = no record.  Each lane folds FOLD_K records;
+// a run that began in an earlier lane's range goes to (out_key, out_pt)[lane], runs beginning here are added
+// into their bucket.  Repeated until one lane covers everything: serial depth FOLD_K * log_FOLD_K(n).
+#define MSM_FOLD_K 8
+void launch_msm_fold(hipStream_t s, g1_xyzz_t* buckets, const g1_xyzz_t* in_pt, const uint32_t* in_key, uint32_t n_in,
+                     g1_xyzz_t* out_pt, uint32_t* out_key);
 // level i: in = nodes of (i+1) points, component-major; out = nodes of (i+2) points
 void launch_msm_tree_level(hipStream_t s, const g1_xyzz_t* in, g1_xyzz_t* out, uint32_t n_in_nodes, int level);
 // node = [P, T_0 .. T_{nbits-1}] ; out_xyzz = P + sum 2^i T_i
@@ -49,7 +60,7 @@ void launch_srs_from_be96(hipStream_t s, const uint8_t* be96, g1_affine_t* out, 
 void launch_srs_to_be96(hipStream_t s, const g1_affine_t* in, uint8_t* be96, uint64_t n);
 // window tables for points [first, first+count): tmp holds (nwin-1)*count XYZZ values
 void launch_srs_precompute(hipStream_t s, g1_affine_t* table, uint64_t stride, uint64_t first, uint64_t count,
-                           int c, int nwin, g1_xyzz_t* tmp);
+                           const WinLayout& lay, g1_xyzz_t* tmp);
 // synthetic SRS: out[j] = [s0 * tau^(j_base+j)] G for j < count (discrete logs known -> tests / benches only)
 // (global index j_base + j); gtab: 32*255 affine scratch (built when build_gtab); tmp: count XYZZ + count*32 B
 void launch_srs_generate(hipStream_t s, g1_affine_t* out, uint64_t count, uint64_t j_base, const uint32_t* tau_mont,

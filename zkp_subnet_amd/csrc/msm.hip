@@ -29,30 +29,32 @@ KZG_DEV void load_scalar(uint32_t* s, const uint32_t* scalars, uint64_t j, int m
     for (int i = 0; i < 8; i++) s[i] = v.l[i];
 }
 // signed-digit recoding: digit in [-2^(c-1)+1, 2^(c-1)]; returns magnitude (0 = skip), sets neg, updates carry
-KZG_DEV uint32_t signed_digit(const uint32_t* s, int w, int c, uint32_t& carry, uint32_t& neg) {
-    uint32_t d = window_bits(s, w * c, c) + carry;
+KZG_DEV uint32_t signed_digit(const uint32_t* s, int w, const WinLayout& lay, uint32_t& carry, uint32_t& neg) {
+    const int lo = lay.off[w], c = lay.off[w + 1] - lo;
+    uint32_t d = window_bits(s, lo, c) + carry;
     const uint32_t half = 1u << (c - 1);
     neg = d > half;
     carry = neg;
     return neg ? (1u << c) - d : d;
 }
 
-__global__ void __launch_bounds__(256) k_msm_digits_hist(const uint32_t* __restrict__ scalars, uint64_t n, int c,
-                                                          int nwin, int mont, uint32_t* __restrict__ hist,
+__global__ void __launch_bounds__(256) k_msm_digits_hist(const uint32_t* __restrict__ scalars, uint64_t n,
+                                                          const WinLayout lay, int mont, uint32_t* __restrict__ hist,
                                                           uint32_t* __restrict__ rank) {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     uint32_t s[8];
     load_scalar(s, scalars, j, mont);
     uint32_t carry = 0, neg;
-    for (int w = 0; w < nwin; w++) {
-        uint32_t mag = signed_digit(s, w, c, carry, neg);
+    for (int w = 0; w < lay.nwin; w++) {
+        uint32_t mag = signed_digit(s, w, lay, carry, neg);
         if (mag) rank[(uint64_t)w * n + j] = atomicAdd(&hist[mag - 1], 1u);
     }
 }
 
-__global__ void __launch_bounds__(256) k_msm_scatter(const uint32_t* __restrict__ scalars, uint64_t n, int c,
-                                                      int nwin, int mont, uint64_t srs_offset, uint64_t srs_stride,
+__global__ void __launch_bounds__(256) k_msm_scatter(const uint32_t* __restrict__ scalars, uint64_t n,
+                                                      const WinLayout lay, int mont, uint64_t srs_offset,
+                                                      uint64_t srs_stride,
                                                       const uint32_t* __restrict__ offsets,
                                                       const uint32_t* __restrict__ rank,
                                                       uint32_t* __restrict__ sorted) {
@@ -61,8 +63,8 @@ __global__ void __launch_bounds__(256) k_msm_scatter(const uint32_t* __restrict_
     uint32_t s[8];
     load_scalar(s, scalars, j, mont);
     uint32_t carry = 0, neg;
-    for (int w = 0; w < nwin; w++) {
-        uint32_t mag = signed_digit(s, w, c, carry, neg);
+    for (int w = 0; w < lay.nwin; w++) {
+        uint32_t mag = signed_digit(s, w, lay, carry, neg);
         if (mag) {
             uint32_t pos = offsets[mag - 1] + rank[(uint64_t)w * n + j];
             sorted[pos] = (uint32_t)((uint64_t)w * srs_stride + srs_offset + j) | (neg << 31);
@@ -188,23 +190,46 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t* __res
     carry_key[t] = my_carry_key;
 }
 
-// Carries of one bucket are contiguous in chunk order; the first lane of each run folds the run into the bucket.
-__global__ void __launch_bounds__(256) k_msm_fixup(g1_xyzz_t* __restrict__ buckets,
-                                                    const g1_xyzz_t* __restrict__ carries,
-                                                    const uint32_t* __restrict__ carry_key, uint32_t nchunks) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nchunks) return;
-    const uint32_t key = carry_key[t];
-    if (key == NONE_KEY) return;
-    if (t > 0 && carry_key[t - 1] == key) return;
+// One fold level over (key, point) records sorted by key (NONE_KEY = empty slot; a run of equal keys is
+// contiguous).  Lane v folds records [v*K, (v+1)*K): a run continuing from the previous lane's range becomes this
+// lane's output record; a run that BEGINS in this range is added into its bucket (its beginner is the bucket's
+// only writer in this launch).  Works for any distribution: n records shrink to n/K per level.
+__global__ void __launch_bounds__(256) k_msm_fold(g1_xyzz_t* __restrict__ buckets, const g1_xyzz_t* __restrict__ in_pt,
+                                                   const uint32_t* __restrict__ in_key, uint32_t n_in,
+                                                   g1_xyzz_t* __restrict__ out_pt, uint32_t* __restrict__ out_key) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lo = v * MSM_FOLD_K;
+    if (lo >= n_in) return;
+    const uint32_t hi = min(lo + MSM_FOLD_K, n_in);
+    const uint32_t prev = lo ? in_key[lo - 1] : NONE_KEY;
+    uint32_t cur = NONE_KEY, my_key = NONE_KEY;
+    bool cur_is_carry = false;
     g1_xyzz_t acc, q, r;
-    load_xyzz(acc, &buckets[key]);
-    for (uint32_t u = t; u < nchunks && carry_key[u] == key; u++) {
-        load_xyzz(q, &carries[u]);
-        g1_add(r, acc, q);
-        acc = r;
+    g1_set_inf(acc);
+    for (uint32_t u = lo; u <= hi; u++) {
+        const uint32_t k = u < hi ? in_key[u] : NONE_KEY;
+        if (k != cur) {
+            if (cur != NONE_KEY) {  // close the finished run
+                if (cur_is_carry) {
+                    store_xyzz(&out_pt[v], acc);
+                    my_key = cur;
+                } else {
+                    load_xyzz(q, &buckets[cur]);
+                    g1_add(r, q, acc);
+                    store_xyzz(&buckets[cur], r);
+                }
+            }
+            cur = k;
+            cur_is_carry = (u == lo) && (k == prev);
+            g1_set_inf(acc);
+        }
+        if (k != NONE_KEY) {
+            load_xyzz(q, &in_pt[u]);
+            g1_add(r, acc, q);
+            acc = r;
+        }
     }
-    store_xyzz(&buckets[key], acc);
+    out_key[v] = my_key;
 }
 
 // ------------------------------------------------------------------------------------------------ bucket tree
@@ -330,17 +355,18 @@ __global__ void __launch_bounds__(256) k_srs_to_be96(const g1_affine_t* __restri
     limbs_to_be<12>(be + 96 * j + 48, y.l);
 }
 
-// window tables: tmp[(w-1)*count + j] = 2^(c*w) P_{first+j} in XYZZ
+// window tables: tmp[(w-1)*count + j] = 2^off[w] P_{first+j} in XYZZ
 __global__ void __launch_bounds__(256) k_precomp_dbl(const g1_affine_t* __restrict__ table, uint64_t first,
-                                                      uint64_t count, int c, int nwin, g1_xyzz_t* __restrict__ tmp) {
+                                                      uint64_t count, const WinLayout lay,
+                                                      g1_xyzz_t* __restrict__ tmp) {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     g1_affine_t p;
     load_affine(p, table + first + j);
     g1_xyzz_t cur, r;
     g1_from_affine(cur, p);
-    for (int w = 1; w < nwin; w++) {
-        for (int k = 0; k < c; k++) {
+    for (int w = 1; w < lay.nwin; w++) {
+        for (int k = lay.off[w - 1]; k < lay.off[w]; k++) {
             g1_dbl(r, cur);
             cur = r;
         }
@@ -507,7 +533,7 @@ static inline uint32_t nblk(uint64_t n, uint32_t b) { return (uint32_t)((n + b -
 void launch_msm_digits_hist(hipStream_t s, const MsmShape& sh, const uint32_t* scalars, int scalars_mont,
                             uint32_t* hist, uint32_t* rank) {
     if (!sh.n) return;
-    k_msm_digits_hist<<<nblk(sh.n, 256), 256, 0, s>>>(scalars, sh.n, sh.c, sh.nwin, scalars_mont, hist, rank);
+    k_msm_digits_hist<<<nblk(sh.n, 256), 256, 0, s>>>(scalars, sh.n, sh.lay, scalars_mont, hist, rank);
 }
 void launch_msm_scan(hipStream_t s, const MsmShape& sh, const uint32_t* hist, uint32_t* offsets) {
     k_msm_scan<<<1, 1024, 0, s>>>(hist, sh.nbuckets, offsets);
@@ -515,8 +541,8 @@ void launch_msm_scan(hipStream_t s, const MsmShape& sh, const uint32_t* hist, ui
 void launch_msm_scatter(hipStream_t s, const MsmShape& sh, const uint32_t* scalars, int scalars_mont,
                         const uint32_t* offsets, const uint32_t* rank, uint32_t* sorted) {
     if (!sh.n) return;
-    k_msm_scatter<<<nblk(sh.n, 256), 256, 0, s>>>(scalars, sh.n, sh.c, sh.nwin, scalars_mont, sh.srs_offset,
-                                                  sh.srs_stride, offsets, rank, sorted);
+    k_msm_scatter<<<nblk(sh.n, 256), 256, 0, s>>>(scalars, sh.n, sh.lay, scalars_mont, sh.srs_offset, sh.srs_stride,
+                                                  offsets, rank, sorted);
 }
 void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t* table, const uint32_t* offsets,
                            const uint32_t* sorted, g1_xyzz_t* buckets, g1_xyzz_t* carries, uint32_t* carry_key,
@@ -525,10 +551,11 @@ void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t*
     k_msm_accumulate<<<nblk(nchunks, 256), 256, 0, s>>>(table, offsets, sorted, sh.nbuckets, (uint32_t)sh.chunk,
                                                         nchunks, buckets, carries, carry_key);
 }
-void launch_msm_fixup(hipStream_t s, g1_xyzz_t* buckets, const g1_xyzz_t* carries, const uint32_t* carry_key,
-                      uint32_t nchunks) {
-    if (!nchunks) return;
-    k_msm_fixup<<<nblk(nchunks, 256), 256, 0, s>>>(buckets, carries, carry_key, nchunks);
+void launch_msm_fold(hipStream_t s, g1_xyzz_t* buckets, const g1_xyzz_t* in_pt, const uint32_t* in_key, uint32_t n_in,
+                     g1_xyzz_t* out_pt, uint32_t* out_key) {
+    if (!n_in) return;
+    k_msm_fold<<<nblk((n_in + MSM_FOLD_K - 1) / MSM_FOLD_K, 256), 256, 0, s>>>(buckets, in_pt, in_key, n_in, out_pt,
+                                                                               out_key);
 }
 void launch_msm_tree_level(hipStream_t s, const g1_xyzz_t* in, g1_xyzz_t* out, uint32_t n_in_nodes, int level) {
     uint32_t threads = (n_in_nodes >> 1) * (uint32_t)(level + 2);
@@ -552,10 +579,10 @@ void launch_srs_to_be96(hipStream_t s, const g1_affine_t* in, uint8_t* be96, uin
     k_srs_to_be96<<<nblk(n, 256), 256, 0, s>>>(in, be96, n);
 }
 void launch_srs_precompute(hipStream_t s, g1_affine_t* table, uint64_t stride, uint64_t first, uint64_t count,
-                           int c, int nwin, g1_xyzz_t* tmp) {
-    if (!count || nwin < 2) return;
-    k_precomp_dbl<<<nblk(count, 256), 256, 0, s>>>(table, first, count, c, nwin, tmp);
-    k_precomp_norm<<<nblk(count, 256), 256, 0, s>>>(table, stride, first, count, nwin, tmp);
+                           const WinLayout& lay, g1_xyzz_t* tmp) {
+    if (!count || lay.nwin < 2) return;
+    k_precomp_dbl<<<nblk(count, 256), 256, 0, s>>>(table, first, count, lay, tmp);
+    k_precomp_norm<<<nblk(count, 256), 256, 0, s>>>(table, stride, first, count, lay.nwin, tmp);
 }
 void launch_srs_generate(hipStream_t s, g1_affine_t* out, uint64_t count, uint64_t j_base, const uint32_t* tau_mont,
                          const uint32_t* s0_mont, g1_affine_t* gtab, g1_xyzz_t* tmp, bool build_gtab) {

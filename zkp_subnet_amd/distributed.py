@@ -1,0 +1,49 @@
+"""Multi-GPU MSM: one process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).
+
+The MSM shards by SRS segment: rank g owns points / scalars [g*n/G, (g+1)*n/G), reduces them to ONE
+192-byte partial sum on its GPU, and the only exchange on the data path is an all_gather of those partials
+(G x 192 B: latency-bound, a ring all-reduce is neither needed nor expressible -- RCCL has no EC-add reduce op),
+followed by G-1 point additions + affine + compression on every rank.  Pianist segments (one worker row per GPU)
+need no exchange at all."""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+PARTIAL_BYTES = 192
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block partition [lo, hi) of n items; sizes differ by at most one."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def all_gather_partials(partial: bytes, group=None) -> List[bytes]:
+    """all_gather of one 192-byte partial per rank.  Uses the default process group's backend: device tensors for
+    nccl/RCCL, host tensors for gloo.  Without an initialised process group: world of one."""
+    import torch
+    import torch.distributed as dist
+
+    assert len(partial) == PARTIAL_BYTES
+    if not (dist.is_available() and dist.is_initialized()):
+        return [partial]
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    src = torch.frombuffer(bytearray(partial), dtype=torch.uint8).to(dev)
+    out = torch.empty(world * PARTIAL_BYTES, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, src, group=group)
+    raw = out.cpu().numpy().tobytes()
+    return [raw[i * PARTIAL_BYTES:(i + 1) * PARTIAL_BYTES] for i in range(world)]
+
+
+def sharded_msm(engine, scalars_shard_be32: Optional[bytes] = None, srs_offset: int = 0, slot: Optional[int] = None,
+                n: Optional[int] = None, group=None) -> bytes:
+    """This rank's shard -> partial -> all_gather -> sum.  Every rank returns the same 48-byte compressed point.
+    Either pass the shard's scalars (host bytes) or a device-resident slot + n."""
+    if slot is not None:
+        partial = engine.msm_partial_resident(slot, n, srs_offset)
+    else:
+        partial = engine.msm_partial(scalars_shard_be32, srs_offset)
+    return engine.g1_sum(b"".join(all_gather_partials(partial, group)))

@@ -66,6 +66,15 @@ class HipEngine:
         return self._lib.kzg_get_window(self._h)
 
     @property
+    def window_offsets(self) -> List[int]:
+        """Bit offset of every Pippenger window plus the closing 256 (table w holds 2^offset[w] * P)."""
+        arr = (ctypes.c_int32 * 70)()
+        nwin = self._lib.kzg_get_window_layout(self._h, arr, 70)
+        if nwin < 0:
+            raise KzgError(nwin, "no window layout yet (load an SRS first)")
+        return list(arr[: nwin + 1])
+
+    @property
     def srs_points(self) -> int:
         return self._lib.kzg_srs_points(self._h)
 

@@ -1,0 +1,49 @@
+"""The parts of the reference validator that DEFINE what the miner must compute (reference
+neurons/validator.py:35-42,106-120,135-176): challenge generation (IFFT-then-eval convention), and the reward rule
+(verify against the challenge's alpha/eval, linear latency discount).  Chain plumbing is out of scope."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+from .protocol import Prove
+
+
+@dataclass
+class Challenge:  # reference neurons/validator.py:35-42
+    polys: List[List[str]]
+    alpha: str
+    evals: List[str]
+
+    def to_synapse(self, i: int) -> Prove:
+        return Prove(index=i, poly=self.polys[i], alpha=self.alpha)
+
+
+def _ok(resp, key, what):
+    with resp as response:
+        if response.status_code != 200:
+            raise Exception(f"Failed to {what}.")
+        return response.json().get(key)
+
+
+def generate_challenge(client, machines_count: int) -> Challenge:  # reference neurons/validator.py:106-120
+    poly = _ok(client.random_poly(), "poly", "generate a random polynomial")
+    alpha = _ok(client.random_point(), "point", "generate a random x")
+    evals = []
+    for i in range(machines_count):
+        fft_coeffs = _ok(client.fft(poly[i], left=True, inverse=True), "poly", "fft")
+        evals.append(_ok(client.eval(fft_coeffs, alpha), "y", "evaluate the polynomial"))
+    return Challenge(polys=poly, alpha=alpha, evals=evals)
+
+
+def reward(client, challenge: Challenge, response: Optional[Prove], index: int, process_time: Optional[float],
+           timeout: float = 30.0) -> float:  # reference neurons/validator.py:135-176
+    if response is None or response.commitment is None or response.proof is None:
+        return 0.0
+    if process_time is None or process_time > timeout:
+        return 0.0
+    valid = _ok(client.worker_verify(index, response.proof, challenge.alpha, challenge.evals[index],
+                                     response.commitment), "valid", "verify the proof")
+    if not valid:
+        return 0.0
+    return 1 - process_time / timeout
