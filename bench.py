@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- the driver's measurement contract for the KZG segment-prover hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload msm20|kzg22]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Default workload (BASELINE.json configs[1], the one the metric is quoted on): one step = one 2^20-point BLS12-381 G1
+Pippenger MSM per GPU over a cached (device-resident) SRS segment with device-resident random scalars.  With N > 1
+the MSM is SRS-sharded: rank g owns segment [g*2^20, (g+1)*2^20) of a 2^20*N-point SRS, reduces it to one 192-byte
+partial on its GPU, the partials are all_gathered over RCCL/xGMI and summed on every rank (weak scaling: per-GPU work
+fixed).  `value` = points of all ranks / wall time of the K timed steps (max over ranks).
+
+Extra objects on the JSON line: `roofline` for the dominant kernel (k_msm_accumulate, duration from HIP events on the
+library's own stream, denominators from SURVEY.md 8d: 128 B per point) and `cpu_baseline` (oracle/kzg_cpu.c, a C port
+timed on this box's host cores on a bounded sample of the same inputs; also used here as a parity check).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy peak
+HBM_COPY_GBS = 6290.0
+TAU = 0x2F6C7A1D3B5E9F80412D6A7C93E1B5F7086A4D2C1E9B3F5A7D6C8E0F1A2B3C4D % R_MOD
+
+
+def uniform_fr(n, seed):
+    """n scalars uniform in [0, r): seeded PCG64 stream, 255-bit candidates, rejection of values >= r."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    r_words = np.array([(R_MOD >> (64 * (3 - i))) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+    out = []
+    have = 0
+    while have < n:
+        m = int((n - have) * 1.15) + 64
+        raw = rng.integers(0, 256, size=(m, 32), dtype=np.uint8)
+        raw[:, 0] &= 0x7F
+        w = raw.view(">u8").astype(np.uint64)
+        lt = np.zeros(m, dtype=bool)
+        eq = np.ones(m, dtype=bool)
+        for i in range(4):
+            lt |= eq & (w[:, i] < r_words[i])
+            eq &= w[:, i] == r_words[i]
+        keep = raw[lt]
+        out.append(keep)
+        have += len(keep)
+    return np.concatenate(out)[:n].tobytes()
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="msm20", choices=["msm20", "kzg22"])
+    ap.add_argument("--log-n", type=int, default=0, help="override log2(points per GPU) (debug)")
+    ap.add_argument("--window", type=int, default=0)
+    ap.add_argument("--cpu-sample-log", type=int, default=17)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from zkp_subnet_amd import HipEngine
+    from zkp_subnet_amd.distributed import all_gather_partials
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng = HipEngine(local_rank, window=args.window)
+    t_setup = time.time()
+    if args.workload == "msm20":
+        lg = args.log_n or 20
+        n = 1 << lg
+        # this rank's SRS segment: points [rank*n, (rank+1)*n) of the 2^lg * world point SRS [tau^j] G
+        eng.gen_srs(TAU, 1, lg, 0, factors=[pow(TAU, rank * n, R_MOD)])
+        scal = uniform_fr(n, seed=rank)                       # seed 0 on rank 0
+        eng.upload_fr(0, scal, False)
+        alpha = None
+    else:
+        lg = args.log_n or 22
+        n = 1 << lg
+        # Pianist segments: worker row `rank`, one per GPU, no exchange (BASELINE.json configs[2] / [4])
+        from zkp_subnet_amd.engine import lagrange_factor
+        ms = max(0, (world - 1).bit_length())
+        eng.gen_srs(TAU, 0, lg + ms, ms, factors=[lagrange_factor(rank, ms, (TAU * 7 + 1) % R_MOD)])
+        scal = uniform_fr(n, seed=rank)
+        eng.upload_fr(0, scal, True)
+        alpha = uniform_fr(1, seed=1)
+    setup_s = time.time() - t_setup
+    plan = eng.msm_plan(n)
+
+    results = []
+
+    def step():
+        if args.workload == "msm20":
+            if world == 1:
+                results.append(eng.msm_resident(0, n, 0))
+            else:
+                part = eng.msm_partial_resident(0, n, 0)
+                results.append(eng.g1_sum(b"".join(all_gather_partials(part))))
+        else:
+            results.append(eng.commit_open_resident(0, 0, n, alpha, True))
+
+    for _ in range(args.warmup):
+        step()
+    results.clear()
+    eng.set_profiling(True)
+    stage_sum = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for k, v in eng.timings().items():
+            stage_sum[k] = stage_sum.get(k, 0.0) + v
+    barrier()
+    elapsed = time.perf_counter() - t0
+    eng.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert all(r == results[0] for r in results), "non-deterministic result across steps"
+
+    if rank == 0:
+        stages = {k: v / args.steps for k, v in stage_sum.items()}
+        units = n * world * args.steps
+        acc_ms = stages.get("accumulate", 0.0)
+        if args.workload == "msm20":
+            alg_bytes = 128.0 * n                 # 96 B affine point + 32 B scalar, each read once
+            launches = 1
+            metric, unit, value = "BLS12-381 G1 MSM points/sec at 2^20", "points/s", units / elapsed
+            wl = f"2^{lg}-point BLS12-381 G1 Pippenger MSM per GPU (uniform scalars in [0,r), cached SRS)"
+        else:
+            alg_bytes = 128.0 * n                 # per MSM launch; the path runs two (commit: n, open: n-1)
+            launches = 2
+            metric, unit, value = "KZG commit+open coefficients/sec at 2^22", "coefficients/s", units / elapsed
+            wl = f"degree-2^{lg} KZG commit+open per GPU (INTT + 2 MSM + quotient), evaluation-form input"
+        per_launch_s = acc_ms / 1e3 / launches if acc_ms else float("nan")
+        achieved = alg_bytes / per_launch_s / 1e9 if acc_ms else None
+        out = {
+            "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": wl, "points_per_gpu": n, "window_bits": eng.window, "windows": plan["windows"],
+                       "buckets": plan["buckets"], "entries_per_lane": plan["chunk"], "lanes": plan["lanes"],
+                       "parallelism": "single GPU" if world == 1 else
+                       (f"SRS-sharded x{world}, all_gather of 192 B partials over RCCL" if args.workload == "msm20"
+                        else f"Pianist segments x{world}, no exchange")},
+            "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "kernel_ms": per_launch_s * 1e3 if acc_ms else None, "algorithmic_bytes": alg_bytes,
+                         "frac_of_measured_copy_peak": (achieved / HBM_COPY_GBS) if achieved else None,
+                         "note": "integer-VALU-bound (12-limb Montgomery on v_mad_u64_u32), not HBM-bound; see DESIGN.md"},
+            "stages_ms": {k: round(v, 4) for k, v in stages.items()},
+            "setup_s": round(setup_s, 2),
+        }
+        if args.workload == "kzg22":
+            out["kzg_commit_open_latency_ms"] = elapsed / args.steps * 1e3
+        # ---- CPU baseline: the oracle's C port on a bounded sample of the same inputs, all host cores
+        if world == 1 and not args.no_cpu_baseline and args.workload == "msm20":
+            from oracle import cpu as oc
+
+            oc.build()
+            m = 1 << min(args.cpu_sample_log, lg)
+            cores = host_cores()
+            srs = eng.srs_read(0, m)
+            prep = oc.PreparedMsm(srs, scal[: 32 * m])
+            tc = time.perf_counter()
+            cpu_res = prep.run(cores)
+            cpu_s = time.perf_counter() - tc
+            tc1 = time.perf_counter()
+            prep1 = oc.PreparedMsm(srs[: 96 * (m >> 3)], scal[: 32 * (m >> 3)])
+            prep1.run(1)
+            cpu1_s = time.perf_counter() - tc1
+            gpu_same = eng.msm(scal[: 32 * m], 0)
+            out["cpu_baseline"] = {
+                "value": m / cpu_s, "unit": "points/s", "cores": cores, "kind": "port",
+                "sample": f"first 2^{m.bit_length() - 1} points/scalars of the same workload, one Pippenger MSM, "
+                          f"{cores} threads ({cpu_s:.2f} s wall); 1 thread on 2^{(m >> 3).bit_length() - 1}: "
+                          f"{(m >> 3) / cpu1_s:.0f} points/s",
+                "single_thread_points_per_s": (m >> 3) / cpu1_s,
+                "matches_gpu_bit_exact": cpu_res == gpu_same,
+            }
+            assert cpu_res == gpu_same, "GPU MSM differs from the CPU oracle on the baseline sample"
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

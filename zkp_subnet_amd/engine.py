@@ -88,12 +88,17 @@ class HipEngine:
         self.scale, self.machines_scale = scale, machines_scale
 
     def gen_srs(self, tau_x: int, tau_y: int, scale: int, machines_scale: int,
-                workers: Optional[Sequence[int]] = None) -> None:
+                workers: Optional[Sequence[int]] = None, factors: Optional[Sequence[int]] = None) -> None:
         """Synthetic tau-derived SRS for the listed worker indices (default: all 2^machines_scale), slice k of
-        the resident SRS = worker workers[k].  NOTE: resident slice index == position in `workers`."""
-        if workers is None:
-            workers = range(1 << machines_scale)
-        s0 = b"".join(lagrange_factor(i, machines_scale, tau_y).to_bytes(32, "big") for i in workers)
+        the resident SRS = worker workers[k].  NOTE: resident slice index == position in `workers`.
+        `factors` overrides the per-slice factor s0_k (slice k, point j = [s0_k tau_x^j] G): bench.py uses it to
+        generate one SRS *segment* per rank (s0 = tau^(rank * n_local))."""
+        if factors is not None:
+            s0 = b"".join((f % R_MODULUS).to_bytes(32, "big") for f in factors)
+        else:
+            if workers is None:
+                workers = range(1 << machines_scale)
+            s0 = b"".join(lagrange_factor(i, machines_scale, tau_y).to_bytes(32, "big") for i in workers)
         self._chk(self._lib.kzg_gen_srs(self._h, (tau_x % R_MODULUS).to_bytes(32, "big"), s0, len(s0) // 32, scale,
                                         machines_scale))
         self.scale, self.machines_scale = scale, machines_scale
