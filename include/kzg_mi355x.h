@@ -109,9 +109,9 @@ int kzg_b64_decode_fr(const char* packed43, uint64_t n, uint8_t* out_be32);
 int kzg_b64_encode_fr(const uint8_t* be32, uint64_t n, char* out_packed43);
 
 /* ---- unit-op hooks for the parity tests (tests/test_gpu_field.py); not part of the serving surface */
-int kzg_test_field(kzg_ctx* ctx, int field /*0 Fp,1 Fr*/, int op /*0 mul,1 add,2 sub,3 mul(plain C)*/,
+int kzg_test_field(kzg_ctx* ctx, int field /*0 Fp,1 Fr*/, int op /*0 mul,1 add,2 sub,3 mul(plain C ref),4 sqr*/,
                    const uint8_t* a_be, const uint8_t* b_be, uint8_t* out_be, uint64_t n);
-int kzg_test_g1(kzg_ctx* ctx, int op /*0 a+b mixed,1 2a+b full,2 2a,3 4a*/, const uint8_t* a_be96,
+int kzg_test_g1(kzg_ctx* ctx, int op /*0 a+b mixed,1 2a+b full,2 2a,3 4a,4 a+20a+20b chain*/, const uint8_t* a_be96,
                 const uint8_t* b_be96, uint8_t* out_be96, uint64_t n);
 
 #ifdef __cplusplus

@@ -38,7 +38,7 @@ if want("field"):
         a = b"".join(v.to_bytes(w, "big") for v in vals_a)
         b = b"".join(v.to_bytes(w, "big") for v in vals_b)
         for op, fn in ((0, lambda x, y: x * y % mod), (1, lambda x, y: (x + y) % mod), (2, lambda x, y: (x - y) % mod),
-                       (3, lambda x, y: x * y % mod)):
+                       (3, lambda x, y: x * y % mod), (4, lambda x, y: x * x % mod)):
             out = eng.test_field(field, op, a, b)
             got = [int.from_bytes(out[i * w:(i + 1) * w], "big") for i in range(len(vals_a))]
             exp = [fn(x, y) for x, y in zip(vals_a, vals_b)]

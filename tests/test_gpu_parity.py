@@ -55,7 +55,7 @@ def test_field_ops_bit_exact(hip, field, mod, w):
     a = b"".join(v.to_bytes(w, "big") for v in va)
     b = b"".join(v.to_bytes(w, "big") for v in vb)
     for op, fn in ((0, lambda x, y: x * y % mod), (1, lambda x, y: (x + y) % mod), (2, lambda x, y: (x - y) % mod),
-                   (3, lambda x, y: x * y % mod)):
+                   (3, lambda x, y: x * y % mod), (4, lambda x, y: x * x % mod)):
         out = eng.test_field(field, op, a, b)
         exp = b"".join(fn(x, y).to_bytes(w, "big") for x, y in zip(va, vb))
         assert out == exp, f"field {field} op {op}"
@@ -74,9 +74,15 @@ def test_g1_ops_bit_exact_including_exceptional_cases(hip):
     pa[4] = pb[4] = None
     a = b"".join(o.g1_to_be96(p) for p in pa)
     b = b"".join(o.g1_to_be96(p) for p in pb)
+    def chain(x, y):                      # a, then 40 alternating mixed adds of b, a, b, a ...
+        r = x
+        for k in range(40):
+            r = o.g1_add(r, x if k & 1 else y)
+        return r
+
     exp = {0: lambda x, y: o.g1_add(x, y), 1: lambda x, y: o.g1_add(o.g1_add(x, x), y),
-           2: lambda x, y: o.g1_add(x, x), 3: lambda x, y: o.g1_mul(x, 4) if x else None}
-    for op in range(4):
+           2: lambda x, y: o.g1_add(x, x), 3: lambda x, y: o.g1_mul(x, 4) if x else None, 4: chain}
+    for op in range(5):
         out = eng.test_g1(op, a, b)
         assert out == b"".join(o.g1_to_be96(exp[op](x, y)) for x, y in zip(pa, pb)), f"g1 op {op}"
 

@@ -400,43 +400,70 @@ int precompute_tables(kzg_ctx* ctx) {
 }
 
 // ---- unit-op test kernels
-template <class P>
-__global__ void __launch_bounds__(256) k_test_field(int op, const uint8_t* a_be, const uint8_t* b_be, uint8_t* out_be,
-                                                     uint64_t n) {
+// Fr: saturated 32-bit Montgomery (field.cuh).  Fp: op 0 mul / 1 add / 2 sub / 4 sqr on the 28-bit-limb working
+// representation (fp28.cuh); op 3 = the plain-C++ 12 x 32-bit CIOS reference product.
+__global__ void __launch_bounds__(256) k_test_fr(int op, const uint8_t* a_be, const uint8_t* b_be, uint8_t* out_be,
+                                                  uint64_t n) {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    constexpr int N = P::N;
-    field_t<P> a, b, r;
-    limbs_from_be<N>(a.l, a_be + 4 * N * j);
-    limbs_from_be<N>(b.l, b_be + 4 * N * j);
+    fr_t a, b, r;
+    limbs_from_be<8>(a.l, a_be + 32 * j);
+    limbs_from_be<8>(b.l, b_be + 32 * j);
     f_to_mont(a, a);
     f_to_mont(b, b);
     if (op == 0) f_mul(r, a, b);
     else if (op == 1) f_add(r, a, b);
     else if (op == 2) f_sub(r, a, b);
-    else f_mul_inline(r, a, b);
+    else if (op == 3) f_mul_inline(r, a, b);
+    else f_mul(r, a, a);
     f_from_mont(r, r);
-    limbs_to_be<N>(out_be + 4 * N * j, r.l);
+    limbs_to_be<8>(out_be + 32 * j, r.l);
+}
+__global__ void __launch_bounds__(256) k_test_fp(int op, const uint8_t* a_be, const uint8_t* b_be, uint8_t* out_be,
+                                                  uint64_t n) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    if (op == 3) {
+        fp32_t a, b, r;
+        limbs_from_be<12>(a.l, a_be + 48 * j);
+        limbs_from_be<12>(b.l, b_be + 48 * j);
+        f_to_mont(a, a);
+        f_to_mont(b, b);
+        f_mul_inline(r, a, b);
+        f_from_mont(r, r);
+        limbs_to_be<12>(out_be + 48 * j, r.l);
+        return;
+    }
+    fp_t a, b, r;
+    fp_from_be48(a, a_be + 48 * j);
+    fp_from_be48(b, b_be + 48 * j);
+    if (op == 0) fp_mul(r, a, b);
+    else if (op == 1) fp_add(r, a, b);
+    else if (op == 2) fp_sub4(r, a, b);
+    else fp_sqr(r, a);
+    fp_to_be48(out_be + 48 * j, r);
 }
 __global__ void __launch_bounds__(256) k_test_g1(int op, const uint8_t* a_be, const uint8_t* b_be, uint8_t* out_be,
                                                   uint64_t n) {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    g1_affine_t a, b, o;
-    limbs_from_be<12>(a.x.l, a_be + 96 * j); limbs_from_be<12>(a.y.l, a_be + 96 * j + 48);
-    limbs_from_be<12>(b.x.l, b_be + 96 * j); limbs_from_be<12>(b.y.l, b_be + 96 * j + 48);
-    f_to_mont(a.x, a.x); f_to_mont(a.y, a.y); f_to_mont(b.x, b.x); f_to_mont(b.y, b.y);
+    g1_aff28 a, b, o;
+    fp_from_be48(a.x, a_be + 96 * j); fp_from_be48(a.y, a_be + 96 * j + 48);
+    fp_from_be48(b.x, b_be + 96 * j); fp_from_be48(b.y, b_be + 96 * j + 48);
     g1_xyzz_t pa, pb, r, t;
-    g1_from_affine(pa, a);
-    g1_from_affine(pb, b);
+    g1_from_aff(pa, a);
+    g1_from_aff(pb, b);
     if (op == 0) { r = pa; g1_madd_checked(r, b); }
     else if (op == 1) { g1_dbl(t, pa); g1_add(r, t, pb); }
     else if (op == 2) { g1_dbl(r, pa); }
-    else { g1_dbl(t, pa); g1_dbl(r, t); }
-    g1_to_affine(o, r);
-    fp_t x, y;
-    f_from_mont(x, o.x); f_from_mont(y, o.y);
-    limbs_to_be<12>(out_be + 96 * j, x.l); limbs_to_be<12>(out_be + 96 * j + 48, y.l);
+    else if (op == 3) { g1_dbl(t, pa); g1_dbl(r, t); }
+    else {  // long dependent chain: ((a + b) + b + ... ) exercising the class invariants across many mixed adds
+        r = pa;
+        for (int k = 0; k < 40; k++) g1_madd_checked(r, (k & 1) ? a : b);
+    }
+    g1_to_aff(o, r);
+    fp_to_be48(out_be + 96 * j, o.x);
+    fp_to_be48(out_be + 96 * j + 48, o.y);
 }
 
 const char B64[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
@@ -616,7 +643,8 @@ static int msm_host_common(kzg_ctx* ctx, const uint8_t* scalars_be32, uint64_t n
     rc = msm_core(ctx, ctx->scal.as<uint32_t>(), 0, n, srs_offset, ctx->res.as<g1_xyzz_t>());
     if (rc) return rc;
     if (partial) {
-        HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, ctx->res.p, 192, hipMemcpyDeviceToHost, ctx->stream));
+        launch_xyzz_pack(ctx->stream, ctx->res.as<g1_xyzz_t>(), ctx->small.as<uint32_t>(), 1);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, ctx->small.p, 192, hipMemcpyDeviceToHost, ctx->stream));
     } else {
         launch_g1_compress(ctx->stream, ctx->res.as<g1_xyzz_t>(), ctx->small.as<uint8_t>());
         HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, ctx->small.p, 48, hipMemcpyDeviceToHost, ctx->stream));
@@ -639,13 +667,15 @@ int kzg_g1_sum(kzg_ctx* ctx, const uint8_t* partials_xyzz192, uint32_t count, ui
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, ctx->in_be.ensure((size_t)count * 192 + 192));
+    HIPCHK(ctx, ctx->bufB.ensure(((size_t)count + 1) * sizeof(g1_xyzz_t)));
     HIPCHK(ctx, ctx->res.ensure(4 * sizeof(g1_xyzz_t)));
     HIPCHK(ctx, ctx->small.ensure(1024));
     int rc = clear_flags(ctx);
     if (rc) return rc;
     if (count) HIPCHK(ctx, hipMemcpyAsync(ctx->in_be.p, partials_xyzz192, (size_t)count * 192, hipMemcpyHostToDevice,
                                           ctx->stream));
-    launch_g1_sum(ctx->stream, ctx->in_be.as<g1_xyzz_t>(), count, ctx->res.as<g1_xyzz_t>());
+    launch_xyzz_unpack(ctx->stream, ctx->in_be.as<uint32_t>(), ctx->bufB.as<g1_xyzz_t>(), count);
+    launch_g1_sum(ctx->stream, ctx->bufB.as<g1_xyzz_t>(), count, ctx->res.as<g1_xyzz_t>());
     launch_g1_compress(ctx->stream, ctx->res.as<g1_xyzz_t>(), ctx->small.as<uint8_t>());
     HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, ctx->small.p, 48, hipMemcpyDeviceToHost, ctx->stream));
     rc = finish(ctx);
@@ -784,7 +814,8 @@ static int msm_resident_common(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_
     rc = msm_core(ctx, ctx->slot[slot].as<uint32_t>(), ctx->slot_mont[slot], n, srs_offset, ctx->res.as<g1_xyzz_t>());
     if (rc) return rc;
     if (partial) {
-        HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, ctx->res.p, 192, hipMemcpyDeviceToHost, ctx->stream));
+        launch_xyzz_pack(ctx->stream, ctx->res.as<g1_xyzz_t>(), ctx->small.as<uint32_t>(), 1);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, ctx->small.p, 192, hipMemcpyDeviceToHost, ctx->stream));
     } else {
         Span sp(ctx, KZG_T_FINAL);
         launch_g1_compress(ctx->stream, ctx->res.as<g1_xyzz_t>(), ctx->small.as<uint8_t>());
@@ -905,8 +936,8 @@ int kzg_test_field(kzg_ctx* ctx, int field, int op, const uint8_t* a_be, const u
     HIPCHK(ctx, hipMemcpyAsync(da, a_be, n * w, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(db, b_be, n * w, hipMemcpyHostToDevice, ctx->stream));
     uint32_t blocks = (uint32_t)((n + 255) / 256);
-    if (field == 0) k_test_field<FpParams><<<blocks, 256, 0, ctx->stream>>>(op, da, db, ctx->out_be.as<uint8_t>(), n);
-    else k_test_field<FrParams><<<blocks, 256, 0, ctx->stream>>>(op, da, db, ctx->out_be.as<uint8_t>(), n);
+    if (field == 0) k_test_fp<<<blocks, 256, 0, ctx->stream>>>(op, da, db, ctx->out_be.as<uint8_t>(), n);
+    else k_test_fr<<<blocks, 256, 0, ctx->stream>>>(op, da, db, ctx->out_be.as<uint8_t>(), n);
     HIPCHK(ctx, hipMemcpyAsync(out_be, ctx->out_be.p, n * w, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());

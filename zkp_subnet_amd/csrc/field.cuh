@@ -359,5 +359,5 @@ KZG_DEV void f_pow_const(field_t<P>& r, const field_t<P>& a) {
     r = acc;
 }
 
-typedef field_t<FpParams> fp_t;
+typedef field_t<FpParams> fp32_t;  // saturated 12 x 32-bit Fp: reference implementation for tests + inversion helper
 typedef field_t<FrParams> fr_t;

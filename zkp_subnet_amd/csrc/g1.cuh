@@ -1,188 +1,166 @@
-// BLS12-381 G1 (y^2 = x^3 + 4 over Fp) for the MSM kernels.
-//   affine point  : (x, y) Montgomery form, 96 B, 16-B aligned; (0,0) encodes infinity ((0,0) is off-curve)
-//   bucket / sum  : extended Jacobian "XYZZ" (X, Y, ZZ, ZZZ), x = X/ZZ, y = Y/ZZZ, ZZ == 0 encodes infinity.
-// XYZZ is chosen because the bucket update is a *mixed* add (affine SRS point into a running bucket):
-// 8M + 2S with no field inversion and no Z bookkeeping (EFD madd-2008-s); bucket+bucket is 12M + 2S.
-// The Fp product is a real function call (s_swappc) by default: one 6.6 KB copy instead of ten inlined copies
-// per point addition keeps the hot loop inside the instruction cache.
+// BLS12-381 G1 (y^2 = x^3 + 4 over Fp) for the MSM kernels, on the 28-bit-limb Fp of fp28.cuh.
+//   affine point (HBM)  : x, y canonical Montgomery residues packed as 12 x u32 each, 96 B; all-zero = infinity
+//   bucket / sum (XYZZ) : X, Y, ZZ, ZZZ as 14-limb fp_t, 224 B, x = X/ZZ, y = Y/ZZZ; ZZ all-zero limbs = infinity
+// Stored-coordinate classes (fp28.cuh): X normalised limbs, value < 14p; Y normalised, < 6p; ZZ, ZZZ product outputs
+// (< 2p).  Every formula below ends inside these classes, so they hold inductively; subtrahends use the multiple
+// of p that dominates their class (X: M16, Y: M8, product outputs: M4).
+// XYZZ because the bucket update is a *mixed* add (affine table point into a running bucket): 8M + 2S, no inversion
+// (EFD madd-2008-s); bucket + bucket is add-2008-s (12M + 2S).
 #pragma once
 #include "field.cuh"
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-struct fp_ret {
-    u32x4 v0, v1, v2;
-};
-
-#ifndef KZG_FP_MUL_INLINE
-// operands travel in VGPRs (vector-typed arguments stay in registers under the AMDGPU calling convention,
-// a 48-byte struct by value would go through scratch)
-static __device__ __noinline__ fp_ret fp_mul_raw(u32x4 a0, u32x4 a1, u32x4 a2, u32x4 b0, u32x4 b1, u32x4 b2) {
-    fp_t a, b, r;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        a.l[i] = a0[i]; a.l[4 + i] = a1[i]; a.l[8 + i] = a2[i];
-        b.l[i] = b0[i]; b.l[4 + i] = b1[i]; b.l[8 + i] = b2[i];
-    }
-    f_mul(r, a, b);
-    fp_ret o;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        o.v0[i] = r.l[i]; o.v1[i] = r.l[4 + i]; o.v2[i] = r.l[8 + i];
-    }
-    return o;
-}
-KZG_DEV void fp_mul(fp_t& r, const fp_t& a, const fp_t& b) {
-    u32x4 a0 = {a.l[0], a.l[1], a.l[2], a.l[3]}, a1 = {a.l[4], a.l[5], a.l[6], a.l[7]},
-          a2 = {a.l[8], a.l[9], a.l[10], a.l[11]};
-    u32x4 b0 = {b.l[0], b.l[1], b.l[2], b.l[3]}, b1 = {b.l[4], b.l[5], b.l[6], b.l[7]},
-          b2 = {b.l[8], b.l[9], b.l[10], b.l[11]};
-    fp_ret o = fp_mul_raw(a0, a1, a2, b0, b1, b2);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        r.l[i] = o.v0[i]; r.l[4 + i] = o.v1[i]; r.l[8 + i] = o.v2[i];
-    }
-}
-#else
-KZG_DEV void fp_mul(fp_t& r, const fp_t& a, const fp_t& b) { f_mul(r, a, b); }
-#endif
-KZG_DEV void fp_sqr(fp_t& r, const fp_t& a) { fp_mul(r, a, a); }
-KZG_DEV void fp_add(fp_t& r, const fp_t& a, const fp_t& b) { f_add(r, a, b); }
-KZG_DEV void fp_sub(fp_t& r, const fp_t& a, const fp_t& b) { f_sub(r, a, b); }
-KZG_DEV void fp_dbl(fp_t& r, const fp_t& a) { f_add(r, a, a); }
+#include "fp28.cuh"
 
 struct alignas(16) g1_affine_t {
-    fp_t x, y;
+    uint32_t x[12], y[12];
 };
 struct alignas(16) g1_xyzz_t {
     fp_t x, y, zz, zzz;
 };
+struct g1_aff28 {  // affine point in registers
+    fp_t x, y;
+};
 
-KZG_DEV bool g1_affine_is_inf(const g1_affine_t& p) { return f_is_zero(p.x) && f_is_zero(p.y); }
-KZG_DEV bool g1_is_inf(const g1_xyzz_t& p) { return f_is_zero(p.zz); }
+KZG_DEV bool g1_is_inf(const g1_xyzz_t& p) { return fp_limbs_zero(p.zz); }
 KZG_DEV void g1_set_inf(g1_xyzz_t& p) {
-    f_zero(p.x); f_zero(p.y); f_zero(p.zz); f_zero(p.zzz);
+    fp_zero(p.x); fp_zero(p.y); fp_zero(p.zz); fp_zero(p.zzz);
 }
-KZG_DEV void g1_from_affine(g1_xyzz_t& r, const g1_affine_t& p) {
-    if (g1_affine_is_inf(p)) { g1_set_inf(r); return; }
-    r.x = p.x; r.y = p.y; f_one(r.zz); f_one(r.zzz);
+KZG_DEV bool g1_aff_is_inf(const g1_aff28& p) { return fp_limbs_zero(p.x) && fp_limbs_zero(p.y); }
+KZG_DEV void g1_from_aff(g1_xyzz_t& r, const g1_aff28& p) {
+    if (g1_aff_is_inf(p)) { g1_set_inf(r); return; }
+    r.x = p.x; r.y = p.y; fp_one(r.zz); fp_one(r.zzz);
 }
-KZG_DEV void g1_neg_affine(g1_affine_t& r, const g1_affine_t& p, bool negate) {
+KZG_DEV void g1_neg_aff(g1_aff28& p, bool negate) {
     fp_t ny;
-    f_neg(ny, p.y);
-    r.x = p.x;
-    bi_select<12>(r.y.l, p.y.l, ny.l, negate);
+    fp_neg_canon(ny, p.y);
+    fp_select(p.y, p.y, ny, negate);
 }
 
-// 2*(x, y) for an affine non-infinity point (EFD mdbl-2008-s-1, a = 0)
-KZG_DEV void g1_dbl_affine(g1_xyzz_t& r, const fp_t& x, const fp_t& y) {
-    fp_t U, V, W, S, M, t;
-    fp_dbl(U, y);
+// 2*(x, y), affine non-infinity input (EFD mdbl-2008-s-1, a = 0)
+KZG_DEV void g1_dbl_aff(g1_xyzz_t& r, const fp_t& x, const fp_t& y) {
+    fp_t U, V, W, S, M, t, u;
+    fp_dbl(U, y);                       // < 2p, limbs < 2^29
     fp_sqr(V, U);
     fp_mul(W, U, V);
     fp_mul(S, x, V);
-    fp_sqr(M, x);
-    fp_dbl(t, M); fp_add(M, t, M);
-    fp_sqr(r.x, M); fp_sub(r.x, r.x, S); fp_sub(r.x, r.x, S);
-    fp_sub(t, S, r.x); fp_mul(t, M, t);
-    fp_mul(U, W, y);
-    fp_sub(r.y, t, U);
+    fp_sqr(t, x);
+    fp_add(M, t, t); fp_add(M, M, t);   // 3x^2: limbs < 3*2^28, value < 6p
+    fp_sqr(u, M);
+    fp_sub4(u, u, S); fp_sub4(u, u, S);
+    fp_norm(r.x, u);                    // < 2p + 8p
+    fp_sub16(t, S, r.x);
+    fp_mul(t, M, t);
+    fp_mul(u, W, y);
+    fp_sub4(t, t, u);
+    fp_norm(r.y, t);                    // < 6p
     r.zz = V; r.zzz = W;
 }
 // r = 2*p (EFD dbl-2008-s-1, a = 0)
 KZG_DEV void g1_dbl(g1_xyzz_t& r, const g1_xyzz_t& p) {
     if (g1_is_inf(p)) { g1_set_inf(r); return; }
-    fp_t U, V, W, S, M, t, x3;
-    fp_dbl(U, p.y);
+    fp_t U, V, W, S, M, t, u, x3;
+    fp_dbl(U, p.y);                     // Y < 6p -> < 12p, limbs < 2^29
     fp_sqr(V, U);
     fp_mul(W, U, V);
     fp_mul(S, p.x, V);
-    fp_sqr(M, p.x);
-    fp_dbl(t, M); fp_add(M, t, M);
-    fp_sqr(x3, M); fp_sub(x3, x3, S); fp_sub(x3, x3, S);
-    fp_sub(t, S, x3); fp_mul(t, M, t);
-    fp_mul(U, W, p.y);
-    fp_sub(r.y, t, U);
+    fp_sqr(t, p.x);
+    fp_add(M, t, t); fp_add(M, M, t);
+    fp_sqr(u, M);
+    fp_sub4(u, u, S); fp_sub4(u, u, S);
+    fp_norm(x3, u);
+    fp_sub16(t, S, x3);
+    fp_mul(t, M, t);
+    fp_mul(u, W, p.y);
+    fp_sub4(t, t, u);
+    fp_norm(r.y, t);
     r.x = x3;
     fp_mul(r.zz, V, p.zz);
     fp_mul(r.zzz, W, p.zzz);
 }
-// acc += (qx, qy), affine non-infinity q (EFD madd-2008-s: 8M + 2S).  Branch-free on the common path; the
-// only branches are the rare acc == q doubling and the "acc was empty" select.
+// acc += (qx, qy): affine, canonical, non-infinity (EFD madd-2008-s: 8M + 2S).  The common path is branch-free:
+// an empty accumulator is handled by a select at the end; the only branch is the rare acc == +-q case.
 KZG_DEV void g1_madd(g1_xyzz_t& acc, const fp_t& qx, const fp_t& qy) {
     const bool acc_inf = g1_is_inf(acc);
-    fp_t U2, S2, P, R, PP, PPP, Q, t, x3, y3;
+    fp_t U2, S2, P, R, PP, PPP, Q, RR, t, u, x3, y3, zz3, zzz3;
     fp_mul(U2, qx, acc.zz);
     fp_mul(S2, qy, acc.zzz);
-    fp_sub(P, U2, acc.x);
-    fp_sub(R, S2, acc.y);
-    if (!acc_inf && f_is_zero(P) && f_is_zero(R)) {  // same point: the chord formula degenerates
-        g1_dbl_affine(acc, qx, qy);
+    fp_sub16(P, U2, acc.x);             // < 18p, limbs < 2^28 + 2^29
+    fp_sub8(R, S2, acc.y);              // < 10p
+    fp_sqr(PP, P);
+    fp_sqr(RR, R);
+    if (!acc_inf && fp_is_zero_n(PP)) {  // x coordinates agree: q == acc (double) or q == -acc (cancel)
+        if (fp_is_zero_n(RR)) g1_dbl_aff(acc, qx, qy);
+        else g1_set_inf(acc);
         return;
     }
-    fp_sqr(PP, P);
     fp_mul(PPP, P, PP);
     fp_mul(Q, acc.x, PP);
-    fp_sqr(x3, R); fp_sub(x3, x3, PPP); fp_sub(x3, x3, Q); fp_sub(x3, x3, Q);
-    fp_sub(t, Q, x3); fp_mul(t, R, t);
-    fp_mul(y3, acc.y, PPP);
-    fp_sub(y3, t, y3);
-    fp_mul(t, acc.zz, PP);      // P == 0, R != 0 (q == -acc) gives ZZ3 = 0: infinity, as it must
-    fp_mul(U2, acc.zzz, PPP);
+    fp_sub4(t, RR, PPP); fp_sub4(t, t, Q); fp_sub4(t, t, Q);
+    fp_norm(x3, t);                     // < 2p + 12p = 14p
+    fp_sub16(t, Q, x3);                 // < 18p
+    fp_mul(t, R, t);
+    fp_mul(u, acc.y, PPP);
+    fp_sub4(t, t, u);
+    fp_norm(y3, t);                     // < 6p
+    fp_mul(zz3, acc.zz, PP);
+    fp_mul(zzz3, acc.zzz, PPP);
     fp_t one;
-    f_one(one);
-    bi_select<12>(acc.x.l, x3.l, qx.l, acc_inf);
-    bi_select<12>(acc.y.l, y3.l, qy.l, acc_inf);
-    bi_select<12>(acc.zz.l, t.l, one.l, acc_inf);
-    bi_select<12>(acc.zzz.l, U2.l, one.l, acc_inf);
+    fp_one(one);
+    fp_select(acc.x, x3, qx, acc_inf);
+    fp_select(acc.y, y3, qy, acc_inf);
+    fp_select(acc.zz, zz3, one, acc_inf);
+    fp_select(acc.zzz, zzz3, one, acc_inf);
 }
-// acc += q, affine q that may be infinity
-KZG_DEV void g1_madd_checked(g1_xyzz_t& acc, const g1_affine_t& q) {
-    if (g1_affine_is_inf(q)) return;
+KZG_DEV void g1_madd_checked(g1_xyzz_t& acc, const g1_aff28& q) {
+    if (g1_aff_is_inf(q)) return;
     g1_madd(acc, q.x, q.y);
 }
 // r = p + q (EFD add-2008-s: 12M + 2S) with the exceptional cases
 KZG_DEV void g1_add(g1_xyzz_t& r, const g1_xyzz_t& p, const g1_xyzz_t& q) {
     if (g1_is_inf(p)) { r = q; return; }
     if (g1_is_inf(q)) { r = p; return; }
-    fp_t U1, U2, S1, S2, P, R, PP, PPP, Q, t, x3;
+    fp_t U1, U2, S1, S2, P, R, PP, PPP, Q, RR, t, u, x3;
     fp_mul(U1, p.x, q.zz);
     fp_mul(U2, q.x, p.zz);
     fp_mul(S1, p.y, q.zzz);
     fp_mul(S2, q.y, p.zzz);
-    fp_sub(P, U2, U1);
-    fp_sub(R, S2, S1);
-    if (f_is_zero(P)) {
-        if (f_is_zero(R)) { g1_dbl(r, p); return; }
+    fp_sub4(P, U2, U1);
+    fp_sub4(R, S2, S1);
+    fp_sqr(PP, P);
+    fp_sqr(RR, R);
+    if (fp_is_zero_n(PP)) {
+        if (fp_is_zero_n(RR)) { g1_dbl(r, p); return; }
         g1_set_inf(r);
         return;
     }
-    fp_sqr(PP, P);
     fp_mul(PPP, P, PP);
     fp_mul(Q, U1, PP);
-    fp_sqr(x3, R); fp_sub(x3, x3, PPP); fp_sub(x3, x3, Q); fp_sub(x3, x3, Q);
-    fp_sub(t, Q, x3); fp_mul(t, R, t);
-    fp_mul(S1, S1, PPP);
-    fp_sub(r.y, t, S1);
+    fp_sub4(t, RR, PPP); fp_sub4(t, t, Q); fp_sub4(t, t, Q);
+    fp_norm(x3, t);
+    fp_sub16(t, Q, x3);
+    fp_mul(t, R, t);
+    fp_mul(u, S1, PPP);
+    fp_sub4(t, t, u);
+    fp_norm(r.y, t);
     r.x = x3;
     fp_mul(t, p.zz, q.zz); fp_mul(r.zz, t, PP);
     fp_mul(t, p.zzz, q.zzz); fp_mul(r.zzz, t, PPP);
 }
 
-// ---- Fp inversion.  One lane's Fermat ladder (381 squarings) costs > 1 ms of pure latency on a GPU, so the
-// single inversion that ends every MSM uses the binary extended Euclid instead: only shifts, adds and compares on
-// 12 limbs, ~760 halvings + ~380 subtractions.  Invariants x1*A = u*k, x2*A = v*k (mod p) with k = R^2, so for a
-// Montgomery-form input A = aR the result x1 = R^2/A = a^-1 R is the Montgomery form of the inverse directly.
+// ---- inversion.  One lane's Fermat ladder (381 squarings) is > 1 ms of pure latency, so the single inversion that
+// ends every MSM uses the binary extended Euclid on saturated 32-bit limbs: shifts, adds, compares only.
+// Invariants x1*A = u*k, x2*A = v*k (mod p) with k = R^2 (R = 2^392), so for A = aR the result R^2/A = a^-1 R
+// is again a Montgomery residue.
 template <int N>
 KZG_DEV void bi_shr1(uint32_t* a) {
 #pragma unroll
     for (int i = 0; i < N - 1; i++) a[i] = __builtin_amdgcn_alignbit(a[i + 1], a[i], 1);
     a[N - 1] >>= 1;
 }
-KZG_DEV void fp_half(uint32_t* x) {  // x/2 mod p for x in [0, p)
+KZG_DEV void fp32_half(uint32_t* x) {  // x/2 mod p for x in [0, p), 12 x 32-bit limbs
     const uint32_t mask = 0u - (x[0] & 1u);
     uint32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 12; i++) x[i] = __builtin_addc(x[i], FpParams::mod(i) & mask, c, &c);  // < 2^382: no carry out
+    for (int i = 0; i < 12; i++) x[i] = __builtin_addc(x[i], FpParams::mod(i) & mask, c, &c);
     bi_shr1<12>(x);
 }
 KZG_DEV bool bi_is_one12(const uint32_t* a) {
@@ -191,59 +169,111 @@ KZG_DEV bool bi_is_one12(const uint32_t* a) {
     for (int i = 1; i < 12; i++) t |= a[i];
     return t == 0;
 }
+// a: any loose Montgomery residue != 0 mod p; r: canonical Montgomery residue of the inverse
 KZG_DEV void fp_inv(fp_t& r, const fp_t& a) {
-    if (f_is_zero(a)) { f_zero(r); return; }
+    fp_t ac, k;
+    fp_canon_mont(ac, a);
+    if (fp_limbs_zero(ac)) { fp_zero(r); return; }
+#pragma unroll
+    for (int i = 0; i < 14; i++) k.l[i] = fp28_r2(i);
     uint32_t u[12], v[12];
-    fp_t x1, x2;
+    fp32_t x1, x2;
+    fp_pack(u, ac);
+    fp_pack(x1.l, k);
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-        u[i] = a.l[i];
         v[i] = FpParams::mod(i);
-        x1.l[i] = FpParams::r2(i);
         x2.l[i] = 0;
     }
     for (int guard = 0; guard < 2000 && !bi_is_one12(u) && !bi_is_one12(v); guard++) {  // bounded: never hangs
-        while (!(u[0] & 1u)) { bi_shr1<12>(u); fp_half(x1.l); }
-        while (!(v[0] & 1u)) { bi_shr1<12>(v); fp_half(x2.l); }
+        while (!(u[0] & 1u)) { bi_shr1<12>(u); fp32_half(x1.l); }
+        while (!(v[0] & 1u)) { bi_shr1<12>(v); fp32_half(x2.l); }
         if (bi_ge<12>(u, v)) {
             bi_sub<12>(u, u, v);
             f_sub(x1, x1, x2);
-            if (bi_is_zero<12>(u)) break;  // u == v == 1 before the subtraction
+            if (bi_is_zero<12>(u)) break;
         } else {
             bi_sub<12>(v, v, u);
             f_sub(x2, x2, x1);
         }
     }
-    const bool take_x1 = bi_is_one12(u);
-    bi_select<12>(r.l, x2.l, x1.l, take_x1);
+    uint32_t w[12];
+    bi_select<12>(w, x2.l, x1.l, bi_is_one12(u));
+    fp_unpack(r, w);
 }
-// Fermat ladder a^(p-2): used where thousands of lanes invert at once (throughput-bound batch normalisation)
-struct FpInvExp {
-    static constexpr int BITS = 381;
-    __device__ static constexpr uint32_t limb(int i) { return i == 0 ? FpParams::mod(0) - 2u : FpParams::mod(i); }
-};
+// Fermat ladder a^(p-2): for the batch normalisations where thousands of lanes invert at once (no divergence)
 KZG_DEV void fp_inv_fermat(fp_t& r, const fp_t& a) {
     fp_t acc;
-    f_one(acc);
-    for (int i = FpInvExp::BITS - 1; i >= 0; i--) {
+    fp_one(acc);
+    for (int i = 380; i >= 0; i--) {
         fp_sqr(acc, acc);
         uint32_t w = 0;
 #pragma unroll
-        for (int k = 0; k < 12; k++) w = (k == (i >> 5)) ? FpInvExp::limb(k) : w;
+        for (int k = 0; k < 12; k++) w = (k == (i >> 5)) ? (k == 0 ? FpParams::mod(0) - 2u : FpParams::mod(k)) : w;
         if ((w >> (i & 31)) & 1u) fp_mul(acc, acc, a);
     }
     r = acc;
 }
-// affine (Montgomery) from XYZZ; infinity -> (0,0)
-KZG_DEV void g1_to_affine(g1_affine_t& r, const g1_xyzz_t& p) {
-    if (g1_is_inf(p)) { f_zero(r.x); f_zero(r.y); return; }
+// affine (canonical Montgomery, in registers) from XYZZ; infinity -> zeros
+KZG_DEV void g1_to_aff(g1_aff28& r, const g1_xyzz_t& p) {
+    if (g1_is_inf(p)) { fp_zero(r.x); fp_zero(r.y); return; }
     fp_t i, t;
     fp_mul(t, p.zz, p.zzz);
     fp_inv(i, t);
     fp_mul(t, i, p.zzz);  // 1/ZZ
-    fp_mul(r.x, p.x, t);
+    fp_mul(t, p.x, t);
+    fp_canon(r.x, t);
     fp_mul(t, i, p.zz);   // 1/ZZZ
-    fp_mul(r.y, p.y, t);
+    fp_mul(t, p.y, t);
+    fp_canon(r.y, t);
+}
+
+// ---- HBM formats
+KZG_DEV void g1_load_aff(g1_aff28& p, const g1_affine_t* src) {
+    const uint4* q = reinterpret_cast<const uint4*>(src);
+    uint32_t w[24];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        uint4 v = q[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+    fp_unpack(p.x, w);
+    fp_unpack(p.y, w + 12);
+}
+KZG_DEV void g1_store_aff(g1_affine_t* dst, const g1_aff28& p) {  // p canonical
+    uint32_t w[24];
+    fp_pack(w, p.x);
+    fp_pack(w + 12, p.y);
+    uint4* q = reinterpret_cast<uint4*>(dst);
+#pragma unroll
+    for (int i = 0; i < 6; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+KZG_DEV void store_xyzz(g1_xyzz_t* dst, const g1_xyzz_t& p) {
+    uint4* q = reinterpret_cast<uint4*>(dst);
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(&p);
+    uint32_t t[56];
+    const fp_t* f[4] = {&p.x, &p.y, &p.zz, &p.zzz};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int i = 0; i < 14; i++) t[14 * k + i] = f[k]->l[i];
+    (void)w;
+#pragma unroll
+    for (int i = 0; i < 14; i++) q[i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
+}
+KZG_DEV void load_xyzz(g1_xyzz_t& p, const g1_xyzz_t* src) {
+    const uint4* q = reinterpret_cast<const uint4*>(src);
+    uint32_t t[56];
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        uint4 v = q[i];
+        t[4 * i] = v.x; t[4 * i + 1] = v.y; t[4 * i + 2] = v.z; t[4 * i + 3] = v.w;
+    }
+    fp_t* f[4] = {&p.x, &p.y, &p.zz, &p.zzz};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int i = 0; i < 14; i++) f[k]->l[i] = t[14 * k + i];
 }
 
 // ---- byte codecs (big-endian wire <-> little-endian limbs)
@@ -260,26 +290,44 @@ KZG_DEV void limbs_to_be(uint8_t* be, const uint32_t* l) {
 #pragma unroll
     for (int i = 0; i < N; i++) w[N - 1 - i] = bswap32(l[i]);
 }
-// ZCash 48-byte compressed encoding of an affine Montgomery-form point
-KZG_DEV void g1_compress(uint8_t* out48, const g1_affine_t& p) {
-    if (g1_affine_is_inf(p)) {
+// 48 big-endian bytes of a canonical integer < p  <->  Montgomery residue
+KZG_DEV bool fp_from_be48(fp_t& r, const uint8_t* be) {  // returns false when the integer is >= p
+    uint32_t w[12], pm[12];
+    limbs_from_be<12>(w, be);
+#pragma unroll
+    for (int i = 0; i < 12; i++) pm[i] = FpParams::mod(i);
+    const bool ok = !bi_ge<12>(w, pm);
+    fp_t a;
+    fp_unpack(a, w);
+    fp_to_mont(r, a);
+    fp_canon(r, r);
+    return ok;
+}
+KZG_DEV void fp_to_be48(uint8_t* be, const fp_t& a_mont) {
+    fp_t c;
+    fp_from_mont(c, a_mont);
+    uint32_t w[12];
+    fp_pack(w, c);
+    limbs_to_be<12>(be, w);
+}
+// ZCash 48-byte compressed encoding of an affine canonical-Montgomery point
+KZG_DEV void g1_compress(uint8_t* out48, const g1_aff28& p) {
+    if (g1_aff_is_inf(p)) {
         uint32_t* w = reinterpret_cast<uint32_t*>(out48);
 #pragma unroll
         for (int i = 0; i < 12; i++) w[i] = 0;
         out48[0] = 0xC0;
         return;
     }
-    fp_t x, y, two_y;
-    f_from_mont(x, p.x);
-    f_from_mont(y, p.y);
-    // y > (p-1)/2  <=>  2y > p - 1  <=>  2y >= p (p odd, 2y != p)
-    uint32_t t[13];
-    uint32_t c = bi_add<12>(t, y.l, y.l);
-    uint32_t pm[12];
+    fp_t yc;
+    fp_from_mont(yc, p.y);
+    uint32_t y[12], t[12], pm[12];
+    fp_pack(y, yc);
+    // y > (p-1)/2  <=>  2y >= p (p odd)
+    uint32_t c = bi_add<12>(t, y, y);
 #pragma unroll
     for (int i = 0; i < 12; i++) pm[i] = FpParams::mod(i);
-    bool larger = c || bi_ge<12>(t, pm);
-    (void)two_y;
-    limbs_to_be<12>(out48, x.l);
+    const bool larger = c || bi_ge<12>(t, pm);
+    fp_to_be48(out48, p.x);
     out48[0] |= larger ? 0xA0 : 0x80;
 }

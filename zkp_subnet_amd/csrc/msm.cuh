@@ -54,6 +54,9 @@ void launch_msm_final(hipStream_t s, const g1_xyzz_t* node, int nbits, g1_xyzz_t
 void launch_g1_sum(hipStream_t s, const g1_xyzz_t* in, uint32_t count, g1_xyzz_t* out_xyzz);
 // affine + ZCash compression of one point
 void launch_g1_compress(hipStream_t s, const g1_xyzz_t* in, uint8_t* out48);
+// working XYZZ (224 B) <-> ABI partial-sum format (4 x 48 B packed canonical Montgomery residues, zeros = infinity)
+void launch_xyzz_pack(hipStream_t s, const g1_xyzz_t* in, uint32_t* out48w, uint32_t count);
+void launch_xyzz_unpack(hipStream_t s, const uint32_t* in48w, g1_xyzz_t* out, uint32_t count);
 
 // SRS plumbing
 void launch_srs_from_be96(hipStream_t s, const uint8_t* be96, g1_affine_t* out, uint64_t n, uint32_t* bad_flag);

@@ -98,39 +98,6 @@ __global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ accumulate
-KZG_DEV void load_affine(g1_affine_t& p, const g1_affine_t* src) {
-    const uint4* q = reinterpret_cast<const uint4*>(src);
-    uint4 v[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) v[i] = q[i];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        p.x.l[4 * i] = v[i].x; p.x.l[4 * i + 1] = v[i].y; p.x.l[4 * i + 2] = v[i].z; p.x.l[4 * i + 3] = v[i].w;
-        p.y.l[4 * i] = v[3 + i].x; p.y.l[4 * i + 1] = v[3 + i].y; p.y.l[4 * i + 2] = v[3 + i].z;
-        p.y.l[4 * i + 3] = v[3 + i].w;
-    }
-}
-KZG_DEV void store_xyzz(g1_xyzz_t* dst, const g1_xyzz_t& p) {
-    uint4* q = reinterpret_cast<uint4*>(dst);
-    const fp_t* f[4] = {&p.x, &p.y, &p.zz, &p.zzz};
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-            q[3 * k + i] = make_uint4(f[k]->l[4 * i], f[k]->l[4 * i + 1], f[k]->l[4 * i + 2], f[k]->l[4 * i + 3]);
-}
-KZG_DEV void load_xyzz(g1_xyzz_t& p, const g1_xyzz_t* src) {
-    const uint4* q = reinterpret_cast<const uint4*>(src);
-    fp_t* f[4] = {&p.x, &p.y, &p.zz, &p.zzz};
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            uint4 v = q[3 * k + i];
-            f[k]->l[4 * i] = v.x; f[k]->l[4 * i + 1] = v.y; f[k]->l[4 * i + 2] = v.z; f[k]->l[4 * i + 3] = v.w;
-        }
-}
-
 // Each lane owns sorted entries [t*K, (t+1)*K).  A bucket run that began in an earlier chunk is summed into
 // carries[t] (at most one per chunk: only the FIRST run of a chunk can have begun earlier); every run that
 // begins inside the chunk is stored straight to its bucket -- the lane that sees a run begin is its only writer.
@@ -176,9 +143,9 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t* __res
             boundary = offsets[cur + 1];
         }
         const uint32_t v = sorted[e];
-        g1_affine_t p;
-        load_affine(p, table + (v & 0x7fffffffu));
-        g1_neg_affine(p, p, v >> 31);
+        g1_aff28 p;
+        g1_load_aff(p, table + (v & 0x7fffffffu));
+        g1_neg_aff(p, v >> 31);
         g1_madd_checked(acc, p);
     }
     if (pending_carry) {
@@ -311,9 +278,36 @@ __global__ void __launch_bounds__(64) k_g1_compress(const g1_xyzz_t* __restrict_
     if (threadIdx.x != 0) return;
     g1_xyzz_t p;
     load_xyzz(p, in);
-    g1_affine_t a;
-    g1_to_affine(a, p);
+    g1_aff28 a;
+    g1_to_aff(a, p);
     g1_compress(out48, a);
+}
+// XYZZ working form <-> the 192-byte partial-sum format of the C-ABI (4 x 12 u32: canonical Montgomery residues)
+__global__ void __launch_bounds__(64) k_xyzz_pack(const g1_xyzz_t* __restrict__ in, uint32_t* __restrict__ out48w,
+                                                   uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    g1_xyzz_t p;
+    load_xyzz(p, &in[i]);
+    const bool inf = g1_is_inf(p);
+    fp_t c;
+    const fp_t* f[4] = {&p.x, &p.y, &p.zz, &p.zzz};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        fp_canon_mont(c, *f[k]);
+        if (inf) fp_zero(c);
+        fp_pack(out48w + 48 * i + 12 * k, c);
+    }
+}
+__global__ void __launch_bounds__(64) k_xyzz_unpack(const uint32_t* __restrict__ in48w, g1_xyzz_t* __restrict__ out,
+                                                     uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    g1_xyzz_t p;
+    fp_t* f[4] = {&p.x, &p.y, &p.zz, &p.zzz};
+#pragma unroll
+    for (int k = 0; k < 4; k++) fp_unpack(*f[k], in48w + 48 * i + 12 * k);
+    store_xyzz(&out[i], p);
 }
 
 // ------------------------------------------------------------------------------------------------ SRS plumbing
@@ -321,38 +315,40 @@ __global__ void __launch_bounds__(256) k_srs_from_be96(const uint8_t* __restrict
                                                         uint64_t n, uint32_t* __restrict__ bad) {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    g1_affine_t p;
-    limbs_from_be<12>(p.x.l, be + 96 * j);
-    limbs_from_be<12>(p.y.l, be + 96 * j + 48);
-    if (g1_affine_is_inf(p)) {
-        out[j] = p;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(be + 96 * j);
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < 24; i++) any |= w[i];
+    g1_aff28 p;
+    if (!any) {
+        fp_zero(p.x); fp_zero(p.y);
+        g1_store_aff(&out[j], p);
         return;
     }
-    uint32_t pm[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) pm[i] = FpParams::mod(i);
-    if (bi_ge<12>(p.x.l, pm) || bi_ge<12>(p.y.l, pm)) atomicOr(bad, 1u);
-    f_to_mont(p.x, p.x);
-    f_to_mont(p.y, p.y);
+    bool ok = fp_from_be48(p.x, be + 96 * j);
+    ok &= fp_from_be48(p.y, be + 96 * j + 48);
+    if (!ok) atomicOr(bad, 1u);
     // on-curve: y^2 == x^3 + 4
     fp_t y2, x3, four, t;
     fp_sqr(y2, p.y);
     fp_sqr(x3, p.x); fp_mul(x3, x3, p.x);
-    f_one(four); fp_dbl(four, four); fp_dbl(four, four);
+    fp_one(four); fp_dbl(four, four); fp_dbl(four, four);
     fp_add(t, x3, four);
-    if (!f_eq(y2, t)) atomicOr(bad, 2u);
-    out[j] = p;
+    fp_sub4(t, t, y2);                 // == 0 mod p on the curve
+    fp_t one, chk;
+    fp_one(one);
+    fp_mul(chk, t, one);
+    if (!fp_is_zero_n(chk)) atomicOr(bad, 2u);
+    g1_store_aff(&out[j], p);
 }
 __global__ void __launch_bounds__(256) k_srs_to_be96(const g1_affine_t* __restrict__ in, uint8_t* __restrict__ be,
                                                       uint64_t n) {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    g1_affine_t p = in[j];
-    fp_t x, y;
-    f_from_mont(x, p.x);
-    f_from_mont(y, p.y);
-    limbs_to_be<12>(be + 96 * j, x.l);
-    limbs_to_be<12>(be + 96 * j + 48, y.l);
+    g1_aff28 p;
+    g1_load_aff(p, in + j);
+    fp_to_be48(be + 96 * j, p.x);
+    fp_to_be48(be + 96 * j + 48, p.y);
 }
 
 // window tables: tmp[(w-1)*count + j] = 2^off[w] P_{first+j} in XYZZ
@@ -361,10 +357,10 @@ __global__ void __launch_bounds__(256) k_precomp_dbl(const g1_affine_t* __restri
                                                       g1_xyzz_t* __restrict__ tmp) {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
-    g1_affine_t p;
-    load_affine(p, table + first + j);
+    g1_aff28 p;
+    g1_load_aff(p, table + first + j);
     g1_xyzz_t cur, r;
-    g1_from_affine(cur, p);
+    g1_from_aff(cur, p);
     for (int w = 1; w < lay.nwin; w++) {
         for (int k = lay.off[w - 1]; k < lay.off[w]; k++) {
             g1_dbl(r, cur);
@@ -373,77 +369,96 @@ __global__ void __launch_bounds__(256) k_precomp_dbl(const g1_affine_t* __restri
         store_xyzz(&tmp[(uint64_t)(w - 1) * count + j], cur);
     }
 }
-// per-lane Montgomery batch inversion over the lane's nwin-1 window points; prefix products are parked in
-// the destination slots' x field
+// d = ZZ*ZZZ products chained per lane (Montgomery batch inversion); prefix products are parked in the
+// destination slots (as packed canonical residues)
+KZG_DEV void park_fp(g1_affine_t* slot, const fp_t& v_loose) {
+    fp_t c;
+    fp_canon_mont(c, v_loose);
+    fp_pack(slot->x, c);
+}
+KZG_DEV void unpark_fp(fp_t& v, const g1_affine_t* slot) { fp_unpack(v, slot->x); }
+KZG_DEV void xyzz_to_aff_with_inv(g1_aff28& o, const g1_xyzz_t& p, const fp_t& iw /* 1/(zz*zzz) */) {
+    fp_t t;
+    fp_mul(t, iw, p.zzz);   // 1/zz
+    fp_mul(t, p.x, t);
+    fp_canon(o.x, t);
+    fp_mul(t, iw, p.zz);    // 1/zzz
+    fp_mul(t, p.y, t);
+    fp_canon(o.y, t);
+}
 __global__ void __launch_bounds__(256) k_precomp_norm(g1_affine_t* __restrict__ table, uint64_t stride,
                                                        uint64_t first, uint64_t count, int nwin,
                                                        const g1_xyzz_t* __restrict__ tmp) {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
-    fp_t acc, d, one;
-    f_one(one);
-    acc = one;
+    fp_t acc, d;
+    fp_one(acc);
     for (int w = 1; w < nwin; w++) {
         g1_xyzz_t p;
         load_xyzz(p, &tmp[(uint64_t)(w - 1) * count + j]);
-        table[(uint64_t)w * stride + first + j].x = acc;
+        park_fp(&table[(uint64_t)w * stride + first + j], acc);
         if (!g1_is_inf(p)) {
             fp_mul(d, p.zz, p.zzz);
             fp_mul(acc, acc, d);
         }
     }
     fp_t inv;
-    fp_inv(inv, acc);
+    fp_inv_fermat(inv, acc);
     for (int w = nwin - 1; w >= 1; w--) {
         g1_xyzz_t p;
         load_xyzz(p, &tmp[(uint64_t)(w - 1) * count + j]);
         g1_affine_t* dst = &table[(uint64_t)w * stride + first + j];
-        g1_affine_t o;
+        g1_aff28 o;
         if (g1_is_inf(p)) {
-            f_zero(o.x); f_zero(o.y);
+            fp_zero(o.x); fp_zero(o.y);
         } else {
-            fp_t pre = dst->x, iw, t;
+            fp_t pre, iw;
+            unpark_fp(pre, dst);
             fp_mul(d, p.zz, p.zzz);
             fp_mul(iw, inv, pre);   // 1 / (zz*zzz)
             fp_mul(inv, inv, d);
-            fp_mul(t, iw, p.zzz);   // 1 / zz
-            fp_mul(o.x, p.x, t);
-            fp_mul(t, iw, p.zz);    // 1 / zzz
-            fp_mul(o.y, p.y, t);
+            xyzz_to_aff_with_inv(o, p, iw);
         }
-        *dst = o;
+        g1_store_aff(dst, o);
     }
 }
 
 // ---- synthetic SRS (tests / benches): out[j] = [s0 tau^j] G via an 8-bit fixed-base table of G
-KZG_DEV void g1_generator(g1_affine_t& g) {
+KZG_DEV void g1_generator(g1_aff28& g) {
     constexpr uint32_t gx[12] = {0xdb22c6bbu, 0xfb3af00au, 0xf97a1aefu, 0x6c55e83fu, 0x171bac58u, 0xa14e3a3fu,
                                  0x9774b905u, 0xc3688c4fu, 0x4fa9ac0fu, 0x2695638cu, 0x3197d794u, 0x17f1d3a7u};
     constexpr uint32_t gy[12] = {0x46c5e7e1u, 0x0caa2329u, 0xa2888ae4u, 0xd03cc744u, 0x2c04b3edu, 0x00db18cbu,
                                  0xd5d00af6u, 0xfcf5e095u, 0x741d8ae4u, 0xa09e30edu, 0xe3aaa0f1u, 0x08b3f481u};
+    uint32_t wx[12], wy[12];
 #pragma unroll
-    for (int i = 0; i < 12; i++) { g.x.l[i] = gx[i]; g.y.l[i] = gy[i]; }
-    f_to_mont(g.x, g.x);
-    f_to_mont(g.y, g.y);
+    for (int i = 0; i < 12; i++) { wx[i] = gx[i]; wy[i] = gy[i]; }
+    fp_t x, y;
+    fp_unpack(x, wx);
+    fp_unpack(y, wy);
+    fp_to_mont(g.x, x); fp_canon(g.x, g.x);
+    fp_to_mont(g.y, y); fp_canon(g.y, g.y);
 }
 // gtab[w*255 + d] = (d+1) * 2^(8w) * G, affine
 __global__ void __launch_bounds__(256) k_gen_gtab(g1_affine_t* __restrict__ gtab) {
     uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= 32 * 255) return;
     uint32_t w = gid / 255, d = gid % 255 + 1;
-    g1_affine_t g;
+    g1_aff28 g;
     g1_generator(g);
     g1_xyzz_t base, r, acc;
-    g1_from_affine(base, g);
+    g1_from_aff(base, g);
     for (uint32_t k = 0; k < 8 * w; k++) { g1_dbl(r, base); base = r; }
     g1_set_inf(acc);
     for (int b = 7; b >= 0; b--) {
         g1_dbl(r, acc); acc = r;
         if ((d >> b) & 1u) { g1_add(r, acc, base); acc = r; }
     }
-    g1_affine_t o;
-    g1_to_affine(o, acc);
-    gtab[gid] = o;
+    g1_aff28 o;
+    fp_t t, iw;
+    fp_mul(t, acc.zz, acc.zzz);
+    fp_inv_fermat(iw, t);
+    xyzz_to_aff_with_inv(o, acc, iw);
+    g1_store_aff(&gtab[gid], o);
 }
 // scal[j] = s0 * tau^j (canonical limbs); 64 consecutive j per lane
 __global__ void __launch_bounds__(256) k_srs_scalars(uint32_t* __restrict__ scal, uint64_t count, uint64_t j_base,
@@ -481,8 +496,8 @@ __global__ void __launch_bounds__(256) k_srs_fixed_mul(const uint32_t* __restric
     for (int w = 0; w < 32; w++) {
         uint32_t d = (limb_at(s, w >> 2) >> (8 * (w & 3))) & 0xffu;
         if (d) {
-            g1_affine_t p;
-            load_affine(p, gtab + w * 255 + d - 1);
+            g1_aff28 p;
+            g1_load_aff(p, gtab + w * 255 + d - 1);
             g1_madd(acc, p.x, p.y);
         }
     }
@@ -496,34 +511,32 @@ __global__ void __launch_bounds__(256) k_batch_affine(const g1_xyzz_t* __restric
     if (j0 >= count) return;
     uint64_t j1 = min(j0 + 16, count);
     fp_t acc, d, inv;
-    f_one(acc);
+    fp_one(acc);
     for (uint64_t j = j0; j < j1; j++) {
         g1_xyzz_t p;
         load_xyzz(p, &tmp[j]);
-        out[j].x = acc;
+        park_fp(&out[j], acc);
         if (!g1_is_inf(p)) {
             fp_mul(d, p.zz, p.zzz);
             fp_mul(acc, acc, d);
         }
     }
-    fp_inv(inv, acc);
+    fp_inv_fermat(inv, acc);
     for (uint64_t j = j1; j-- > j0;) {
         g1_xyzz_t p;
         load_xyzz(p, &tmp[j]);
-        g1_affine_t o;
+        g1_aff28 o;
         if (g1_is_inf(p)) {
-            f_zero(o.x); f_zero(o.y);
+            fp_zero(o.x); fp_zero(o.y);
         } else {
-            fp_t pre = out[j].x, iw, tt;
+            fp_t pre, iw;
+            unpark_fp(pre, &out[j]);
             fp_mul(d, p.zz, p.zzz);
             fp_mul(iw, inv, pre);
             fp_mul(inv, inv, d);
-            fp_mul(tt, iw, p.zzz);
-            fp_mul(o.x, p.x, tt);
-            fp_mul(tt, iw, p.zz);
-            fp_mul(o.y, p.y, tt);
+            xyzz_to_aff_with_inv(o, p, iw);
         }
-        out[j] = o;
+        g1_store_aff(&out[j], o);
     }
 }
 
@@ -569,6 +582,12 @@ void launch_g1_sum(hipStream_t s, const g1_xyzz_t* in, uint32_t count, g1_xyzz_t
 }
 void launch_g1_compress(hipStream_t s, const g1_xyzz_t* in, uint8_t* out48) {
     k_g1_compress<<<1, 64, 0, s>>>(in, out48);
+}
+void launch_xyzz_pack(hipStream_t s, const g1_xyzz_t* in, uint32_t* out48w, uint32_t count) {
+    if (count) k_xyzz_pack<<<nblk(count, 64), 64, 0, s>>>(in, out48w, count);
+}
+void launch_xyzz_unpack(hipStream_t s, const uint32_t* in48w, g1_xyzz_t* out, uint32_t count) {
+    if (count) k_xyzz_unpack<<<nblk(count, 64), 64, 0, s>>>(in48w, out, count);
 }
 void launch_srs_from_be96(hipStream_t s, const uint8_t* be96, g1_affine_t* out, uint64_t n, uint32_t* bad_flag) {
     if (!n) return;
