@@ -138,12 +138,14 @@ void prof_end(kzg_ctx* ctx) {  // stream already synchronised
 int choose_window(uint64_t T) {
     int lg = 0;
     while (((uint64_t)1 << (lg + 1)) <= T) lg++;
+    // measured on MI355X (bench.py --window sweep): the bucket tree costs ~log2(B) dependent point additions of
+    // latency, the accumulate n*ceil(256/c) mixed additions of throughput
     if (lg <= 9) return 8;
     if (lg <= 12) return 10;
     if (lg <= 15) return 12;
-    if (lg <= 18) return 14;
-    if (lg <= 22) return 16;
-    return 18;
+    if (lg <= 17) return 14;
+    if (lg <= 19) return 16;
+    return 20;
 }
 // nwin = ceil(256/c) windows of width base or base+1 (256 = nwin*base + extra): the widest is <= c bits
 void set_window(kzg_ctx* ctx, int c) {
@@ -186,9 +188,9 @@ int msm_core(kzg_ctx* ctx, const uint32_t* scalars, int mont, uint64_t n, uint64
     sh.srs_offset = srs_offset; sh.srs_stride = ctx->stride; sh.chunk = pick_chunk(entries);
     const uint32_t nchunks = (uint32_t)((entries + sh.chunk - 1) / sh.chunk);
     const size_t B = ctx->nbuckets;
-    HIPCHK(ctx, ctx->rank.ensure(entries * 4));
+    HIPCHK(ctx, ctx->rank.ensure(entries * 8));          // partitioned (key_low, value) pairs
     HIPCHK(ctx, ctx->sorted.ensure(entries * 4));
-    HIPCHK(ctx, ctx->hist.ensure(B * 4));
+    HIPCHK(ctx, ctx->hist.ensure(4096 * 4));
     HIPCHK(ctx, ctx->offsets.ensure((B + 1) * 4));
     HIPCHK(ctx, ctx->bufA.ensure(B * sizeof(g1_xyzz_t)));
     HIPCHK(ctx, ctx->bufB.ensure(B * sizeof(g1_xyzz_t)));
@@ -197,18 +199,9 @@ int msm_core(kzg_ctx* ctx, const uint32_t* scalars, int mont, uint64_t n, uint64
     HIPCHK(ctx, ctx->carry_key.ensure(((size_t)nchunks + nfold) * 4));
     {
         Span sp(ctx, KZG_T_DIGITS);
-        HIPCHK(ctx, hipMemsetAsync(ctx->hist.p, 0, B * 4, s));
         HIPCHK(ctx, hipMemsetAsync(ctx->bufA.p, 0, B * sizeof(g1_xyzz_t), s));
-        launch_msm_digits_hist(s, sh, scalars, mont, ctx->hist.as<uint32_t>(), ctx->rank.as<uint32_t>());
-    }
-    {
-        Span sp(ctx, KZG_T_SCAN);
-        launch_msm_scan(s, sh, ctx->hist.as<uint32_t>(), ctx->offsets.as<uint32_t>());
-    }
-    {
-        Span sp(ctx, KZG_T_SCATTER);
-        launch_msm_scatter(s, sh, scalars, mont, ctx->offsets.as<uint32_t>(), ctx->rank.as<uint32_t>(),
-                           ctx->sorted.as<uint32_t>());
+        launch_msm_sort(s, sh, scalars, mont, ctx->hist.as<uint32_t>(), ctx->rank.as<uint2>(),
+                        ctx->offsets.as<uint32_t>(), ctx->sorted.as<uint32_t>());
     }
     {
         Span sp(ctx, KZG_T_ACCUMULATE);

@@ -3,9 +3,9 @@
 // Design (DESIGN.md "MSM"): the SRS is fixed, so every point P_j is stored with its window multiples
 // 2^(c*w) P_j (table[w][j], affine, Montgomery; sized for 288 GB HBM).  All nwin signed c-bit digits of all
 // scalars then fall into ONE set of B = 2^(c-1) buckets:
-//   1. msm_digits_hist   scalar -> signed digits, per-bucket histogram (global atomics), rank of each entry
-//   2. msm_scan          exclusive prefix sum of the histogram -> bucket offsets
-//   3. msm_scatter       counting-sort scatter: sorted[offset[key] + rank] = table index | sign
+//   1-3. msm_sort        scalar -> signed digits; two-level counting sort with all per-entry atomics in LDS:
+//                        partition by the key's high bits, then one workgroup per partition sorts the low bits
+//                        -> offsets[bucket], sorted[] = table index | sign
 //   4. msm_accumulate    HOT: every lane sums a fixed-size chunk of the sorted entries with mixed XYZZ adds
 //                        (perfect load balance for any scalar distribution); bucket runs that span chunks
 //                        leave "carry" partial sums
@@ -32,11 +32,10 @@ struct MsmShape {
     int chunk;           // sorted entries per lane in msm_accumulate
 };
 
-void launch_msm_digits_hist(hipStream_t s, const MsmShape& sh, const uint32_t* scalars, int scalars_mont,
-                            uint32_t* hist, uint32_t* rank);
-void launch_msm_scan(hipStream_t s, const MsmShape& sh, const uint32_t* hist, uint32_t* offsets);
-void launch_msm_scatter(hipStream_t s, const MsmShape& sh, const uint32_t* scalars, int scalars_mont,
-                        const uint32_t* offsets, const uint32_t* rank, uint32_t* sorted);
+// signed-digit recode + two-level counting sort: fills offsets[0..nbuckets] and sorted[0..entries).
+// part_ws: 4096 u32 scratch; parted: one uint2 per entry
+void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars, int scalars_mont, uint32_t* part_ws,
+                     uint2* parted, uint32_t* offsets, uint32_t* sorted);
 void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t* table, const uint32_t* offsets,
                            const uint32_t* sorted, g1_xyzz_t* buckets, g1_xyzz_t* carries, uint32_t* carry_key,
                            uint32_t nchunks);
