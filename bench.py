@@ -86,15 +86,17 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the latter: 1-rank RCCL group (self-test)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from zkp_subnet_amd import HipEngine
     from zkp_subnet_amd.distributed import all_gather_partials
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -125,7 +127,7 @@ def main():
 
     def step():
         if args.workload == "msm20":
-            if world == 1:
+            if not use_dist:
                 results.append(eng.msm_resident(0, n, 0))
             else:
                 part = eng.msm_partial_resident(0, n, 0)
@@ -147,7 +149,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     eng.set_profiling(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -216,7 +218,7 @@ def main():
             assert cpu_res == gpu_same, "GPU MSM differs from the CPU oracle on the baseline sample"
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -43,15 +43,15 @@ KZG_DEV uint32_t signed_digit(const uint32_t* s, int w, const WinLayout& lay, ui
 // per block and partition to reserve room); level 2 gives each partition to one workgroup that histograms the low
 // bits in LDS, emits the bucket offsets, and scatters inside its own (L2-resident) slice.  The previous version
 // issued one global atomic per entry (24 G/s chip-wide: 0.9 ms at 2^20, 8 ms at 2^22).
-#define SORT_SCALARS_PER_BLOCK 1024
 struct SortShape {
     uint64_t n, srs_offset, srs_stride;
     int mont, hbits, lbits;  // key = (part << lbits) | low
+    uint32_t spb;            // scalars per workgroup in the two level-1 kernels
 };
 template <class F>
 KZG_DEV void for_each_entry(const uint32_t* __restrict__ scalars, const SortShape& ss, const WinLayout& lay, F&& f) {
-    const uint64_t base = (uint64_t)blockIdx.x * SORT_SCALARS_PER_BLOCK;
-    for (uint32_t r = 0; r < SORT_SCALARS_PER_BLOCK / 256; r++) {
+    const uint64_t base = (uint64_t)blockIdx.x * ss.spb;
+    for (uint32_t r = 0; r < ss.spb / 256; r++) {
         const uint64_t j = base + r * 256 + threadIdx.x;
         if (j >= ss.n) break;
         uint32_t s[8];
@@ -283,6 +283,7 @@ __global__ void __launch_bounds__(256) k_msm_tree_level(const g1_xyzz_t* __restr
     store_xyzz(&out[(uint64_t)k * n_out + m], r);
 }
 
+// sum of the values held by lanes [0, nthreads) (power of two <= blockDim), result in every lane's `mine`
 KZG_DEV void lds_tree_sum(g1_xyzz_t* sm, g1_xyzz_t& mine, uint32_t tid, uint32_t nthreads) {
     store_xyzz(&sm[tid], mine);
     __syncthreads();
@@ -316,7 +317,7 @@ __global__ void __launch_bounds__(64) k_msm_final(const g1_xyzz_t* __restrict__ 
     } else if ((int)tid == nbits) {
         load_xyzz(v, &node[0]);
     }
-    lds_tree_sum(sm, v, tid, 64);
+    lds_tree_sum(sm, v, tid, nbits + 1 <= 32 ? 32 : 64);   // lanes >= nbits + 1 hold infinity
     if (tid == 0) store_xyzz(out, v);
 }
 
@@ -331,7 +332,9 @@ __global__ void __launch_bounds__(64) k_g1_sum(const g1_xyzz_t* __restrict__ in,
         g1_add(r, acc, q);
         acc = r;
     }
-    lds_tree_sum(sm, acc, tid, 64);
+    uint32_t lanes = 1;                      // tree only over the lanes that can hold a term
+    while (lanes < count && lanes < 64) lanes <<= 1;
+    lds_tree_sum(sm, acc, tid, lanes);
     if (tid == 0) store_xyzz(out, acc);
 }
 
@@ -609,14 +612,16 @@ void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars,
     const int keybits = sh.c - 1;
     SortShape ss;
     ss.n = sh.n; ss.srs_offset = sh.srs_offset; ss.srs_stride = sh.srs_stride; ss.mont = scalars_mont;
-    ss.lbits = keybits > 8 ? (keybits - 8 > 12 ? 12 : keybits - 8) : 0;
+    // up to 1024 partitions: level 2 runs one workgroup per partition, so more partitions = more parallel level 2
+    ss.lbits = keybits > 10 ? (keybits - 10 > 12 ? 12 : keybits - 10) : 0;
     ss.hbits = keybits - ss.lbits;  // <= 10 for c <= 23
+    ss.spb = sh.n >= (1u << 21) ? 4096u : 1024u;
     const uint32_t npart = 1u << ss.hbits;
     uint32_t* part_count = part_ws;              // [npart]
     uint32_t* part_base = part_ws + 1024;        // [npart + 1]
     uint32_t* part_cursor = part_ws + 2 * 1024 + 8;
     hipMemsetAsync(part_count, 0, npart * 4, s);
-    const uint32_t blocks = nblk(sh.n, SORT_SCALARS_PER_BLOCK);
+    const uint32_t blocks = nblk(sh.n, ss.spb);
     k_sort_count<<<blocks, 256, 0, s>>>(scalars, ss, sh.lay, part_count);
     k_sort_part_scan<<<1, 1024, 0, s>>>(part_count, npart, part_base, part_cursor);
     k_sort_partition<<<blocks, 256, 0, s>>>(scalars, ss, sh.lay, part_base, part_cursor, parted);
