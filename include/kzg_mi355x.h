@@ -77,6 +77,21 @@ int kzg_ntt(kzg_ctx* ctx, uint8_t* inout_be32, uint64_t n, int inverse);
 /* replaces Client.eval(poly, x)                     (reference neurons/validator.py:97-104) */
 int kzg_eval(kzg_ctx* ctx, const uint8_t* coeffs_be32, uint64_t n, const uint8_t x_be32[32], uint8_t out_be32[32]);
 
+/* ---- verification: replaces Client.worker_verify(i, proof, alpha, eval, commitment)
+ *      (reference neurons/validator.py:77-86; tests/test_miner.py:101-111).  Host-side pairing check
+ *      e(C - y [L_i]_1, [1]_2) == e(pi, [tau_x - alpha]_2): one-off per proof, no GPU involved, so the verifier key is
+ *      its own object.  *out_valid = 1 / 0; malformed or off-curve proof / commitment bytes give valid = 0. */
+typedef struct kzg_vk kzg_vk;
+/* tau_g2: uncompressed G2 x.c1||x.c0||y.c1||y.c0 (4 x 48 B big-endian); li_g1: [L_i(tau_y)]_1 per resident slice */
+int kzg_vk_create(const uint8_t tau_g2_be192[192], const uint8_t* li_g1_be96, uint32_t n_slices, kzg_vk** out);
+/* synthetic setup with known trapdoor (same tau / s0 as kzg_gen_srs): tests and benches */
+int kzg_vk_create_synthetic(const uint8_t tau_be32[32], const uint8_t* s0_be32, uint32_t n_slices, kzg_vk** out);
+void kzg_vk_destroy(kzg_vk* vk);
+int kzg_vk_verify(const kzg_vk* vk, uint32_t i, const uint8_t proof48[48], const uint8_t alpha_be32[32],
+                  const uint8_t eval_be32[32], const uint8_t commitment48[48], int* out_valid);
+/* test hook: final_exp(miller(P, Q)) as 12 x 48 B in tower order (Fp12 = Fp6[w], Fp6 = Fp2[v], Fp2 = Fp[u]) */
+int kzg_vk_pairing(const uint8_t p_be96[96], const uint8_t q_be192[192], uint8_t out_fp12[576]);
+
 /* ---- multi-GPU: each rank reduces its SRS shard to ONE partial sum; the 192-byte partials are exchanged by
  *      the caller (RCCL all_gather over xGMI in zkp_subnet_amd.distributed) and summed on any rank. */
 int kzg_msm_partial(kzg_ctx* ctx, const uint8_t* scalars_be32, uint64_t n, uint64_t srs_offset,

@@ -342,6 +342,14 @@ def test_client_and_miner_on_hip_engine(hip, fr_kat):
     with miner.client.worker_open(i=0, poly=syn.poly, x=syn.alpha) as r:
         assert r.status_code == 200
         ev, proof = r.json()["eval"], r.json()["proof"]
+    with miner.client.worker_verify(i=0, proof=proof, alpha=syn.alpha, eval=ev, commitment=commitment) as r:
+        assert r.status_code == 200 and r.json().get("valid") is True       # reference tests/test_miner.py:101-111
+    raw = base64.b64decode(proof)                                            # reference tests/test_validator.py:79-86
+    bumped = base64.b64encode((int.from_bytes(raw, "big") + 1).to_bytes(len(raw), "big")).decode()
+    with miner.client.worker_verify(i=0, proof=bumped, alpha=syn.alpha, eval=ev, commitment=commitment) as r:
+        assert r.status_code == 200 and r.json().get("valid") is False
+    with miner.client.worker_verify(i=1, proof=proof, alpha=syn.alpha, eval=ev, commitment=commitment) as r:
+        assert r.json().get("valid") is False                               # another worker's basis
     ret = miner.forward(syn)
     assert (ret.commitment, ret.proof, ret.eval) == (commitment, proof, ev)
     tx, ty = derive_taus(6)
@@ -356,4 +364,13 @@ def test_client_and_miner_on_hip_engine(hip, fr_kat):
         coeffs = r.json()["poly"]
     with miner.client.eval(coeffs, syn.alpha) as r:
         assert r.json()["y"] == ev
+    # validator mirror end to end on the HIP engine: challenge -> forward -> pairing-verified reward table
+    from zkp_subnet_amd.validator import generate_challenge, reward
+
+    ch = generate_challenge(miner.client, 2)
+    responses = [miner.forward(ch.to_synapse(i)) for i in range(2)]
+    assert [reward(miner.client, ch, responses[i], i, 0.0) for i in range(2)] == [1.0, 1.0]
+    assert reward(miner.client, ch, responses[0], 0, 15.0) == 0.5
+    assert reward(miner.client, ch, responses[0], 1, 0.0) == 0.0
+    assert responses[1].eval == ch.evals[1]
     miner.stop()

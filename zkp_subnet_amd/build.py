@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libkzg_mi355x.so")
-SOURCES = ["msm.hip", "fr_kernels.hip", "api.hip"]
+SOURCES = ["msm.hip", "fr_kernels.hip", "api.hip", "pairing_host.cpp"]
 HEADERS = ["bigint.cuh", "field.cuh", "fp28.cuh", "g1.cuh", "msm.cuh", "fr_kernels.cuh", "../../include/kzg_mi355x.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 
@@ -40,7 +40,7 @@ def build(force: bool = False, extra_flags=()) -> str:
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         if force or _stale(o, [s] + hdrs):
             jobs.append([hipcc, *FLAGS, *extra_flags, "-c", s, "-o", o])
     if jobs:
@@ -48,7 +48,7 @@ def build(force: bool = False, extra_flags=()) -> str:
             for res in ex.map(lambda cmd: subprocess.run(cmd, capture_output=True, text=True), jobs):
                 if res.returncode != 0:
                     raise RuntimeError("hipcc failed:\n" + " ".join(res.args) + "\n" + res.stderr[-4000:])
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
+    objs = [os.path.join(OBJ, os.path.splitext(s)[0] + ".o") for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
         res = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs],
                              capture_output=True, text=True)

@@ -97,6 +97,11 @@ class Client:
                 raise ValueError("setup file must be a whole number of 96-byte affine G1 points")
             self.engine.load_srs(data, scale, machines_scale)
             self._slice_of = None
+            vk_path = self.setup_path + ".vk"   # 192 B [tau_x]_2 (uncompressed) + one 96 B [L_i(tau_y)]_1 per slice
+            if os.path.exists(vk_path) and hasattr(self.engine, "set_verifier_key"):
+                with open(vk_path, "rb") as f:
+                    vk = f.read()
+                self.engine.set_verifier_key(vk[:192], vk[192:])
         else:
             seed = self.seed if self.seed is not None else 0
             tau_x, tau_y = derive_taus(seed)
@@ -144,7 +149,7 @@ class Client:
     def worker_verify(self, i: int, proof: str, alpha: str, eval: str, commitment: str):
         verify = getattr(self.engine, "verify", None)
         if verify is None:
-            raise NotImplementedError("worker_verify (pairing check) is not built yet: SURVEY 8f rank 1")
+            raise NotImplementedError("this engine has no verifier")
         ok = verify(self._slice(i), codec.g1_from_b64(proof), codec.fr_to_be32(alpha), codec.fr_to_be32(eval),
                     codec.g1_from_b64(commitment))
         return {"valid": bool(ok)}

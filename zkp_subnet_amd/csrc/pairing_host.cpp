@@ -1,0 +1,541 @@
+// Host-side KZG opening verifier (BLS12-381 optimal-ate pairing) -- product code, plain C++17, no GPU.
+//
+// Replaces what the reference reaches through client.worker_verify(i, proof, alpha, eval, commitment)
+// (reference neurons/validator.py:77-86, used by reward() at :160-170 and tests/test_miner.py:101-111):
+//     accept  <=>  e(C - y [L_i(tau_y)]_1, [1]_2) == e(pi, [tau_x - alpha]_2)
+// checked as  e(C - y L_i, -G2) * e(pi, tau_G2 - alpha G2) == 1  (two Miller loops, one final exponentiation).
+// Verification is one-off per proof (two pairings), so it runs on the host; the MSM / NTT
+// hot path never touches this file.  Tower Fp2 = Fp[u]/(u^2+1), Fp6 = Fp2[v]/(v^3 - (1+u)), Fp12 = Fp6[w]/(w^2 - v);
+// affine Miller loop on the twist with full Fp12 line values; final exponentiation = easy part by conjugation and
+// inversion, hard part (p^6+1)/r as one fixed exponent.  Checked against the independent pure-Python pairing of
+// oracle/pairing.py (direct degree-12 extension) in tests/test_verify.py.
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/kzg_mi355x.h"
+
+namespace {
+
+typedef uint64_t u64;
+typedef unsigned __int128 u128;
+
+// ------------------------------------------------------------------------------------------------ Fp
+struct Fp {
+    u64 l[6];
+};
+const u64 PM[6] = {0xb9feffffffffaaabULL, 0x1eabfffeb153ffffULL, 0x6730d2a0f6b0f624ULL,
+                   0x64774b84f38512bfULL, 0x4b1ba7b6434bacd7ULL, 0x1a0111ea397fe69aULL};
+const u64 P_INV = 0x89f3fffcfffcfffdULL;  // -p^-1 mod 2^64
+const Fp FP_R = {{0x760900000002fffdULL, 0xebf4000bc40c0002ULL, 0x5f48985753c758baULL, 0x77ce585370525745ULL,
+                  0x5c071a97a256ec6dULL, 0x15f65ec3fa80e493ULL}};   // 2^384 mod p
+const Fp FP_R2 = {{0xf4df1f341c341746ULL, 0x0a76e6a609d104f1ULL, 0x8de5476c4c95b6d5ULL, 0x67eb88a9939d83c0ULL,
+                   0x9a793e85b519952dULL, 0x11988fe592cae3aaULL}};  // 2^768 mod p
+const u64 R_ORDER[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+const u64 SQRT_EXP[6] = {0xee7fbfffffffeaabULL, 0x07aaffffac54ffffULL, 0xd9cc34a83dac3d89ULL,
+                         0xd91dd2e13ce144afULL, 0x92c6e9ed90d2eb35ULL, 0x0680447a8e5ff9a6ULL};  // (p+1)/4
+const u64 HARD_EXP[32] = {  // (p^6 + 1) / r
+    0x8739e1cdc0705d6aULL, 0x09a5256de0381a16ULL, 0x9cf0f70a61c791e2ULL, 0x3a09c4497903f76eULL,
+    0x2d7271563890f133ULL, 0x224741b36fec7760ULL, 0x338259c22a12bd40ULL, 0x38ee1cd4778e0de7ULL,
+    0xc3b5ef4b188a20b0ULL, 0x1d615d49e2764d7bULL, 0x816101ddd076117dULL, 0xf007c01e7ebe3afcULL,
+    0x27d7bd90935021c3ULL, 0xc3b5e2f557c0b15fULL, 0x5e886c94c4f82384ULL, 0xee6a95db11e63f56ULL,
+    0x2b822f514a9c4f6fULL, 0x12d6a874d21b73daULL, 0x1304275ef499dffbULL, 0x967878febcb95d1fULL,
+    0x4744497f8b2f2922ULL, 0x85a2e707f0841855ULL, 0x9f0c50126c802eecULL, 0xfb46e197bd2fa489ULL,
+    0x548ce0809bc5f61aULL, 0xcf56fb1573beaa8cULL, 0xad7375a3763bdf7cULL, 0xe0ec9031179bdeccULL,
+    0x6579aea83c48c1daULL, 0xdbf85ae664cf5bb3ULL, 0x7b6f235c55ca7566ULL, 0x000028b314877503ULL};
+const u64 ATE_LOOP = 0xd201000000010000ULL;  // |x|
+
+inline bool ge6(const u64* a, const u64* b) {
+    for (int i = 5; i >= 0; i--) {
+        if (a[i] != b[i]) return a[i] > b[i];
+    }
+    return true;
+}
+inline u64 sub6(u64* r, const u64* a, const u64* b) {
+    u64 br = 0;
+    for (int i = 0; i < 6; i++) {
+        u128 t = (u128)a[i] - b[i] - br;
+        r[i] = (u64)t;
+        br = (u64)(t >> 64) & 1;
+    }
+    return br;
+}
+inline u64 add6(u64* r, const u64* a, const u64* b) {
+    u128 c = 0;
+    for (int i = 0; i < 6; i++) {
+        c += (u128)a[i] + b[i];
+        r[i] = (u64)c;
+        c >>= 64;
+    }
+    return (u64)c;
+}
+inline Fp operator+(const Fp& a, const Fp& b) {
+    Fp r;
+    u64 c = add6(r.l, a.l, b.l);
+    if (c || ge6(r.l, PM)) sub6(r.l, r.l, PM);
+    return r;
+}
+inline Fp operator-(const Fp& a, const Fp& b) {
+    Fp r;
+    if (sub6(r.l, a.l, b.l)) add6(r.l, r.l, PM);
+    return r;
+}
+inline bool is_zero(const Fp& a) {
+    u64 t = 0;
+    for (int i = 0; i < 6; i++) t |= a.l[i];
+    return t == 0;
+}
+inline Fp neg(const Fp& a) {
+    if (is_zero(a)) return a;
+    Fp r;
+    sub6(r.l, PM, a.l);
+    return r;
+}
+inline bool operator==(const Fp& a, const Fp& b) { return memcmp(a.l, b.l, sizeof(a.l)) == 0; }
+inline Fp operator*(const Fp& a, const Fp& b) {  // CIOS Montgomery product
+    u64 t[8] = {0};
+    for (int i = 0; i < 6; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 6; j++) {
+            c += (u128)a.l[j] * b.l[i] + t[j];
+            t[j] = (u64)c;
+            c >>= 64;
+        }
+        c += t[6];
+        t[6] = (u64)c;
+        t[7] = (u64)(c >> 64);
+        u64 q = t[0] * P_INV;
+        c = (u128)q * PM[0] + t[0];
+        c >>= 64;
+        for (int j = 1; j < 6; j++) {
+            c += (u128)q * PM[j] + t[j];
+            t[j - 1] = (u64)c;
+            c >>= 64;
+        }
+        c += t[6];
+        t[5] = (u64)c;
+        t[6] = t[7] + (u64)(c >> 64);
+    }
+    Fp r;
+    if (t[6] || ge6(t, PM)) sub6(r.l, t, PM);
+    else memcpy(r.l, t, sizeof(r.l));
+    return r;
+}
+Fp fp_pow(const Fp& a, const u64* e, int words) {
+    Fp acc = FP_R;
+    for (int i = words * 64 - 1; i >= 0; i--) {
+        acc = acc * acc;
+        if ((e[i / 64] >> (i % 64)) & 1) acc = acc * a;
+    }
+    return acc;
+}
+Fp inv(const Fp& a) {
+    u64 e[6], two[6] = {2, 0, 0, 0, 0, 0};
+    sub6(e, PM, two);
+    return fp_pow(a, e, 6);
+}
+bool fp_from_be48(Fp& r, const uint8_t* b) {  // false when >= p
+    Fp t;
+    for (int i = 0; i < 6; i++) {
+        u64 v = 0;
+        for (int k = 0; k < 8; k++) v = (v << 8) | b[(5 - i) * 8 + k];
+        t.l[i] = v;
+    }
+    if (ge6(t.l, PM)) return false;
+    r = t * FP_R2;
+    return true;
+}
+void fp_to_limbs(u64* out, const Fp& a) {
+    Fp one{{1, 0, 0, 0, 0, 0}};
+    Fp t = a * one;
+    memcpy(out, t.l, sizeof(t.l));
+}
+void fp_to_be48(uint8_t* b, const Fp& a) {
+    u64 t[6];
+    fp_to_limbs(t, a);
+    for (int i = 0; i < 6; i++)
+        for (int k = 0; k < 8; k++) b[(5 - i) * 8 + k] = (uint8_t)(t[i] >> (56 - 8 * k));
+}
+Fp fp_small(u64 v) {
+    Fp t{{v, 0, 0, 0, 0, 0}};
+    return t * FP_R2;
+}
+
+// ------------------------------------------------------------------------------------------------ Fp2
+struct Fp2 {
+    Fp c0, c1;
+};
+inline Fp2 operator+(const Fp2& a, const Fp2& b) { return {a.c0 + b.c0, a.c1 + b.c1}; }
+inline Fp2 operator-(const Fp2& a, const Fp2& b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
+inline Fp2 neg(const Fp2& a) { return {neg(a.c0), neg(a.c1)}; }
+inline bool is_zero(const Fp2& a) { return is_zero(a.c0) && is_zero(a.c1); }
+inline bool operator==(const Fp2& a, const Fp2& b) { return a.c0 == b.c0 && a.c1 == b.c1; }
+inline Fp2 operator*(const Fp2& a, const Fp2& b) {
+    Fp t0 = a.c0 * b.c0, t1 = a.c1 * b.c1;
+    Fp m = (a.c0 + a.c1) * (b.c0 + b.c1);
+    return {t0 - t1, m - t0 - t1};
+}
+inline Fp2 mul_xi(const Fp2& a) { return {a.c0 - a.c1, a.c0 + a.c1}; }  // * (1 + u)
+Fp2 inv(const Fp2& a) {
+    Fp d = inv(a.c0 * a.c0 + a.c1 * a.c1);
+    return {a.c0 * d, neg(a.c1) * d};
+}
+Fp2 fp2_small(u64 v) { return {fp_small(v), Fp{}}; }
+Fp2 fp2_one() { return {FP_R, Fp{}}; }
+
+// ------------------------------------------------------------------------------------------------ Fp6, Fp12
+struct Fp6 {
+    Fp2 c0, c1, c2;
+};
+inline Fp6 operator+(const Fp6& a, const Fp6& b) { return {a.c0 + b.c0, a.c1 + b.c1, a.c2 + b.c2}; }
+inline Fp6 operator-(const Fp6& a, const Fp6& b) { return {a.c0 - b.c0, a.c1 - b.c1, a.c2 - b.c2}; }
+inline Fp6 neg(const Fp6& a) { return {neg(a.c0), neg(a.c1), neg(a.c2)}; }
+inline Fp6 operator*(const Fp6& a, const Fp6& b) {
+    Fp2 t0 = a.c0 * b.c0, t1 = a.c1 * b.c1, t2 = a.c2 * b.c2;
+    Fp2 c0 = t0 + mul_xi((a.c1 + a.c2) * (b.c1 + b.c2) - t1 - t2);
+    Fp2 c1 = (a.c0 + a.c1) * (b.c0 + b.c1) - t0 - t1 + mul_xi(t2);
+    Fp2 c2 = (a.c0 + a.c2) * (b.c0 + b.c2) - t0 - t2 + t1;
+    return {c0, c1, c2};
+}
+inline Fp6 mul_v(const Fp6& a) { return {mul_xi(a.c2), a.c0, a.c1}; }
+Fp6 inv(const Fp6& a) {
+    Fp2 c0 = a.c0 * a.c0 - mul_xi(a.c1 * a.c2);
+    Fp2 c1 = mul_xi(a.c2 * a.c2) - a.c0 * a.c1;
+    Fp2 c2 = a.c1 * a.c1 - a.c0 * a.c2;
+    Fp2 t = inv(mul_xi(a.c2 * c1 + a.c1 * c2) + a.c0 * c0);
+    return {c0 * t, c1 * t, c2 * t};
+}
+struct Fp12 {
+    Fp6 c0, c1;
+};
+inline Fp12 operator*(const Fp12& a, const Fp12& b) {
+    Fp6 t0 = a.c0 * b.c0, t1 = a.c1 * b.c1;
+    return {t0 + mul_v(t1), (a.c0 + a.c1) * (b.c0 + b.c1) - t0 - t1};
+}
+inline Fp12 conj(const Fp12& a) { return {a.c0, neg(a.c1)}; }
+Fp12 inv(const Fp12& a) {
+    Fp6 t = inv(a.c0 * a.c0 - mul_v(a.c1 * a.c1));
+    return {a.c0 * t, neg(a.c1) * t};
+}
+Fp12 fp12_one() {
+    Fp12 r{};
+    r.c0.c0 = fp2_one();
+    return r;
+}
+bool is_one(const Fp12& a) {
+    Fp12 o = fp12_one();
+    return memcmp(&a, &o, sizeof(a)) == 0;
+}
+
+// ------------------------------------------------------------------------------------------------ curves
+template <class F>
+struct Aff {
+    F x, y;
+    bool inf;
+};
+template <class F>
+struct Jac {
+    F x, y, z;
+};
+template <class F>
+F f_one();
+template <>
+Fp f_one<Fp>() { return FP_R; }
+template <>
+Fp2 f_one<Fp2>() { return fp2_one(); }
+template <class F>
+Jac<F> jac_inf() {
+    Jac<F> r{};
+    r.x = f_one<F>();
+    r.y = f_one<F>();
+    return r;
+}
+template <class F>
+Jac<F> to_jac(const Aff<F>& a) {
+    if (a.inf) return jac_inf<F>();
+    return {a.x, a.y, f_one<F>()};
+}
+template <class F>
+Jac<F> jac_double(const Jac<F>& p) {
+    if (is_zero(p.z) || is_zero(p.y)) return jac_inf<F>();
+    F A = p.x * p.x, B = p.y * p.y, C = B * B;
+    F t = p.x + B;
+    F D = t * t - A - C;
+    D = D + D;
+    F E = A + A + A, Fq = E * E;
+    F x3 = Fq - D - D;
+    F c8 = C + C;
+    c8 = c8 + c8;
+    c8 = c8 + c8;
+    F y3 = E * (D - x3) - c8;
+    F z3 = p.y * p.z;
+    z3 = z3 + z3;
+    return {x3, y3, z3};
+}
+template <class F>
+Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
+    if (is_zero(p.z)) return q;
+    if (is_zero(q.z)) return p;
+    F z1z1 = p.z * p.z, z2z2 = q.z * q.z;
+    F u1 = p.x * z2z2, u2 = q.x * z1z1;
+    F s1 = p.y * q.z * z2z2, s2 = q.y * p.z * z1z1;
+    if (u1 == u2) {
+        if (s1 == s2) return jac_double(p);
+        return jac_inf<F>();
+    }
+    F h = u2 - u1, rr = s2 - s1;
+    F hh = h * h, hhh = h * hh, v = u1 * hh;
+    F x3 = rr * rr - hhh - v - v;
+    F y3 = rr * (v - x3) - s1 * hhh;
+    F z3 = p.z * q.z * h;
+    return {x3, y3, z3};
+}
+template <class F>
+Jac<F> jac_mul(const Aff<F>& p, const u64* k, int words) {
+    Jac<F> acc = jac_inf<F>(), base = to_jac(p);
+    for (int i = words * 64 - 1; i >= 0; i--) {
+        acc = jac_double(acc);
+        if ((k[i / 64] >> (i % 64)) & 1) acc = jac_add(acc, base);
+    }
+    return acc;
+}
+template <class F>
+Aff<F> to_aff(const Jac<F>& p) {
+    if (is_zero(p.z)) return {F{}, F{}, true};
+    F zi = inv(p.z), zi2 = zi * zi;
+    return {p.x * zi2, p.y * zi2 * zi, false};
+}
+template <class F>
+Aff<F> aff_neg(const Aff<F>& a) {
+    return {a.x, neg(a.y), a.inf};
+}
+
+typedef Aff<Fp> G1A;
+typedef Aff<Fp2> G2A;
+
+bool g1_on_curve(const G1A& p) { return p.inf || p.y * p.y == p.x * p.x * p.x + fp_small(4); }
+bool g2_on_curve(const G2A& p) {
+    Fp2 b{fp_small(4), fp_small(4)};
+    return p.inf || p.y * p.y == p.x * p.x * p.x + b;
+}
+template <class F>
+bool in_subgroup(const Aff<F>& p) {
+    return is_zero(jac_mul(p, R_ORDER, 4).z);
+}
+G1A g1_generator() {
+    static const uint8_t gx[48] = {0x17, 0xf1, 0xd3, 0xa7, 0x31, 0x97, 0xd7, 0x94, 0x26, 0x95, 0x63, 0x8c, 0x4f, 0xa9, 0xac, 0x0f,
+                                   0xc3, 0x68, 0x8c, 0x4f, 0x97, 0x74, 0xb9, 0x05, 0xa1, 0x4e, 0x3a, 0x3f, 0x17, 0x1b, 0xac, 0x58,
+                                   0x6c, 0x55, 0xe8, 0x3f, 0xf9, 0x7a, 0x1a, 0xef, 0xfb, 0x3a, 0xf0, 0x0a, 0xdb, 0x22, 0xc6, 0xbb};
+    static const uint8_t gy[48] = {0x08, 0xb3, 0xf4, 0x81, 0xe3, 0xaa, 0xa0, 0xf1, 0xa0, 0x9e, 0x30, 0xed, 0x74, 0x1d, 0x8a, 0xe4,
+                                   0xfc, 0xf5, 0xe0, 0x95, 0xd5, 0xd0, 0x0a, 0xf6, 0x00, 0xdb, 0x18, 0xcb, 0x2c, 0x04, 0xb3, 0xed,
+                                   0xd0, 0x3c, 0xc7, 0x44, 0xa2, 0x88, 0x8a, 0xe4, 0x0c, 0xaa, 0x23, 0x29, 0x46, 0xc5, 0xe7, 0xe1};
+    G1A g{};
+    fp_from_be48(g.x, gx);
+    fp_from_be48(g.y, gy);
+    return g;
+}
+bool hex48(Fp& out, const char* hex) {
+    uint8_t b[48];
+    for (int i = 0; i < 48; i++) {
+        auto nib = [](char c) { return (uint8_t)(c <= '9' ? c - '0' : (c | 32) - 'a' + 10); };
+        b[i] = (uint8_t)((nib(hex[2 * i]) << 4) | nib(hex[2 * i + 1]));
+    }
+    return fp_from_be48(out, b);
+}
+G2A g2_generator() {
+    G2A g{};
+    hex48(g.x.c0, "024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8");
+    hex48(g.x.c1, "13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e");
+    hex48(g.y.c0, "0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801");
+    hex48(g.y.c1, "0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be");
+    return g;
+}
+
+// ZCash compressed G1 -> affine; false when malformed / not on the curve
+bool g1_decompress(G1A& out, const uint8_t* c48) {
+    if (!(c48[0] & 0x80)) return false;
+    if (c48[0] & 0x40) {
+        if (c48[0] != 0xC0) return false;
+        for (int i = 1; i < 48; i++)
+            if (c48[i]) return false;
+        out = {Fp{}, Fp{}, true};
+        return true;
+    }
+    uint8_t xb[48];
+    memcpy(xb, c48, 48);
+    xb[0] &= 0x1F;
+    Fp x;
+    if (!fp_from_be48(x, xb)) return false;
+    Fp rhs = x * x * x + fp_small(4);
+    Fp y = fp_pow(rhs, SQRT_EXP, 6);
+    if (!(y * y == rhs)) return false;
+    u64 yl[6], twice[6];
+    fp_to_limbs(yl, y);
+    u64 c = add6(twice, yl, yl);
+    const bool larger = c || ge6(twice, PM);  // y > (p-1)/2
+    if (larger != ((c48[0] & 0x20) != 0)) y = neg(y);
+    out = {x, y, false};
+    return true;
+}
+bool g1_from_be96(G1A& out, const uint8_t* b) {
+    bool zero = true;
+    for (int i = 0; i < 96; i++) zero &= b[i] == 0;
+    if (zero) {
+        out = {Fp{}, Fp{}, true};
+        return true;
+    }
+    out.inf = false;
+    return fp_from_be48(out.x, b) && fp_from_be48(out.y, b + 48) && g1_on_curve(out);
+}
+// uncompressed G2, ZCash order x.c1 || x.c0 || y.c1 || y.c0
+bool g2_from_be192(G2A& out, const uint8_t* b) {
+    bool zero = true;
+    for (int i = 0; i < 192; i++) zero &= b[i] == 0;
+    if (zero) {
+        out = {Fp2{}, Fp2{}, true};
+        return true;
+    }
+    out.inf = false;
+    return fp_from_be48(out.x.c1, b) && fp_from_be48(out.x.c0, b + 48) && fp_from_be48(out.y.c1, b + 96) &&
+           fp_from_be48(out.y.c0, b + 144) && g2_on_curve(out);
+}
+bool fr_from_be32(u64* k, const uint8_t* b) {  // canonical check
+    for (int i = 0; i < 4; i++) {
+        u64 v = 0;
+        for (int j = 0; j < 8; j++) v = (v << 8) | b[(3 - i) * 8 + j];
+        k[i] = v;
+    }
+    for (int i = 3; i >= 0; i--) {
+        if (k[i] != R_ORDER[i]) return k[i] < R_ORDER[i];
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------ pairing
+// Line through T (and Q, or tangent) on the twist, evaluated at P in G1, scaled by w^3 (killed by the final
+// exponentiation):  l = (lam xT - yT)  -  lam xP * v  +  yP * v w
+Fp12 line_value(const Fp2& lam, const G2A& t, const G1A& p) {
+    Fp12 l{};
+    l.c0.c0 = lam * t.x - t.y;
+    l.c0.c1 = neg(Fp2{lam.c0 * p.x, lam.c1 * p.x});
+    l.c1.c1 = Fp2{p.y, Fp{}};
+    return l;
+}
+Fp12 miller_loop(const G1A& p, const G2A& q) {
+    if (p.inf || q.inf) return fp12_one();
+    Fp12 f = fp12_one();
+    G2A t = q;
+    for (int i = 62; i >= 0; i--) {  // bit 63 of |x| is the leading one
+        Fp2 lam = (t.x * t.x) * fp2_small(3) * inv(t.y + t.y);
+        f = f * f * line_value(lam, t, p);
+        Fp2 x3 = lam * lam - t.x - t.x;
+        t = {x3, lam * (t.x - x3) - t.y, false};
+        if ((ATE_LOOP >> i) & 1) {
+            Fp2 lam2 = (q.y - t.y) * inv(q.x - t.x);
+            f = f * line_value(lam2, t, p);
+            Fp2 x4 = lam2 * lam2 - t.x - q.x;
+            t = {x4, lam2 * (t.x - x4) - t.y, false};
+        }
+    }
+    return f;  // the sign of the BLS parameter would invert f: irrelevant for a product-equals-one check
+}
+Fp12 final_exp(const Fp12& f) {
+    Fp12 f1 = conj(f) * inv(f);  // f^(p^6 - 1)
+    Fp12 acc = fp12_one();
+    for (int i = 32 * 64 - 1; i >= 0; i--) {
+        acc = acc * acc;
+        if ((HARD_EXP[i / 64] >> (i % 64)) & 1) acc = acc * f1;
+    }
+    return acc;
+}
+
+struct VerifierKey {
+    G2A tau_g2;
+    G2A g2;
+    std::vector<G1A> li;  // [L_i(tau_y)]_1 per resident slice
+};
+
+}  // namespace
+
+struct kzg_vk {
+    VerifierKey k;
+};
+
+extern "C" {
+
+int kzg_vk_create(const uint8_t tau_g2_be192[192], const uint8_t* li_g1_be96, uint32_t n_slices, kzg_vk** out) {
+    if (!tau_g2_be192 || !li_g1_be96 || !n_slices || !out) return KZG_E_ARG;
+    kzg_vk* vk = new kzg_vk();
+    vk->k.g2 = g2_generator();
+    if (!g2_from_be192(vk->k.tau_g2, tau_g2_be192) || !in_subgroup(vk->k.tau_g2)) {
+        delete vk;
+        return KZG_E_POINT;
+    }
+    for (uint32_t i = 0; i < n_slices; i++) {
+        G1A p;
+        if (!g1_from_be96(p, li_g1_be96 + 96 * (size_t)i) || !in_subgroup(p)) {
+            delete vk;
+            return KZG_E_POINT;
+        }
+        vk->k.li.push_back(p);
+    }
+    *out = vk;
+    return KZG_OK;
+}
+/* synthetic setup with a known trapdoor: tau_G2 = [tau] G2, li_k = [s0_k] G1 (same s0 as kzg_gen_srs) */
+int kzg_vk_create_synthetic(const uint8_t tau_be32[32], const uint8_t* s0_be32, uint32_t n_slices, kzg_vk** out) {
+    if (!tau_be32 || !s0_be32 || !n_slices || !out) return KZG_E_ARG;
+    u64 k[4];
+    if (!fr_from_be32(k, tau_be32)) return KZG_E_SCALAR;
+    kzg_vk* vk = new kzg_vk();
+    vk->k.g2 = g2_generator();
+    vk->k.tau_g2 = to_aff(jac_mul(vk->k.g2, k, 4));
+    const G1A g1 = g1_generator();
+    for (uint32_t i = 0; i < n_slices; i++) {
+        if (!fr_from_be32(k, s0_be32 + 32 * (size_t)i)) {
+            delete vk;
+            return KZG_E_SCALAR;
+        }
+        vk->k.li.push_back(to_aff(jac_mul(g1, k, 4)));
+    }
+    *out = vk;
+    return KZG_OK;
+}
+void kzg_vk_destroy(kzg_vk* vk) { delete vk; }
+
+int kzg_vk_verify(const kzg_vk* vk, uint32_t i, const uint8_t proof48[48], const uint8_t alpha_be32[32],
+                  const uint8_t eval_be32[32], const uint8_t commitment48[48], int* out_valid) {
+    if (!vk || !proof48 || !alpha_be32 || !eval_be32 || !commitment48 || !out_valid) return KZG_E_ARG;
+    *out_valid = 0;
+    if (i >= vk->k.li.size()) return KZG_E_ARG;
+    u64 alpha[4], y[4];
+    if (!fr_from_be32(alpha, alpha_be32) || !fr_from_be32(y, eval_be32)) return KZG_E_SCALAR;
+    G1A c, pi;
+    // malformed or off-curve / out-of-subgroup group elements are an invalid proof, not a call failure
+    if (!g1_decompress(c, commitment48) || !g1_decompress(pi, proof48)) return KZG_OK;
+    if (!in_subgroup(c) || !in_subgroup(pi)) return KZG_OK;
+    // lhs = C - y * L_i ; rhs_q = tau_G2 - alpha * G2
+    Jac<Fp> yl = jac_mul(vk->k.li[i], y, 4);
+    G1A lhs = to_aff(jac_add(to_jac(c), to_jac(aff_neg(to_aff(yl)))));
+    Jac<Fp2> ag = jac_mul(vk->k.g2, alpha, 4);
+    G2A rhs_q = to_aff(jac_add(to_jac(vk->k.tau_g2), to_jac(aff_neg(to_aff(ag)))));
+    Fp12 f = miller_loop(lhs, aff_neg(vk->k.g2)) * miller_loop(pi, rhs_q);
+    *out_valid = is_one(final_exp(f)) ? 1 : 0;
+    return KZG_OK;
+}
+
+/* test hook: out = final_exp(miller(P, Q)) as 12 x 48 bytes in tower order
+ * (c0.c0.c0, c0.c0.c1, c0.c1.c0, ..., c1.c2.c1); P affine be96, Q uncompressed be192 */
+int kzg_vk_pairing(const uint8_t p_be96[96], const uint8_t q_be192[192], uint8_t out_fp12[576]) {
+    if (!p_be96 || !q_be192 || !out_fp12) return KZG_E_ARG;
+    G1A p;
+    G2A q;
+    if (!g1_from_be96(p, p_be96) || !g2_from_be192(q, q_be192)) return KZG_E_POINT;
+    Fp12 e = final_exp(miller_loop(p, q));
+    const Fp* c = reinterpret_cast<const Fp*>(&e);
+    for (int k = 0; k < 12; k++) fp_to_be48(out_fp12 + 48 * k, c[k]);
+    return KZG_OK;
+}
+
+}  // extern "C"

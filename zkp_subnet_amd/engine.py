@@ -42,6 +42,7 @@ class HipEngine:
         self._h = h
         self.device = device
         self.scale = self.machines_scale = 0
+        self.verifier = None          # host-side pairing verifier (zkp_subnet_amd.verifier.Verifier)
         if window:
             self._chk(self._lib.kzg_set_window(self._h, window))
 
@@ -86,6 +87,13 @@ class HipEngine:
     def load_srs(self, g1_be96: bytes, scale: int, machines_scale: int) -> None:
         self._chk(self._lib.kzg_load_srs(self._h, g1_be96, len(g1_be96) // 96, scale, machines_scale))
         self.scale, self.machines_scale = scale, machines_scale
+        self.verifier = None
+
+    def set_verifier_key(self, tau_g2_be192: bytes, li_g1_be96: bytes) -> None:
+        """Verification key of a loaded SRS: [tau_x]_2 (uncompressed G2, 192 B) and [L_i(tau_y)]_1 per resident slice."""
+        from .verifier import Verifier
+
+        self.verifier = Verifier.from_points(tau_g2_be192, li_g1_be96)
 
     def gen_srs(self, tau_x: int, tau_y: int, scale: int, machines_scale: int,
                 workers: Optional[Sequence[int]] = None, factors: Optional[Sequence[int]] = None) -> None:
@@ -102,6 +110,16 @@ class HipEngine:
         self._chk(self._lib.kzg_gen_srs(self._h, (tau_x % R_MODULUS).to_bytes(32, "big"), s0, len(s0) // 32, scale,
                                         machines_scale))
         self.scale, self.machines_scale = scale, machines_scale
+        from .verifier import Verifier
+
+        self.verifier = Verifier.synthetic(tau_x % R_MODULUS, [int.from_bytes(s0[i:i + 32], "big")
+                                                               for i in range(0, len(s0), 32)])
+
+    def verify(self, i: int, proof48: bytes, alpha32: bytes, eval32: bytes, commitment48: bytes) -> bool:
+        """Pairing check of one opening against resident slice i (host-side; reference neurons/validator.py:77-86)."""
+        if self.verifier is None:
+            raise NotImplementedError("no verifier key: call set_verifier_key() after load_srs()")
+        return self.verifier.verify(i, proof48, alpha32, eval32, commitment48)
 
     def srs_read(self, first: int, count: int, window: int = 0) -> bytes:
         out = ctypes.create_string_buffer(96 * count)

@@ -1,0 +1,55 @@
+"""Host-side opening verifier (pairing check) -- binding of the kzg_vk_* entry points.  No GPU involved: this is what
+`Client.worker_verify` runs (reference neurons/validator.py:77-86)."""
+from __future__ import annotations
+
+import ctypes
+from typing import Sequence
+
+from . import _native
+from ._native import KzgError
+
+
+class Verifier:
+    def __init__(self, handle):
+        self._lib = _native.load()
+        self._h = handle
+
+    @classmethod
+    def synthetic(cls, tau_x: int, factors: Sequence[int]) -> "Verifier":
+        """Verifier key for a tau-derived SRS: [tau_x]_2 and [s0_k]_1 per resident slice (s0_k = L_i(tau_y))."""
+        lib = _native.load()
+        h = ctypes.c_void_p()
+        s0 = b"".join(int(f).to_bytes(32, "big") for f in factors)
+        rc = lib.kzg_vk_create_synthetic(int(tau_x).to_bytes(32, "big"), s0, len(s0) // 32, ctypes.byref(h))
+        if rc != 0:
+            raise KzgError(rc, "kzg_vk_create_synthetic failed")
+        return cls(h)
+
+    @classmethod
+    def from_points(cls, tau_g2_be192: bytes, li_g1_be96: bytes) -> "Verifier":
+        lib = _native.load()
+        h = ctypes.c_void_p()
+        rc = lib.kzg_vk_create(tau_g2_be192, li_g1_be96, len(li_g1_be96) // 96, ctypes.byref(h))
+        if rc != 0:
+            raise KzgError(rc, "kzg_vk_create failed: bad G2 / G1 key material")
+        return cls(h)
+
+    def verify(self, i: int, proof48: bytes, alpha32: bytes, eval32: bytes, commitment48: bytes) -> bool:
+        if len(proof48) != 48 or len(commitment48) != 48:
+            return False
+        ok = ctypes.c_int(0)
+        rc = self._lib.kzg_vk_verify(self._h, i, proof48, alpha32, eval32, commitment48, ctypes.byref(ok))
+        if rc != 0:
+            raise KzgError(rc, "kzg_vk_verify: bad argument (index or non-canonical scalar)")
+        return bool(ok.value)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.kzg_vk_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
