@@ -35,6 +35,7 @@ def _stale(target: str, deps) -> bool:
 
 def build(force: bool = False, extra_flags=()) -> str:
     hipcc = _hipcc()
+    extra_flags = tuple(extra_flags) + tuple(os.environ.get("KZG_EXTRA_HIPCC_FLAGS", "").split())
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     jobs = []
