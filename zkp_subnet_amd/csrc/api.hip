@@ -196,7 +196,7 @@ int msm_core(kzg_ctx* ctx, const uint32_t* scalars, int mont, uint64_t n, uint64
     HIPCHK(ctx, ctx->bufB.ensure(B * sizeof(g1_xyzz_t)));
     const size_t nfold = ((size_t)nchunks + MSM_FOLD_K - 1) / MSM_FOLD_K;  // ping-pong: level 0 | levels 1..
     HIPCHK(ctx, ctx->carries.ensure(((size_t)nchunks + nfold) * sizeof(g1_xyzz_t)));
-    HIPCHK(ctx, ctx->carry_key.ensure(((size_t)nchunks + nfold) * 4));
+    HIPCHK(ctx, ctx->carry_key.ensure((2 * (size_t)nchunks + nfold) * 4));
     {
         Span sp(ctx, KZG_T_DIGITS);
         HIPCHK(ctx, hipMemsetAsync(ctx->bufA.p, 0, B * sizeof(g1_xyzz_t), s));
@@ -212,9 +212,11 @@ int msm_core(kzg_ctx* ctx, const uint32_t* scalars, int mont, uint64_t n, uint64
     {
         Span sp(ctx, KZG_T_FIXUP);
         g1_xyzz_t* pt_a = ctx->carries.as<g1_xyzz_t>();
-        uint32_t* key_a = ctx->carry_key.as<uint32_t>();
+        uint32_t* key_raw = ctx->carry_key.as<uint32_t>();
+        uint32_t* key_a = key_raw + nchunks;          // keys after the singleton pre-pass
         g1_xyzz_t* pt_b = pt_a + nchunks;
         uint32_t* key_b = key_a + nchunks;
+        launch_msm_fold_singletons(s, ctx->bufA.as<g1_xyzz_t>(), pt_a, key_raw, nchunks, key_a);
         for (uint32_t cnt = nchunks; cnt;) {  // last level: one lane, nothing precedes it -> no output record
             launch_msm_fold(s, ctx->bufA.as<g1_xyzz_t>(), pt_a, key_a, cnt, pt_b, key_b);
             if (cnt <= MSM_FOLD_K) break;

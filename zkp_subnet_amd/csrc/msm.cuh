@@ -43,6 +43,9 @@ void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t*
 // a run that began in an earlier lane's range goes to (out_key, out_pt)[lane], runs beginning here are added
 // into their bucket.  Repeated until one lane covers everything: serial depth FOLD_K * log_FOLD_K(n).
 #define MSM_FOLD_K 8
+// pre-pass: runs of length one are added to their buckets in parallel; key_out = in_key with those blanked
+void launch_msm_fold_singletons(hipStream_t s, g1_xyzz_t* buckets, const g1_xyzz_t* in_pt, const uint32_t* in_key,
+                                uint32_t n, uint32_t* key_out);
 void launch_msm_fold(hipStream_t s, g1_xyzz_t* buckets, const g1_xyzz_t* in_pt, const uint32_t* in_key, uint32_t n_in,
                      g1_xyzz_t* out_pt, uint32_t* out_key);
 // level i: in = nodes of (i+1) points, component-major; out = nodes of (i+2) points

@@ -218,6 +218,28 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t* __res
     carry_key[t] = my_carry_key;
 }
 
+// Pre-pass of the fold: a carry whose key differs from both neighbours is a complete run of length one, so it can
+// be added to its bucket by its own lane -- all such additions are independent (one round of point additions
+// instead of an 8-deep serial loop per lane).  key_out = keys with the handled records blanked; the general fold
+// levels then see mostly empty slots for well-spread scalars and stay exact for clustered ones.
+__global__ void __launch_bounds__(256) k_msm_fold_singletons(g1_xyzz_t* __restrict__ buckets,
+                                                              const g1_xyzz_t* __restrict__ in_pt,
+                                                              const uint32_t* __restrict__ in_key, uint32_t n,
+                                                              uint32_t* __restrict__ key_out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t k = in_key[t];
+    const uint32_t kl = t ? in_key[t - 1] : NONE_KEY, kr = (t + 1 < n) ? in_key[t + 1] : NONE_KEY;
+    const bool single = k != NONE_KEY && k != kl && k != kr;
+    key_out[t] = single ? NONE_KEY : k;
+    if (!single) return;
+    g1_xyzz_t a, b, r;
+    load_xyzz(a, &buckets[k]);
+    load_xyzz(b, &in_pt[t]);
+    g1_add(r, a, b);
+    store_xyzz(&buckets[k], r);
+}
+
 // One fold level over (key, point) records sorted by key (NONE_KEY = empty slot; a run of equal keys is
 // contiguous).  Lane v folds records [v*K, (v+1)*K): a run continuing from the previous lane's range becomes this
 // lane's output record; a run that BEGINS in this range is added into its bucket (its beginner is the bucket's
@@ -850,6 +872,10 @@ void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t*
     if (!nchunks) return;
     k_msm_accumulate<<<nblk(nchunks, 256), 256, 0, s>>>(table, offsets, sorted, sh.nbuckets, (uint32_t)sh.chunk,
                                                         nchunks, buckets, carries, carry_key);
+}
+void launch_msm_fold_singletons(hipStream_t s, g1_xyzz_t* buckets, const g1_xyzz_t* in_pt, const uint32_t* in_key,
+                                uint32_t n, uint32_t* key_out) {
+    if (n) k_msm_fold_singletons<<<nblk(n, 256), 256, 0, s>>>(buckets, in_pt, in_key, n, key_out);
 }
 void launch_msm_fold(hipStream_t s, g1_xyzz_t* buckets, const g1_xyzz_t* in_pt, const uint32_t* in_key, uint32_t n_in,
                      g1_xyzz_t* out_pt, uint32_t* out_key) {
