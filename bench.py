@@ -68,7 +68,8 @@ def main():
     ap.add_argument("--workload", default="msm20", choices=["msm20", "kzg22"])
     ap.add_argument("--log-n", type=int, default=0, help="override log2(points per GPU) (debug)")
     ap.add_argument("--window", type=int, default=0)
-    ap.add_argument("--cpu-sample-log", type=int, default=17)
+    ap.add_argument("--cpu-sample-log", type=int, default=19)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 16): the box's CPU share for one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -171,6 +172,17 @@ def main():
             wl = f"degree-2^{lg} KZG commit+open per GPU (INTT + 2 MSM + quotient), evaluation-form input"
         per_launch_s = acc_ms / 1e3 / launches if acc_ms else float("nan")
         achieved = alg_bytes / per_launch_s / 1e9 if acc_ms else None
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the value is
+        # the one measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 FETCH correction)
+        # on this exact configuration and committed under profiles/; null for any other configuration.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            if (pmc["workload"], pmc["points_per_gpu"], pmc["window_bits"]) == (args.workload, n, eng.window):
+                traffic = pmc["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -181,10 +193,12 @@ def main():
                        (f"SRS-sharded x{world}, all_gather of 192 B partials over RCCL" if args.workload == "msm20"
                         else f"Pianist segments x{world}, no exchange")},
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel_ms": per_launch_s * 1e3 if acc_ms else None, "algorithmic_bytes": alg_bytes,
                          "frac_of_measured_copy_peak": (achieved / HBM_COPY_GBS) if achieved else None,
-                         "note": "integer-VALU-bound (12-limb Montgomery on v_mad_u64_u32), not HBM-bound; see DESIGN.md"},
+                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc, 2 x FETCH_SIZE + WRITE_SIZE)" if traffic else None,
+                         "note": "integer-VALU-bound (14 x 28-bit-limb Montgomery products on v_mad_u64_u32: ~3.7k mads "
+                                 "per mixed point addition), not HBM-bound; see DESIGN.md 3.3"},
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "setup_s": round(setup_s, 2),
         }
@@ -196,7 +210,7 @@ def main():
 
             oc.build()
             m = 1 << min(args.cpu_sample_log, lg)
-            cores = host_cores()
+            cores = args.cpu_threads or min(host_cores(), 16)
             srs = eng.srs_read(0, m)
             prep = oc.PreparedMsm(srs, scal[: 32 * m])
             tc = time.perf_counter()
@@ -209,9 +223,9 @@ def main():
             gpu_same = eng.msm(scal[: 32 * m], 0)
             out["cpu_baseline"] = {
                 "value": m / cpu_s, "unit": "points/s", "cores": cores, "kind": "port",
-                "sample": f"first 2^{m.bit_length() - 1} points/scalars of the same workload, one Pippenger MSM, "
-                          f"{cores} threads ({cpu_s:.2f} s wall); 1 thread on 2^{(m >> 3).bit_length() - 1}: "
-                          f"{(m >> 3) / cpu1_s:.0f} points/s",
+                "sample": f"first 2^{m.bit_length() - 1} points/scalars of the same workload, one Pippenger MSM split over "
+                          f"{cores} threads ({cpu_s:.2f} s wall, {host_cores()} host cores visible); 1 thread on "
+                          f"2^{(m >> 3).bit_length() - 1}: {(m >> 3) / cpu1_s:.0f} points/s",
                 "single_thread_points_per_s": (m >> 3) / cpu1_s,
                 "matches_gpu_bit_exact": cpu_res == gpu_same,
             }
