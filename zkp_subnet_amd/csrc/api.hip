@@ -142,8 +142,8 @@ int choose_window(uint64_t T) {
     // latency, the accumulate n*ceil(256/c) mixed additions of throughput
     if (lg <= 9) return 8;
     if (lg <= 12) return 10;
-    if (lg <= 15) return 12;
-    if (lg <= 17) return 14;
+    if (lg <= 14) return 12;
+    if (lg <= 15) return 14;
     if (lg <= 19) return 16;
     return 20;
 }
@@ -194,9 +194,8 @@ int msm_core(kzg_ctx* ctx, const uint32_t* scalars, int mont, uint64_t n, uint64
     HIPCHK(ctx, ctx->offsets.ensure((B + 1) * 4));
     HIPCHK(ctx, ctx->bufA.ensure(B * sizeof(g1_xyzz_t)));
     HIPCHK(ctx, ctx->bufB.ensure(B * sizeof(g1_xyzz_t)));
-    const size_t nfold = ((size_t)nchunks + MSM_FOLD_K - 1) / MSM_FOLD_K;  // ping-pong: level 0 | levels 1..
-    HIPCHK(ctx, ctx->carries.ensure(((size_t)nchunks + nfold) * sizeof(g1_xyzz_t)));
-    HIPCHK(ctx, ctx->carry_key.ensure((2 * (size_t)nchunks + nfold) * 4));
+    HIPCHK(ctx, ctx->carries.ensure((size_t)nchunks * sizeof(g1_xyzz_t)));
+    HIPCHK(ctx, ctx->carry_key.ensure((size_t)nchunks * 4));
     {
         Span sp(ctx, KZG_T_DIGITS);
         HIPCHK(ctx, hipMemsetAsync(ctx->bufA.p, 0, B * sizeof(g1_xyzz_t), s));
@@ -211,19 +210,19 @@ int msm_core(kzg_ctx* ctx, const uint32_t* scalars, int mont, uint64_t n, uint64
     }
     {
         Span sp(ctx, KZG_T_FIXUP);
-        g1_xyzz_t* pt_a = ctx->carries.as<g1_xyzz_t>();
-        uint32_t* key_raw = ctx->carry_key.as<uint32_t>();
-        uint32_t* key_a = key_raw + nchunks;          // keys after the singleton pre-pass
-        g1_xyzz_t* pt_b = pt_a + nchunks;
-        uint32_t* key_b = key_a + nchunks;
-        launch_msm_fold_singletons(s, ctx->bufA.as<g1_xyzz_t>(), pt_a, key_raw, nchunks, key_a);
-        for (uint32_t cnt = nchunks; cnt;) {  // last level: one lane, nothing precedes it -> no output record
-            launch_msm_fold(s, ctx->bufA.as<g1_xyzz_t>(), pt_a, key_a, cnt, pt_b, key_b);
-            if (cnt <= MSM_FOLD_K) break;
-            cnt = (cnt + MSM_FOLD_K - 1) / MSM_FOLD_K;
-            std::swap(pt_a, pt_b);
-            std::swap(key_a, key_b);
-        }
+        // longest run of carries decides how many tree steps are launched (one 4-byte read-back)
+        uint32_t* max_len_d = ctx->flags + 2;
+        HIPCHK(ctx, hipMemsetAsync(max_len_d, 0, 4, s));
+        launch_fold_maxlen(s, ctx->offsets.as<uint32_t>(), ctx->carry_key.as<uint32_t>(), (uint32_t)sh.chunk, nchunks,
+                           max_len_d);
+        uint32_t* max_len_h = reinterpret_cast<uint32_t*>(ctx->host_pin + 32);
+        HIPCHK(ctx, hipMemcpyAsync(max_len_h, max_len_d, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+        for (uint32_t d = 1; d < *max_len_h; d <<= 1)
+            launch_fold_step(s, ctx->offsets.as<uint32_t>(), ctx->carry_key.as<uint32_t>(), (uint32_t)sh.chunk, nchunks, d,
+                             ctx->carries.as<g1_xyzz_t>());
+        launch_fold_heads(s, ctx->offsets.as<uint32_t>(), ctx->carry_key.as<uint32_t>(), (uint32_t)sh.chunk, nchunks,
+                          ctx->carries.as<g1_xyzz_t>(), ctx->bufA.as<g1_xyzz_t>());
     }
     g1_xyzz_t* in = ctx->bufA.as<g1_xyzz_t>();
     g1_xyzz_t* out = ctx->bufB.as<g1_xyzz_t>();
@@ -332,8 +331,10 @@ int commit_open_dev(kzg_ctx* ctx, uint32_t i, const uint32_t* row_dev, uint64_t 
     if (out_c48) {
         rc = msm_core(ctx, coeffs, 1, T, offset, ctx->res.as<g1_xyzz_t>());
         if (rc) return rc;
-        Span sp(ctx, KZG_T_FINAL);
-        launch_g1_compress(s, ctx->res.as<g1_xyzz_t>(), small);
+        if (!out_p48) {  // commit only; with an opening the two points share one inversion below
+            Span sp(ctx, KZG_T_FINAL);
+            launch_g1_compress(s, ctx->res.as<g1_xyzz_t>(), small);
+        }
     }
     if (out_p48) {
         uint32_t* alpha_m = reinterpret_cast<uint32_t*>(small + 192);
@@ -353,7 +354,8 @@ int commit_open_dev(kzg_ctx* ctx, uint32_t i, const uint32_t* row_dev, uint64_t 
         rc = msm_core(ctx, ctx->qbuf.as<uint32_t>(), 0, T - 1, offset, ctx->res.as<g1_xyzz_t>() + 1);
         if (rc) return rc;
         Span sp(ctx, KZG_T_FINAL);
-        launch_g1_compress(s, ctx->res.as<g1_xyzz_t>() + 1, small + 64);
+        if (out_c48) launch_g1_compress_pair(s, ctx->res.as<g1_xyzz_t>(), ctx->res.as<g1_xyzz_t>() + 1, small, small + 64);
+        else launch_g1_compress(s, ctx->res.as<g1_xyzz_t>() + 1, small + 64);
     }
     HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, small, 192, hipMemcpyDeviceToHost, s));
     rc = finish(ctx);

@@ -9,7 +9,7 @@
 //   4. msm_accumulate    HOT: every lane sums a fixed-size chunk of the sorted entries with mixed XYZZ adds
 //                        (perfect load balance for any scalar distribution); bucket runs that span chunks
 //                        leave "carry" partial sums
-//   5. msm_fold          folds the carries into their buckets, MSM_FOLD_K-ary, log depth for ANY distribution
+//   5. fold_step/heads   folds the carries into their buckets: per-bucket binary tree, log depth for ANY distribution
 //   6. msm_tree_level    log2(B) pairwise-merge levels producing P = sum B_k and T_i = sum_{bit i of k} B_k
 //   7. msm_final         sum = P + sum_i 2^i T_i  (-> XYZZ, optionally affine + 48-byte compression)
 #pragma once
@@ -39,15 +39,14 @@ void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars,
 void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t* table, const uint32_t* offsets,
                            const uint32_t* sorted, g1_xyzz_t* buckets, g1_xyzz_t* carries, uint32_t* carry_key,
                            uint32_t nchunks);
-// one fold level: records (key, point) sorted by key, NONE_KEY = no record.  Each lane folds FOLD_K records;
-// a run that began in an earlier lane's range goes to (out_key, out_pt)[lane], runs beginning here are added
-// into their bucket.  Repeated until one lane covers everything: serial depth FOLD_K * log_FOLD_K(n).
-#define MSM_FOLD_K 8
-// pre-pass: runs of length one are added to their buckets in parallel; key_out = in_key with those blanked
-void launch_msm_fold_singletons(hipStream_t s, g1_xyzz_t* buckets, const g1_xyzz_t* in_pt, const uint32_t* in_key,
-                                uint32_t n, uint32_t* key_out);
-void launch_msm_fold(hipStream_t s, g1_xyzz_t* buckets, const g1_xyzz_t* in_pt, const uint32_t* in_key, uint32_t n_in,
-                     g1_xyzz_t* out_pt, uint32_t* out_key);
+// carries -> buckets: per-bucket binary tree over the carries (positions derived from the bucket offsets).
+// max_len: device word, maximum number of carries of one bucket (stays 0 when every run has <= 1 carry)
+void launch_fold_maxlen(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
+                        uint32_t nchunks, uint32_t* max_len);
+void launch_fold_step(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
+                      uint32_t nchunks, uint32_t d, g1_xyzz_t* carries);
+void launch_fold_heads(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
+                       uint32_t nchunks, const g1_xyzz_t* carries, g1_xyzz_t* buckets);
 // level i: in = nodes of (i+1) points, component-major; out = nodes of (i+2) points
 void launch_msm_tree_level(hipStream_t s, const g1_xyzz_t* in, g1_xyzz_t* out, uint32_t n_in_nodes, int level);
 // node = [P, T_0 .. T_{nbits-1}] ; out_xyzz = P + sum 2^i T_i
@@ -56,6 +55,8 @@ void launch_msm_final(hipStream_t s, const g1_xyzz_t* node, int nbits, g1_xyzz_t
 void launch_g1_sum(hipStream_t s, const g1_xyzz_t* in, uint32_t count, g1_xyzz_t* out_xyzz);
 // affine + ZCash compression of one point
 void launch_g1_compress(hipStream_t s, const g1_xyzz_t* in, uint8_t* out48);
+// two points, one shared inversion
+void launch_g1_compress_pair(hipStream_t s, const g1_xyzz_t* in0, const g1_xyzz_t* in1, uint8_t* out0, uint8_t* out1);
 // working XYZZ (224 B) <-> ABI partial-sum format (4 x 48 B packed canonical Montgomery residues, zeros = infinity)
 void launch_xyzz_pack(hipStream_t s, const g1_xyzz_t* in, uint32_t* out48w, uint32_t count);
 void launch_xyzz_unpack(hipStream_t s, const uint32_t* in48w, g1_xyzz_t* out, uint32_t count);

@@ -218,68 +218,54 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t* __res
     carry_key[t] = my_carry_key;
 }
 
-// Pre-pass of the fold: a carry whose key differs from both neighbours is a complete run of length one, so it can
-// be added to its bucket by its own lane -- all such additions are independent (one round of point additions
-// instead of an 8-deep serial loop per lane).  key_out = keys with the handled records blanked; the general fold
-// levels then see mostly empty slots for well-spread scalars and stay exact for clustered ones.
-__global__ void __launch_bounds__(256) k_msm_fold_singletons(g1_xyzz_t* __restrict__ buckets,
-                                                              const g1_xyzz_t* __restrict__ in_pt,
-                                                              const uint32_t* __restrict__ in_key, uint32_t n,
-                                                              uint32_t* __restrict__ key_out) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const uint32_t k = in_key[t];
-    const uint32_t kl = t ? in_key[t - 1] : NONE_KEY, kr = (t + 1 < n) ? in_key[t + 1] : NONE_KEY;
-    const bool single = k != NONE_KEY && k != kl && k != kr;
-    key_out[t] = single ? NONE_KEY : k;
-    if (!single) return;
-    g1_xyzz_t a, b, r;
-    load_xyzz(a, &buckets[k]);
-    load_xyzz(b, &in_pt[t]);
-    g1_add(r, a, b);
-    store_xyzz(&buckets[k], r);
+// ---- carries -> buckets.  The carries of bucket b sit at chunks t0+1 .. t1 with t0 = offsets[b] / K and
+// t1 = (offsets[b+1] - 1) / K, so carry t knows its position i = t - t0 - 1 inside its run of len = t1 - t0 carries
+// without any scan.  A per-run binary tree (step d: element i adds element i + d when i % 2d == 0) folds every run
+// in ceil(log2(len)) fully parallel steps, for ANY scalar distribution; the heads (i == 0) then go into the buckets.
+KZG_DEV bool carry_pos(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ carry_key, uint32_t chunk,
+                       uint32_t t, uint32_t& key, uint32_t& i, uint32_t& len) {
+    key = carry_key[t];
+    if (key == NONE_KEY) return false;
+    const uint32_t t0 = offsets[key] / chunk, t1 = (offsets[key + 1] - 1u) / chunk;
+    i = t - t0 - 1u;
+    len = t1 - t0;
+    return true;
 }
-
-// One fold level over (key, point) records sorted by key (NONE_KEY = empty slot; a run of equal keys is
-// contiguous).  Lane v folds records [v*K, (v+1)*K): a run continuing from the previous lane's range becomes this
-// lane's output record; a run that BEGINS in this range is added into its bucket (its beginner is the bucket's
-// only writer in this launch).  Works for any distribution: n records shrink to n/K per level.
-__global__ void __launch_bounds__(256) k_msm_fold(g1_xyzz_t* __restrict__ buckets, const g1_xyzz_t* __restrict__ in_pt,
-                                                   const uint32_t* __restrict__ in_key, uint32_t n_in,
-                                                   g1_xyzz_t* __restrict__ out_pt, uint32_t* __restrict__ out_key) {
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t lo = v * MSM_FOLD_K;
-    if (lo >= n_in) return;
-    const uint32_t hi = min(lo + MSM_FOLD_K, n_in);
-    const uint32_t prev = lo ? in_key[lo - 1] : NONE_KEY;
-    uint32_t cur = NONE_KEY, my_key = NONE_KEY;
-    bool cur_is_carry = false;
-    g1_xyzz_t acc, q, r;
-    g1_set_inf(acc);
-    for (uint32_t u = lo; u <= hi; u++) {
-        const uint32_t k = u < hi ? in_key[u] : NONE_KEY;
-        if (k != cur) {
-            if (cur != NONE_KEY) {  // close the finished run
-                if (cur_is_carry) {
-                    store_xyzz(&out_pt[v], acc);
-                    my_key = cur;
-                } else {
-                    load_xyzz(q, &buckets[cur]);
-                    g1_add(r, q, acc);
-                    store_xyzz(&buckets[cur], r);
-                }
-            }
-            cur = k;
-            cur_is_carry = (u == lo) && (k == prev);
-            g1_set_inf(acc);
-        }
-        if (k != NONE_KEY) {
-            load_xyzz(q, &in_pt[u]);
-            g1_add(r, acc, q);
-            acc = r;
-        }
-    }
-    out_key[v] = my_key;
+__global__ void __launch_bounds__(256) k_fold_maxlen(const uint32_t* __restrict__ offsets,
+                                                      const uint32_t* __restrict__ carry_key, uint32_t chunk,
+                                                      uint32_t nchunks, uint32_t* __restrict__ max_len) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    uint32_t key, i, len;
+    if (carry_pos(offsets, carry_key, chunk, t, key, i, len) && i == 0 && len > 1) atomicMax(max_len, len);
+}
+__global__ void __launch_bounds__(256) k_fold_step(const uint32_t* __restrict__ offsets,
+                                                    const uint32_t* __restrict__ carry_key, uint32_t chunk,
+                                                    uint32_t nchunks, uint32_t d, g1_xyzz_t* __restrict__ carries) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    uint32_t key, i, len;
+    if (!carry_pos(offsets, carry_key, chunk, t, key, i, len)) return;
+    if ((i & (2u * d - 1u)) || i + d >= len) return;
+    g1_xyzz_t a, b, r;
+    load_xyzz(a, &carries[t]);
+    load_xyzz(b, &carries[t + d]);
+    g1_add(r, a, b);
+    store_xyzz(&carries[t], r);
+}
+__global__ void __launch_bounds__(256) k_fold_heads(const uint32_t* __restrict__ offsets,
+                                                     const uint32_t* __restrict__ carry_key, uint32_t chunk,
+                                                     uint32_t nchunks, const g1_xyzz_t* __restrict__ carries,
+                                                     g1_xyzz_t* __restrict__ buckets) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    uint32_t key, i, len;
+    if (!carry_pos(offsets, carry_key, chunk, t, key, i, len) || i != 0) return;
+    g1_xyzz_t a, b, r;
+    load_xyzz(a, &buckets[key]);
+    load_xyzz(b, &carries[t]);
+    g1_add(r, a, b);
+    store_xyzz(&buckets[key], r);
 }
 
 // ------------------------------------------------------------------------------------------------ bucket tree
@@ -498,6 +484,31 @@ KZG_DEV void coop_dbl(CoopLds& sm, g1_xyzz_t* out, const g1_xyzz_t* p, bool acti
     __syncthreads();
 }
 
+// cooperative variants of the fold kernels (64 carries per workgroup) for the small-slice, latency-bound regime
+__global__ void __launch_bounds__(256) k_fold_step_coop(const uint32_t* __restrict__ offsets,
+                                                         const uint32_t* __restrict__ carry_key, uint32_t chunk,
+                                                         uint32_t nchunks, uint32_t d, g1_xyzz_t* __restrict__ carries) {
+    __shared__ CoopLds sm;
+    const uint32_t t = blockIdx.x * 64 + (threadIdx.x & 63);
+    uint32_t key = 0, i = 0, len = 0;
+    bool active = t < nchunks && carry_pos(offsets, carry_key, chunk, t, key, i, len);
+    active = active && !(i & (2u * d - 1u)) && i + d < len;
+    if (!__syncthreads_or(active)) return;
+    coop_add(sm, &carries[t], &carries[t], &carries[active ? t + d : t], active);
+}
+__global__ void __launch_bounds__(256) k_fold_heads_coop(const uint32_t* __restrict__ offsets,
+                                                          const uint32_t* __restrict__ carry_key, uint32_t chunk,
+                                                          uint32_t nchunks, const g1_xyzz_t* __restrict__ carries,
+                                                          g1_xyzz_t* __restrict__ buckets) {
+    __shared__ CoopLds sm;
+    const uint32_t t = blockIdx.x * 64 + (threadIdx.x & 63);
+    uint32_t key = 0, i = 0, len = 0;
+    const bool active = t < nchunks && carry_pos(offsets, carry_key, chunk, t, key, i, len) && i == 0;
+    if (!__syncthreads_or(active)) return;
+    g1_xyzz_t* dst = &buckets[active ? key : 0];
+    coop_add(sm, dst, dst, &carries[active ? t : 0], active);
+}
+
 // same merge as k_msm_tree_level, 64 operations per 256-thread workgroup, for the narrow (latency-bound) levels
 __global__ void __launch_bounds__(256) k_msm_tree_level_coop(const g1_xyzz_t* __restrict__ in,
                                                               g1_xyzz_t* __restrict__ out, uint32_t n_in, int level) {
@@ -584,6 +595,38 @@ __global__ void __launch_bounds__(64) k_g1_compress(const g1_xyzz_t* __restrict_
     g1_aff28 a;
     g1_to_aff(a, p);
     g1_compress(out48, a);
+}
+// two points, ONE inversion (Montgomery's trick): commit + open share the single-lane inversion latency
+__global__ void __launch_bounds__(64) k_g1_compress_pair(const g1_xyzz_t* __restrict__ in0,
+                                                          const g1_xyzz_t* __restrict__ in1,
+                                                          uint8_t* __restrict__ out0, uint8_t* __restrict__ out1) {
+    if (threadIdx.x != 0) return;
+    g1_xyzz_t p0, p1;
+    load_xyzz(p0, in0);
+    load_xyzz(p1, in1);
+    const bool i0 = g1_is_inf(p0), i1 = g1_is_inf(p1);
+    fp_t d0, d1, one, t, inv, w0, w1;
+    fp_one(one);
+    fp_mul(d0, p0.zz, p0.zzz);
+    fp_mul(d1, p1.zz, p1.zzz);
+    if (i0) d0 = one;
+    if (i1) d1 = one;
+    fp_mul(t, d0, d1);
+    fp_inv(inv, t);
+    fp_mul(w0, inv, d1);  // 1 / d0
+    fp_mul(w1, inv, d0);  // 1 / d1
+    g1_aff28 a0, a1;
+    fp_zero(a0.x); fp_zero(a0.y); fp_zero(a1.x); fp_zero(a1.y);
+    if (!i0) {
+        fp_mul(t, w0, p0.zzz); fp_mul(t, p0.x, t); fp_canon(a0.x, t);
+        fp_mul(t, w0, p0.zz); fp_mul(t, p0.y, t); fp_canon(a0.y, t);
+    }
+    if (!i1) {
+        fp_mul(t, w1, p1.zzz); fp_mul(t, p1.x, t); fp_canon(a1.x, t);
+        fp_mul(t, w1, p1.zz); fp_mul(t, p1.y, t); fp_canon(a1.y, t);
+    }
+    g1_compress(out0, a0);
+    g1_compress(out1, a1);
 }
 // XYZZ working form <-> the 192-byte partial-sum format of the C-ABI (4 x 12 u32: canonical Montgomery residues)
 __global__ void __launch_bounds__(64) k_xyzz_pack(const g1_xyzz_t* __restrict__ in, uint32_t* __restrict__ out48w,
@@ -873,15 +916,23 @@ void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t*
     k_msm_accumulate<<<nblk(nchunks, 256), 256, 0, s>>>(table, offsets, sorted, sh.nbuckets, (uint32_t)sh.chunk,
                                                         nchunks, buckets, carries, carry_key);
 }
-void launch_msm_fold_singletons(hipStream_t s, g1_xyzz_t* buckets, const g1_xyzz_t* in_pt, const uint32_t* in_key,
-                                uint32_t n, uint32_t* key_out) {
-    if (n) k_msm_fold_singletons<<<nblk(n, 256), 256, 0, s>>>(buckets, in_pt, in_key, n, key_out);
+void launch_fold_maxlen(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
+                        uint32_t nchunks, uint32_t* max_len) {
+    if (nchunks) k_fold_maxlen<<<nblk(nchunks, 256), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, max_len);
 }
-void launch_msm_fold(hipStream_t s, g1_xyzz_t* buckets, const g1_xyzz_t* in_pt, const uint32_t* in_key, uint32_t n_in,
-                     g1_xyzz_t* out_pt, uint32_t* out_key) {
-    if (!n_in) return;
-    k_msm_fold<<<nblk((n_in + MSM_FOLD_K - 1) / MSM_FOLD_K, 256), 256, 0, s>>>(buckets, in_pt, in_key, n_in, out_pt,
-                                                                               out_key);
+void launch_fold_step(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
+                      uint32_t nchunks, uint32_t d, g1_xyzz_t* carries) {
+    if (!nchunks) return;
+    if (nchunks > 131072) k_fold_step<<<nblk(nchunks, 256), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, d, carries);
+    else k_fold_step_coop<<<nblk(nchunks, 64), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, d, carries);
+}
+void launch_fold_heads(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
+                       uint32_t nchunks, const g1_xyzz_t* carries, g1_xyzz_t* buckets) {
+    if (!nchunks) return;
+    if (nchunks > 131072)
+        k_fold_heads<<<nblk(nchunks, 256), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, carries, buckets);
+    else
+        k_fold_heads_coop<<<nblk(nchunks, 64), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, carries, buckets);
 }
 void launch_msm_tree_level(hipStream_t s, const g1_xyzz_t* in, g1_xyzz_t* out, uint32_t n_in_nodes, int level) {
     uint32_t ops = (n_in_nodes >> 1) * (uint32_t)(level + 2);
@@ -897,6 +948,9 @@ void launch_g1_sum(hipStream_t s, const g1_xyzz_t* in, uint32_t count, g1_xyzz_t
 }
 void launch_g1_compress(hipStream_t s, const g1_xyzz_t* in, uint8_t* out48) {
     k_g1_compress<<<1, 64, 0, s>>>(in, out48);
+}
+void launch_g1_compress_pair(hipStream_t s, const g1_xyzz_t* in0, const g1_xyzz_t* in1, uint8_t* out0, uint8_t* out1) {
+    k_g1_compress_pair<<<1, 64, 0, s>>>(in0, in1, out0, out1);
 }
 void launch_xyzz_pack(hipStream_t s, const g1_xyzz_t* in, uint32_t* out48w, uint32_t count) {
     if (count) k_xyzz_pack<<<nblk(count, 64), 64, 0, s>>>(in, out48w, count);
