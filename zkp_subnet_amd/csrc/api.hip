@@ -142,8 +142,7 @@ int choose_window(uint64_t T) {
     // latency, the accumulate n*ceil(256/c) mixed additions of throughput
     if (lg <= 9) return 8;
     if (lg <= 12) return 10;
-    if (lg <= 14) return 12;
-    if (lg <= 15) return 14;
+    if (lg <= 13) return 12;
     if (lg <= 19) return 16;
     return 20;
 }

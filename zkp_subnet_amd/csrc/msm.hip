@@ -923,13 +923,13 @@ void launch_fold_maxlen(hipStream_t s, const uint32_t* offsets, const uint32_t* 
 void launch_fold_step(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
                       uint32_t nchunks, uint32_t d, g1_xyzz_t* carries) {
     if (!nchunks) return;
-    if (nchunks > 131072) k_fold_step<<<nblk(nchunks, 256), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, d, carries);
+    if (nchunks > 32768) k_fold_step<<<nblk(nchunks, 256), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, d, carries);
     else k_fold_step_coop<<<nblk(nchunks, 64), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, d, carries);
 }
 void launch_fold_heads(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
                        uint32_t nchunks, const g1_xyzz_t* carries, g1_xyzz_t* buckets) {
     if (!nchunks) return;
-    if (nchunks > 131072)
+    if (nchunks > 32768)
         k_fold_heads<<<nblk(nchunks, 256), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, carries, buckets);
     else
         k_fold_heads_coop<<<nblk(nchunks, 64), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, carries, buckets);
