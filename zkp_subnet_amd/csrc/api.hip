@@ -340,7 +340,7 @@ int commit_open_dev(kzg_ctx* ctx, uint32_t i, const uint32_t* row_dev, uint64_t 
         uint32_t* y_m = reinterpret_cast<uint32_t*>(small + 256);
         HIPCHK(ctx, hipMemcpyAsync(small + 320, alpha_be32, 32, hipMemcpyHostToDevice, s));
         launch_fr_from_be(s, small + 320, alpha_m, 1, 1, ctx->flags);
-        const uint64_t nchunks = (T + 63) / 64;
+        const uint64_t nchunks = (T + 3) / 4;
         HIPCHK(ctx, ctx->hbuf.ensure(nchunks * 32));
         HIPCHK(ctx, ctx->hnext.ensure(nchunks * 32));
         HIPCHK(ctx, ctx->qbuf.ensure(T * 32));
@@ -759,7 +759,7 @@ int kzg_eval(kzg_ctx* ctx, const uint8_t* coeffs_be32, uint64_t n, const uint8_t
     if (rc) return rc;
     HIPCHK(ctx, ctx->coeffA.ensure(n * 32));
     HIPCHK(ctx, ctx->small.ensure(1024));
-    const uint64_t nchunks = (n + 63) / 64;
+    const uint64_t nchunks = (n + 3) / 4;
     HIPCHK(ctx, ctx->hbuf.ensure(nchunks * 32));
     HIPCHK(ctx, ctx->hnext.ensure(nchunks * 32));
     rc = upload_fr(ctx, coeffs_be32, n, ctx->coeffA.as<uint32_t>(), 1);

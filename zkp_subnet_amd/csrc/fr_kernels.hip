@@ -171,15 +171,22 @@ __global__ void __launch_bounds__(256) k_fr_scale(uint32_t* __restrict__ data, u
 }
 
 // ------------------------------------------------------------------------------------------------ eval + quotient
-#define POLY_CHUNK 64
+// Chunk length L = 2^lchunk coefficients per lane: 64 for large polynomials (throughput), down to 4 for small rows
+// where the chunk loops are pure latency (a 2^12 row: 64-long serial Horner loops cost 0.2 ms, 8-long ones 0.03 ms).
+static inline int poly_lchunk(uint64_t n) {
+    int l = 2;
+    while (l < 6 && (n >> (l + 1)) >= 16384) l++;
+    return l;
+}
 // h[t] = sum_k f[t*L + k] alpha^k
-__global__ void __launch_bounds__(256) k_poly_chunk_eval(const uint32_t* __restrict__ f, uint64_t n,
+__global__ void __launch_bounds__(256) k_poly_chunk_eval(const uint32_t* __restrict__ f, uint64_t n, int lchunk,
                                                           const uint32_t* __restrict__ alpha_mont,
                                                           uint32_t* __restrict__ h) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t lo = t * POLY_CHUNK;
+    const uint64_t L = (uint64_t)1 << lchunk;
+    uint64_t lo = t * L;
     if (lo >= n) return;
-    uint64_t hi = lo + POLY_CHUNK < n ? lo + POLY_CHUNK : n;
+    uint64_t hi = lo + L < n ? lo + L : n;
     fr_t a, s, c;
     fr_load(a, alpha_mont);
     f_zero(s);
@@ -193,7 +200,7 @@ __global__ void __launch_bounds__(256) k_poly_chunk_eval(const uint32_t* __restr
 // Suffix recurrence over chunks, H_t = h_t + beta H_{t+1}, beta = alpha^L: one 1024-lane block; lane v serially
 // folds m consecutive chunks, then a Hillis-Steele suffix scan whose multiplier (beta^m)^(2^step) is uniform.
 // Writes hnext[t] = H_{t+1} and y = H_0 = f(alpha).
-__global__ void __launch_bounds__(1024) k_poly_chunk_scan(const uint32_t* __restrict__ h, uint64_t nchunks,
+__global__ void __launch_bounds__(1024) k_poly_chunk_scan(const uint32_t* __restrict__ h, uint64_t nchunks, int lchunk,
                                                            const uint32_t* __restrict__ alpha_mont,
                                                            uint32_t* __restrict__ hnext, uint32_t* __restrict__ y_mont) {
     __shared__ uint4 sm[1024 * 2];
@@ -203,7 +210,7 @@ __global__ void __launch_bounds__(1024) k_poly_chunk_scan(const uint32_t* __rest
     const uint64_t hi = lo + m < nchunks ? lo + m : nchunks;
     fr_t beta, g, c, mult;
     fr_load(beta, alpha_mont);
-    for (int i = 0; i < 6; i++) f_mul(beta, beta, beta);  // alpha^64
+    for (int i = 0; i < lchunk; i++) f_mul(beta, beta, beta);  // alpha^L
     f_zero(g);
     for (uint64_t u = hi; u-- > lo && lo < nchunks;) {
         fr_load(c, h + 8 * u);
@@ -245,14 +252,15 @@ __global__ void __launch_bounds__(1024) k_poly_chunk_scan(const uint32_t* __rest
     if (v == 0) fr_store(y_mont, s);
 }
 // q[j-1] = sum_{k>=j} f_k alpha^(k-j), written canonical (ready to be MSM scalars); q has n-1 entries
-__global__ void __launch_bounds__(256) k_poly_quotient(const uint32_t* __restrict__ f, uint64_t n,
+__global__ void __launch_bounds__(256) k_poly_quotient(const uint32_t* __restrict__ f, uint64_t n, int lchunk,
                                                         const uint32_t* __restrict__ alpha_mont,
                                                         const uint32_t* __restrict__ hnext,
                                                         uint32_t* __restrict__ q_canon) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t lo = t * POLY_CHUNK;
+    const uint64_t L = (uint64_t)1 << lchunk;
+    uint64_t lo = t * L;
     if (lo >= n) return;
-    uint64_t hi = lo + POLY_CHUNK < n ? lo + POLY_CHUNK : n;
+    uint64_t hi = lo + L < n ? lo + L : n;
     fr_t a, s, c, o;
     fr_load(a, alpha_mont);
     fr_load(s, hnext + 8 * t);
@@ -297,9 +305,10 @@ void launch_fr_ntt(hipStream_t s, const uint32_t* in, uint32_t* out, int log_n, 
 void launch_poly_open(hipStream_t s, const uint32_t* f_mont, uint64_t n, const uint32_t* alpha_mont, uint32_t* h,
                       uint32_t* hnext, uint32_t* y_mont, uint32_t* q_canon_or_null) {
     if (!n) return;
-    const uint64_t nchunks = (n + POLY_CHUNK - 1) / POLY_CHUNK;
-    k_poly_chunk_eval<<<nblk(nchunks, 256), 256, 0, s>>>(f_mont, n, alpha_mont, h);
-    k_poly_chunk_scan<<<1, 1024, 0, s>>>(h, nchunks, alpha_mont, hnext, y_mont);
+    const int lchunk = poly_lchunk(n);
+    const uint64_t nchunks = (n + ((uint64_t)1 << lchunk) - 1) >> lchunk;
+    k_poly_chunk_eval<<<nblk(nchunks, 256), 256, 0, s>>>(f_mont, n, lchunk, alpha_mont, h);
+    k_poly_chunk_scan<<<1, 1024, 0, s>>>(h, nchunks, lchunk, alpha_mont, hnext, y_mont);
     if (q_canon_or_null)
-        k_poly_quotient<<<nblk(nchunks, 256), 256, 0, s>>>(f_mont, n, alpha_mont, hnext, q_canon_or_null);
+        k_poly_quotient<<<nblk(nchunks, 256), 256, 0, s>>>(f_mont, n, lchunk, alpha_mont, hnext, q_canon_or_null);
 }
