@@ -193,6 +193,19 @@ def test_msm_adversarial_scalar_distributions(hip, dist):
     assert got == oc.g1_mul_gen(o.poly_eval(sc, tx).to_bytes(32, "big"))
 
 
+@pytest.mark.parametrize("lg,window", [(8, 0), (10, 6), (12, 14), (16, 0)])
+def test_msm_long_carry_runs_small_and_mid_sizes(hip, lg, window):
+    """All-equal and two-valued scalars at sizes where the carry fold takes its cooperative (<= 32768 chunks) and
+    its plain path, with several tree steps per bucket."""
+    n = 1 << lg
+    eng = hip(window)
+    tx = 0xABCDE + lg
+    eng.gen_srs(tx, 1, lg, 0)
+    for sc in ([0x0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F0F % o.R] * n,
+               [7 if i % 3 else o.R - 7 for i in range(n)]):
+        assert eng.msm(o.fr_to_be32(sc), 0) == oc.g1_mul_gen(o.poly_eval(sc, tx).to_bytes(32, "big"))
+
+
 def test_msm_2_20_full_size_trapdoor_and_linearity(hip):
     """BASELINE.json configs[1]: 2^20-point MSM, random scalars, cached SRS.  Bit-exact against [f(tau)]G, which the
     oracle computes without any MSM; plus MSM(s) + MSM(t) == MSM(s + t) through the partial-sum ABI."""

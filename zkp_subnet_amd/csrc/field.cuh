@@ -1,6 +1,7 @@
-// Montgomery prime fields over 32-bit limbs: Fp (BLS12-381 base field, 12 limbs, R = 2^384) and
-// Fr (scalar field, 8 limbs, R = 2^256).  All values are kept fully reduced in [0, m) so equality is a
-// limb compare.  Constants were re-derived in oracle/bls12_381.py.
+// Montgomery prime fields over SATURATED 32-bit limbs, values fully reduced in [0, m): Fr (scalar field, 8 limbs,
+// R = 2^256) for the NTT / opening kernels, and Fp (12 limbs, R = 2^384) as the reference implementation for the
+// unit tests and the packed HBM format.  The MSM's working Fp is the unsaturated 14 x 28-bit form of fp28.cuh.
+// Constants were re-derived in oracle/bls12_381.py.
 #pragma once
 #include "bigint.cuh"
 
@@ -347,17 +348,5 @@ KZG_DEV void f_from_mont(field_t<P>& r, const field_t<P>& a) {
     for (int i = 0; i < P::N; i++) one.l[i] = i == 0 ? 1u : 0u;
     f_mul(r, a, one);
 }
-// r = a^e for a little-endian limb exponent known at compile time through P2::exp(i)
-template <class P, class EXP>
-KZG_DEV void f_pow_const(field_t<P>& r, const field_t<P>& a) {
-    field_t<P> acc;
-    f_one(acc);
-    for (int i = EXP::BITS - 1; i >= 0; i--) {
-        f_sqr(acc, acc);
-        if ((EXP::limb(i >> 5) >> (i & 31)) & 1u) f_mul(acc, acc, a);
-    }
-    r = acc;
-}
-
 typedef field_t<FpParams> fp32_t;  // saturated 12 x 32-bit Fp: reference implementation for tests + inversion helper
 typedef field_t<FrParams> fr_t;
