@@ -87,6 +87,8 @@ int kzg_vk_create(const uint8_t tau_g2_be192[192], const uint8_t* li_g1_be96, ui
 /* synthetic setup with known trapdoor (same tau / s0 as kzg_gen_srs): tests and benches */
 int kzg_vk_create_synthetic(const uint8_t tau_be32[32], const uint8_t* s0_be32, uint32_t n_slices, kzg_vk** out);
 void kzg_vk_destroy(kzg_vk* vk);
+/* serialise: 192 B [tau_x]_2 + 96 B per slice (a `<setup>.vk` file); returns the slice count or a negative status */
+int kzg_vk_export(const kzg_vk* vk, uint8_t* out, uint64_t out_len);
 int kzg_vk_verify(const kzg_vk* vk, uint32_t i, const uint8_t proof48[48], const uint8_t alpha_be32[32],
                   const uint8_t eval_be32[32], const uint8_t commitment48[48], int* out_valid);
 /* test hook: final_exp(miller(P, Q)) as 12 x 48 B in tower order (Fp12 = Fp6[w], Fp6 = Fp2[v], Fp2 = Fp[u]) */

@@ -31,6 +31,10 @@ __global__ void __launch_bounds__(256) k(uint64_t* out, uint32_t seed) {
             if (OP == 10) { uint32_t x = (uint32_t)acc[i]; asm volatile("v_mad_i32_i24 %0, %0, %1, %0" : "+v"(x) : "v"(b)); acc[i] = x; }
             if (OP == 11) { uint32_t x = (uint32_t)acc[i]; asm volatile("v_dot4_u32_u8 %0, %0, %1, %0" : "+v"(x) : "v"(b)); acc[i] = x; }
             if (OP == 12) { uint32_t x = (uint32_t)acc[i]; asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(b) : ); acc[i] = x; }
+            if (OP == 15) { uint32_t x = (uint32_t)acc[i]; asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(x) : "v"(b) : "s10", "s11"); acc[i] = x; }
+            if (OP == 16) { uint32_t x = (uint32_t)acc[i]; asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(b + i)); acc[i] += x; }
+            if (OP == 17) { uint32_t x = (uint32_t)acc[i]; asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(b)); acc[i] = x; }
+            if (OP == 18) { asm volatile("v_lshrrev_b64 %0, 28, %0" : "+v"(acc[i])); }
             if (OP == 13) { uint32_t x = (uint32_t)acc[i]; asm volatile("v_alignbit_b32 %0, %0, %1, 1" : "+v"(x) : "v"(b)); acc[i] = x; }
             if (OP == 14) { uint32_t x = (uint32_t)acc[i]; asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc" : "+v"(acc[i]), "+v"(x) : "v"(a), "v"(b), "v"(x) : "vcc"); }
         }
@@ -67,6 +71,7 @@ int main() {
     run<3>("v_mad_u32_u24", d_out); run<4>("v_mul_hi_u32_u24", d_out); run<10>("v_mad_i32_i24", d_out);
     run<5>("v_fma_f64", d_out); run<6>("v_add_u32", d_out); run<7>("v_lshl_add_u64", d_out);
     run<8>("v_addc_co_u32 chain", d_out); run<9>("add_co+addc (sgpr)", d_out); run<11>("v_dot4_u32_u8", d_out);
-    run<12>("v_cndmask_b32", d_out); run<13>("v_alignbit_b32", d_out);
+    run<12>("v_cndmask_b32 vcc", d_out); run<15>("v_cndmask_b32 sgpr", d_out); run<16>("v_mov_b32(+add)", d_out);
+    run<17>("v_and_b32", d_out); run<18>("v_lshrrev_b64", d_out); run<13>("v_alignbit_b32", d_out);
     return 0;
 }

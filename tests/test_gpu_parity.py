@@ -387,3 +387,31 @@ def test_client_and_miner_on_hip_engine(hip, fr_kat):
     assert reward(miner.client, ch, responses[0], 1, 0.0) == 0.0
     assert responses[1].eval == ch.evals[1]
     miner.stop()
+
+
+def test_setup_cli_file_roundtrip_through_client(hip, tmp_path, fr_kat):
+    """`setup` writes the SRS + verifier key files on the GPU; a fresh Client loads them (the reference's
+    tests/conftest.py:50-65 flow) and commit / open / verify agree with a Client that generated the same SRS in memory."""
+    from zkp_subnet_amd import setup_cli
+    from zkp_subnet_amd.client import Client
+
+    path = str(tmp_path / "test_setup.uncompressed")
+    assert setup_cli.main(["setup", "--setup-path", path, "--precompute-path", path + ".pre", "--scale", "6",
+                           "--machines-scale", "2", "--generate-setup", "--generate-precompute", "--overwrite",
+                           "--seed", "42"]) == 0
+    assert os.path.getsize(path) == 64 * 96 and os.path.getsize(path + ".vk") == 192 + 4 * 96
+    from_file = Client(setup_path=path, precompute_path=path + ".pre")
+    from_file.start(scale=6, machines_scale=2)
+    in_memory = Client(seed=42)
+    in_memory.start(scale=6, machines_scale=2)
+    for i in (0, 3):
+        with from_file.worker_commit_and_open(i, fr_kat["poly"], fr_kat["point"]) as a, \
+                in_memory.worker_commit_and_open(i, fr_kat["poly"], fr_kat["point"]) as b:
+            assert a.status_code == 200 and a.json() == b.json()
+            body = a.json()
+        with from_file.worker_verify(i, body["proof"], fr_kat["point"], body["eval"], body["commitment"]) as r:
+            assert r.json()["valid"] is True
+        with from_file.worker_verify((i + 1) % 4, body["proof"], fr_kat["point"], body["eval"], body["commitment"]) as r:
+            assert r.json()["valid"] is False
+    from_file.stop()
+    in_memory.stop()

@@ -107,6 +107,17 @@ def test_verify_agrees_with_python_pairing_and_trapdoor():
     assert not vk.verify(0, b"\x00" * 48, args[1], args[2], args[3])          # not a compressed point
 
 
+def test_vk_export_roundtrip():
+    rnd = random.Random(8)
+    tx, lis = rnd.randrange(1, o.R), [rnd.randrange(1, o.R) for _ in range(3)]
+    vk = Verifier.synthetic(tx, lis)
+    blob = vk.export(3)
+    assert blob[:192] == pr.g2_to_be192(pr.g2_mul(pr.G2, tx))
+    assert blob[192:] == b"".join(o.g1_to_be96(o.g1_table().mul(li)) for li in lis)
+    vk2 = Verifier.from_points(blob[:192], blob[192:])
+    assert vk2.export(3) == blob
+
+
 def test_bad_key_material_is_refused():
     from zkp_subnet_amd import KzgError
 

@@ -504,6 +504,24 @@ int kzg_vk_create_synthetic(const uint8_t tau_be32[32], const uint8_t* s0_be32, 
 }
 void kzg_vk_destroy(kzg_vk* vk) { delete vk; }
 
+static void g2_to_be192(uint8_t* b, const G2A& p) {
+    if (p.inf) { memset(b, 0, 192); return; }
+    fp_to_be48(b, p.x.c1); fp_to_be48(b + 48, p.x.c0); fp_to_be48(b + 96, p.y.c1); fp_to_be48(b + 144, p.y.c0);
+}
+/* serialise a verifier key: 192 B [tau_x]_2 then 96 B per slice (the layout of a `<setup>.vk` file) */
+int kzg_vk_export(const kzg_vk* vk, uint8_t* out, uint64_t out_len) {
+    if (!vk || !out) return KZG_E_ARG;
+    const uint64_t need = 192 + 96 * (uint64_t)vk->k.li.size();
+    if (out_len < need) return KZG_E_ARG;
+    g2_to_be192(out, vk->k.tau_g2);
+    for (size_t i = 0; i < vk->k.li.size(); i++) {
+        uint8_t* b = out + 192 + 96 * i;
+        if (vk->k.li[i].inf) memset(b, 0, 96);
+        else { fp_to_be48(b, vk->k.li[i].x); fp_to_be48(b + 48, vk->k.li[i].y); }
+    }
+    return (int)vk->k.li.size();
+}
+
 int kzg_vk_verify(const kzg_vk* vk, uint32_t i, const uint8_t proof48[48], const uint8_t alpha_be32[32],
                   const uint8_t eval_be32[32], const uint8_t commitment48[48], int* out_valid) {
     if (!vk || !proof48 || !alpha_be32 || !eval_be32 || !commitment48 || !out_valid) return KZG_E_ARG;

@@ -1,0 +1,65 @@
+"""`python -m zkp_subnet_amd.setup_cli setup ...` -- the analogue of the reference's
+`fourier setup --setup-path P --precompute-path Q --scale S --machines-scale M --generate-setup
+--generate-precompute --overwrite` (reference tests/conftest.py:50-65, Makefile:30-48).
+
+Generates a tau-derived SRS **on the GPU** and writes
+  <setup-path>      2^scale affine G1 points, x||y, 2 x 48 B big-endian each (worker slice i at points [i*T, (i+1)*T))
+  <setup-path>.vk   192 B [tau_x]_2 (uncompressed G2, x.c1||x.c0||y.c1||y.c0) + 96 B [L_i(tau_y)]_1 per worker
+which is what `Client(setup_path=...)` loads.  The window tables the reference keeps in --precompute-path are rebuilt on
+the GPU at Client.start(); --precompute-path is accepted for command-line compatibility and only receives a small
+note.  The trapdoor comes from --seed (tests / staging) or from os.urandom, and is discarded after use.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+from .client import derive_taus
+from .engine import HipEngine, lagrange_factor
+from .verifier import Verifier
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="zkp_subnet_amd.setup_cli")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    sp = sub.add_parser("setup")
+    sp.add_argument("--setup-path", required=True)
+    sp.add_argument("--precompute-path", default="")
+    sp.add_argument("--scale", type=int, default=18)
+    sp.add_argument("--machines-scale", type=int, default=8)
+    sp.add_argument("--generate-setup", action="store_true")
+    sp.add_argument("--generate-precompute", action="store_true")
+    sp.add_argument("--overwrite", action="store_true")
+    sp.add_argument("--seed", type=int, default=None)
+    sp.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    if not a.generate_setup:
+        print("nothing to do (pass --generate-setup)", file=sys.stderr)
+        return 0
+    if os.path.exists(a.setup_path) and not a.overwrite:
+        print(f"{a.setup_path} exists (use --overwrite)", file=sys.stderr)
+        return 1
+    seed = a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "big")
+    tau_x, tau_y = derive_taus(seed)
+    m = 1 << a.machines_scale
+    T = 1 << (a.scale - a.machines_scale)
+    eng = HipEngine(a.device)
+    eng.gen_srs(tau_x, tau_y, a.scale, a.machines_scale)
+    with open(a.setup_path, "wb") as f:
+        step = max(1, (1 << 20) // T)
+        for i in range(0, m, step):
+            f.write(eng.srs_read(i * T, min(step, m - i) * T))
+    vk = Verifier.synthetic(tau_x, [lagrange_factor(i, a.machines_scale, tau_y) for i in range(m)])
+    with open(a.setup_path + ".vk", "wb") as f:
+        f.write(vk.export(m))
+    if a.precompute_path and a.generate_precompute:
+        with open(a.precompute_path, "w") as f:
+            f.write(f"window tables are rebuilt on the GPU at Client.start(); window bits = {eng.window}\n")
+    eng.close()
+    print(f"wrote {a.setup_path} ({m * T} points, {m} worker slices of {T}) and {a.setup_path}.vk")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -34,6 +34,14 @@ class Verifier:
             raise KzgError(rc, "kzg_vk_create failed: bad G2 / G1 key material")
         return cls(h)
 
+    def export(self, n_slices: int) -> bytes:
+        """192 B [tau_x]_2 followed by 96 B [L_i(tau_y)]_1 per slice: the contents of a `<setup>.vk` file."""
+        out = ctypes.create_string_buffer(192 + 96 * n_slices)
+        rc = self._lib.kzg_vk_export(self._h, out, len(out))
+        if rc < 0:
+            raise KzgError(rc, "kzg_vk_export failed")
+        return out.raw[: 192 + 96 * rc]
+
     def verify(self, i: int, proof48: bytes, alpha32: bytes, eval32: bytes, commitment48: bytes) -> bool:
         if len(proof48) != 48 or len(commitment48) != 48:
             return False
