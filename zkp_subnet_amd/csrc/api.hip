@@ -144,7 +144,8 @@ int choose_window(uint64_t T) {
     if (lg <= 12) return 10;
     if (lg <= 13) return 12;
     if (lg <= 19) return 16;
-    return 20;
+    if (lg <= 22) return 20;
+    return 22;
 }
 // nwin = ceil(256/c) windows of width base or base+1 (256 = nwin*base + extra): the widest is <= c bits
 void set_window(kzg_ctx* ctx, int c) {
@@ -159,10 +160,13 @@ void set_window(kzg_ctx* ctx, int c) {
     ctx->c = base + (extra ? 1 : 0);
     ctx->nbuckets = 1u << (ctx->c - 1);
 }
+// sorted entries per accumulate lane: the grid is a whole number of "rounds" of 131072 lanes (2 waves per SIMD on
+// 256 CUs) so that the last round is not a partially filled tail; chunks stay <= 512 entries
 int pick_chunk(uint64_t entries) {
-    uint64_t k = (entries + 131071) / 131072;  // ~2 waves per SIMD on 256 CUs
+    const uint64_t lanes = 131072;
+    const uint64_t rounds = (entries + lanes * 512 - 1) / (lanes * 512);
+    uint64_t k = (entries + lanes * rounds - 1) / (lanes * (rounds ? rounds : 1));
     if (k < 8) k = 8;
-    if (k > 512) k = 512;
     return (int)k;
 }
 int ilog2_exact(uint64_t n) {
