@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(256) k_test_g1(int op, const uint8_t* a_be, co
     else if (op == 3) { g1_dbl(t, pa); g1_dbl(r, t); }
     else {  // long dependent chain: ((a + b) + b + ... ) exercising the class invariants across many mixed adds
         r = pa;
-        for (int k = 0; k < 40; k++) g1_madd_checked(r, (k & 1) ? a : b);
+        for (int k = 0; k < 40; k++) g1_madd_checked<true>(r, (k & 1) ? a : b);  // the inlined-product variant
     }
     g1_to_aff(o, r);
     fp_to_be48(out_be + 96 * j, o.x);

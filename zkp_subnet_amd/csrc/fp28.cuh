@@ -211,8 +211,9 @@ KZG_DEV fp_ret fp_vec(const fp_t& r) {
     return o;
 }
 #ifndef KZG_FP_MUL_INLINE
-// Real function calls (s_swappc): one copy of the product / square per translation unit keeps a point addition's
-// code (10 products) inside the instruction cache; vector-typed arguments stay in VGPRs across the call.
+// Real function calls (s_swappc) for everything except the hot mixed addition (which inlines fp_mul_inline, see
+// g1.cuh fpm<>): one copy of the product / square per translation unit keeps the many point formulas of the tail
+// kernels small; vector-typed arguments stay in VGPRs across the call.
 static __device__ __noinline__ fp_ret fp_mul_raw(u32x4 a0, u32x4 a1, u32x4 a2, u32x2 a3, u32x4 b0, u32x4 b1, u32x4 b2,
                                                   u32x2 b3) {
     fp_t a, b, r;

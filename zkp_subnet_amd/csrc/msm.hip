@@ -190,6 +190,13 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t* __res
     uint32_t my_carry_key = NONE_KEY;
     g1_xyzz_t acc;
     g1_set_inf(acc);
+    uint32_t v_cur = sorted[lo];
+    uint32_t w_cur[24];
+    {
+        const uint4* q = reinterpret_cast<const uint4*>(table + (v_cur & 0x7fffffffu));
+#pragma unroll
+        for (int i = 0; i < 6; i++) { uint4 t4 = q[i]; w_cur[4*i]=t4.x; w_cur[4*i+1]=t4.y; w_cur[4*i+2]=t4.z; w_cur[4*i+3]=t4.w; }
+    }
     for (uint32_t e = lo; e < hi; e++) {
         while (e == boundary) {  // run of `cur` is complete (also steps over empty buckets)
             if (pending_carry) {
@@ -203,11 +210,22 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t* __res
             cur++;
             boundary = offsets[cur + 1];
         }
-        const uint32_t v = sorted[e];
+        // software pipeline: the packed words of the NEXT entry's point are requested before this entry's addition
+        uint32_t wn[24];
+        const uint32_t vn = (e + 1 < hi) ? sorted[e + 1] : v_cur;
+        {
+            const uint4* q = reinterpret_cast<const uint4*>(table + (vn & 0x7fffffffu));
+#pragma unroll
+            for (int i = 0; i < 6; i++) { uint4 t4 = q[i]; wn[4*i]=t4.x; wn[4*i+1]=t4.y; wn[4*i+2]=t4.z; wn[4*i+3]=t4.w; }
+        }
         g1_aff28 p;
-        g1_load_aff(p, table + (v & 0x7fffffffu));
-        g1_neg_aff(p, v >> 31);
-        g1_madd_checked(acc, p);
+        fp_unpack(p.x, w_cur);
+        fp_unpack(p.y, w_cur + 12);
+        g1_neg_aff(p, v_cur >> 31);
+        g1_madd_checked<true>(acc, p);
+#pragma unroll
+        for (int i = 0; i < 24; i++) w_cur[i] = wn[i];
+        v_cur = vn;
     }
     if (pending_carry) {
         store_xyzz(&carries[t], acc);
@@ -844,7 +862,7 @@ __global__ void __launch_bounds__(256) k_srs_fixed_mul(const uint32_t* __restric
         if (d) {
             g1_aff28 p;
             g1_load_aff(p, gtab + w * 255 + d - 1);
-            g1_madd(acc, p.x, p.y);
+            g1_madd<true>(acc, p.x, p.y);
         }
     }
     store_xyzz(&tmp[j], acc);
