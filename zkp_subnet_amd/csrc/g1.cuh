@@ -70,26 +70,27 @@ KZG_DEV void g1_dbl_aff(g1_xyzz_t& r, const fp_t& x, const fp_t& y) {
     r.zz = V; r.zzz = W;
 }
 // r = 2*p (EFD dbl-2008-s-1, a = 0)
+template <bool INL = false>
 KZG_DEV void g1_dbl(g1_xyzz_t& r, const g1_xyzz_t& p) {
     if (g1_is_inf(p)) { g1_set_inf(r); return; }
     fp_t U, V, W, S, M, t, u, x3;
     fp_dbl(U, p.y);                     // Y < 6p -> < 12p, limbs < 2^29
-    fp_sqr(V, U);
-    fp_mul(W, U, V);
-    fp_mul(S, p.x, V);
-    fp_sqr(t, p.x);
+    fps<INL>(V, U);
+    fpm<INL>(W, U, V);
+    fpm<INL>(S, p.x, V);
+    fps<INL>(t, p.x);
     fp_add(M, t, t); fp_add(M, M, t);
-    fp_sqr(u, M);
+    fps<INL>(u, M);
     fp_sub4(u, u, S); fp_sub4(u, u, S);
     fp_norm(x3, u);
     fp_sub16(t, S, x3);
-    fp_mul(t, M, t);
-    fp_mul(u, W, p.y);
+    fpm<INL>(t, M, t);
+    fpm<INL>(u, W, p.y);
     fp_sub4(t, t, u);
     fp_norm(r.y, t);
     r.x = x3;
-    fp_mul(r.zz, V, p.zz);
-    fp_mul(r.zzz, W, p.zzz);
+    fpm<INL>(r.zz, V, p.zz);
+    fpm<INL>(r.zzz, W, p.zzz);
 }
 // acc += (qx, qy): affine, canonical, non-infinity (EFD madd-2008-s: 8M + 2S).  The common path is branch-free:
 // an empty accumulator is handled by a select at the end; the only branch is the rare acc == +-q case.
@@ -132,35 +133,36 @@ KZG_DEV void g1_madd_checked(g1_xyzz_t& acc, const g1_aff28& q) {
     g1_madd<INL>(acc, q.x, q.y);
 }
 // r = p + q (EFD add-2008-s: 12M + 2S) with the exceptional cases
+template <bool INL = false>
 KZG_DEV void g1_add(g1_xyzz_t& r, const g1_xyzz_t& p, const g1_xyzz_t& q) {
     if (g1_is_inf(p)) { r = q; return; }
     if (g1_is_inf(q)) { r = p; return; }
     fp_t U1, U2, S1, S2, P, R, PP, PPP, Q, RR, t, u, x3;
-    fp_mul(U1, p.x, q.zz);
-    fp_mul(U2, q.x, p.zz);
-    fp_mul(S1, p.y, q.zzz);
-    fp_mul(S2, q.y, p.zzz);
+    fpm<INL>(U1, p.x, q.zz);
+    fpm<INL>(U2, q.x, p.zz);
+    fpm<INL>(S1, p.y, q.zzz);
+    fpm<INL>(S2, q.y, p.zzz);
     fp_sub4(P, U2, U1);
     fp_sub4(R, S2, S1);
-    fp_sqr(PP, P);
-    fp_sqr(RR, R);
+    fps<INL>(PP, P);
+    fps<INL>(RR, R);
     if (fp_is_zero_n(PP)) {
-        if (fp_is_zero_n(RR)) { g1_dbl(r, p); return; }
+        if (fp_is_zero_n(RR)) { g1_dbl<INL>(r, p); return; }
         g1_set_inf(r);
         return;
     }
-    fp_mul(PPP, P, PP);
-    fp_mul(Q, U1, PP);
+    fpm<INL>(PPP, P, PP);
+    fpm<INL>(Q, U1, PP);
     fp_sub4(t, RR, PPP); fp_sub4(t, t, Q); fp_sub4(t, t, Q);
     fp_norm(x3, t);
     fp_sub16(t, Q, x3);
-    fp_mul(t, R, t);
-    fp_mul(u, S1, PPP);
+    fpm<INL>(t, R, t);
+    fpm<INL>(u, S1, PPP);
     fp_sub4(t, t, u);
     fp_norm(r.y, t);
     r.x = x3;
-    fp_mul(t, p.zz, q.zz); fp_mul(r.zz, t, PP);
-    fp_mul(t, p.zzz, q.zzz); fp_mul(r.zzz, t, PPP);
+    fpm<INL>(t, p.zz, q.zz); fpm<INL>(r.zz, t, PP);
+    fpm<INL>(t, p.zzz, q.zzz); fpm<INL>(r.zzz, t, PPP);
 }
 
 // ---- inversion.  One lane's Fermat ladder (381 squarings) is > 1 ms of pure latency, and a bit-by-bit binary
