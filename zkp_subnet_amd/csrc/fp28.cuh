@@ -188,6 +188,49 @@ KZG_DEV void fp_sqr_inline(fp_t& r, const fp_t& a) {
     }
 }
 
+// (a*b + c*d) / R with ONE Montgomery reduction (inline only: a 4-operand call would not fit the register ABI).
+// Column bound: a, b loose (limbs <= 1.5 * 2^29: 14 * 2.25 * 2^58 < 2^63) plus c, d with limbs < 2^29 and < 2^28
+// (14 * 2^57 < 2^61) plus the reduction (< 2^60): < 2^63.4.  Value: (ab + cd)/R + p < 2p for a < 10p, b < 18p,
+// c < 8p, d < 2p (196 p^2 / R < p/12).
+KZG_DEV void fp_mul2_inline(fp_t& r, const fp_t& a, const fp_t& b, const fp_t& c, const fp_t& d) {
+    uint32_t q[14];
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 28; k++) {
+        uint64_t acc0 = carry, acc1 = 0;
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            const int j = k - i;
+            if (j >= 0 && j < 14) {
+                acc0 += (uint64_t)a.l[i] * b.l[j];
+                acc1 += (uint64_t)c.l[i] * d.l[j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            const int j = k - i;
+            if (i < k && i < 14 && j >= 0 && j < 14) {
+                if (i & 1) acc0 += (uint64_t)q[i] * fp28_p(j);
+                else acc1 += (uint64_t)q[i] * fp28_p(j);
+            }
+        }
+        uint64_t acc = acc0 + acc1;
+        if (k < 14) {
+            q[k] = ((uint32_t)acc * FP28_PINV) & FP28_MASK;
+            acc += (uint64_t)q[k] * fp28_p(0);
+            carry = acc >> 28;
+        } else {
+            r.l[k - 14] = (k < 27) ? ((uint32_t)acc & FP28_MASK) : (uint32_t)acc;
+            carry = acc >> 28;
+        }
+    }
+}
+// 8p - b limb-wise (b: normalised limbs, value < 6p): a non-negative representative of -b with limbs < 2^29
+KZG_DEV void fp_neg8(fp_t& r, const fp_t& b) {
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = fp28_m8(i) - b.l[i];
+}
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 struct fp_ret {

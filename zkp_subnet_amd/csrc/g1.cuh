@@ -114,10 +114,15 @@ KZG_DEV void g1_madd(g1_xyzz_t& acc, const fp_t& qx, const fp_t& qy) {
     fp_sub4(t, RR, PPP); fp_sub4(t, t, Q); fp_sub4(t, t, Q);
     fp_norm(x3, t);                     // < 2p + 12p = 14p
     fp_sub16(t, Q, x3);                 // < 18p
-    fpm<INL>(t, R, t);
-    fpm<INL>(u, acc.y, PPP);
-    fp_sub4(t, t, u);
-    fp_norm(y3, t);                     // < 6p
+    if constexpr (INL) {                // y3 = (R (Q - x3) - Y1 PPP): two products, ONE reduction; result < 2p
+        fp_neg8(u, acc.y);
+        fp_mul2_inline(y3, R, t, u, PPP);
+    } else {
+        fpm<INL>(t, R, t);
+        fpm<INL>(u, acc.y, PPP);
+        fp_sub4(t, t, u);
+        fp_norm(y3, t);                 // < 6p
+    }
     fpm<INL>(zz3, acc.zz, PP);
     fpm<INL>(zzz3, acc.zzz, PPP);
     fp_t one;
