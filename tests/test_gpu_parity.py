@@ -231,6 +231,24 @@ def test_msm_2_20_full_size_trapdoor_and_linearity(hip):
     assert eng.g1_sum(shards) == got
 
 
+def test_msm_2_24_large_size_trapdoor(hip):
+    """2^24 points on one GPU (12 window tables = 19 GB resident; the same kernels were checked up to 2^26 = 77 GB
+    with tests/bringup_big.py): bit-exact against [f(tau)]G."""
+    lg, n = 24, 1 << 24
+    eng = hip()
+    tx = 0x24242424242424242424
+    eng.gen_srs(tx, 1, lg, 0)
+    s_b = rand_scalars_bytes(n, 24)
+    eng.upload_fr(0, s_b, False)
+    got = eng.msm_resident(0, n, 0)
+    y = oc.fr_eval(s_b, tx.to_bytes(32, "big"))
+    assert got == oc.g1_mul_gen(y)
+    half = n // 2                                               # two SRS segments, as two ranks would hold them
+    parts = eng.msm_partial_resident(0, half, 0) + eng.msm_partial(s_b[32 * half:], half)
+    assert eng.g1_sum(parts) == got
+    eng.close()
+
+
 # ------------------------------------------------------------------ NTT / eval
 def test_ntt_golden_and_roundtrip(hip, golden_ntt):
     eng = hip()

@@ -1,7 +1,7 @@
 // Pippenger G1 MSM for gfx950 -- kernel declarations shared by msm.hip and api.hip.
 //
 // Design (DESIGN.md "MSM"): the SRS is fixed, so every point P_j is stored with its window multiples
-// 2^(c*w) P_j (table[w][j], affine, Montgomery; sized for 288 GB HBM).  All nwin signed c-bit digits of all
+// 2^off[w] P_j (table[w][j], affine, Montgomery; sized for 288 GB HBM).  All nwin signed digits of all
 // scalars then fall into ONE set of B = 2^(c-1) buckets:
 //   1-3. msm_sort        scalar -> signed digits; two-level counting sort with all per-entry atomics in LDS:
 //                        partition by the key's high bits, then one workgroup per partition sorts the low bits

@@ -128,7 +128,15 @@ __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__
     const uint32_t lo = part_base[q], hi = part_base[q + 1];
     for (uint32_t i = t; i < nb; i += 1024) h[i] = 0;
     __syncthreads();
-    for (uint32_t e = lo + t; e < hi; e += 1024) atomicAdd(&h[parted[e].x], 1u);
+    // four independent loads in flight per lane: the loop is otherwise a chain of dependent global-load latencies
+    {
+        uint32_t e = lo + t;
+        for (; e + 3 * 1024 < hi; e += 4 * 1024) {
+            const uint32_t k0 = parted[e].x, k1 = parted[e + 1024].x, k2 = parted[e + 2048].x, k3 = parted[e + 3072].x;
+            atomicAdd(&h[k0], 1u); atomicAdd(&h[k1], 1u); atomicAdd(&h[k2], 1u); atomicAdd(&h[k3], 1u);
+        }
+        for (; e < hi; e += 1024) atomicAdd(&h[parted[e].x], 1u);
+    }
     __syncthreads();
     // exclusive scan of h[0..nb): each lane owns nb/1024 (>= 1 when nb >= 1024) consecutive bins
     const uint32_t per = (nb + 1023u) / 1024u;
@@ -152,9 +160,19 @@ __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__
     }
     if (q == npart - 1 && t == 1023) offsets[(uint64_t)npart << lbits] = hi;
     __syncthreads();
-    for (uint32_t e = lo + t; e < hi; e += 1024) {
-        const uint2 v = parted[e];
-        sorted[atomicAdd(&h[v.x], 1u)] = v.y;
+    {
+        uint32_t e = lo + t;
+        for (; e + 3 * 1024 < hi; e += 4 * 1024) {
+            const uint2 v0 = parted[e], v1 = parted[e + 1024], v2 = parted[e + 2048], v3 = parted[e + 3072];
+            sorted[atomicAdd(&h[v0.x], 1u)] = v0.y;
+            sorted[atomicAdd(&h[v1.x], 1u)] = v1.y;
+            sorted[atomicAdd(&h[v2.x], 1u)] = v2.y;
+            sorted[atomicAdd(&h[v3.x], 1u)] = v3.y;
+        }
+        for (; e < hi; e += 1024) {
+            const uint2 v = parted[e];
+            sorted[atomicAdd(&h[v.x], 1u)] = v.y;
+        }
     }
 }
 
