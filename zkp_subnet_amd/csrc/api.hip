@@ -51,6 +51,16 @@ struct StageSpan {
     hipEvent_t a, b;
 };
 
+// One MSM in flight: its own stream and sort / bucket workspace.  Lane 0 runs on the context's main stream; lane 1
+// lets the opening MSM of commit+open start while the latency-bound tail (carry fold, bucket tree, final
+// combination) of the commitment MSM is still running.
+struct MsmLane {
+    hipStream_t stream = nullptr;
+    DevBuf rank, sorted, hist, offsets, bufA, bufB, carries, carry_key;
+    hipEvent_t ev_sorted = nullptr, ev_done = nullptr;
+};
+#define N_LANES 2
+
 }  // namespace
 
 struct kzg_ctx {
@@ -66,8 +76,9 @@ struct kzg_ctx {
     uint64_t stride = 0, T = 0;
     int scale = 0, mscale = 0;
     // workspace
-    DevBuf in_be, scal, rank, sorted, hist, offsets, bufA, bufB, carries, carry_key, res, coeffA, coeffB, qbuf, hbuf,
-        hnext, small, out_be;
+    DevBuf in_be, scal, res, coeffA, coeffB, qbuf, hbuf, hnext, small, out_be;
+    MsmLane lane[N_LANES];
+    hipEvent_t ev_coeffs = nullptr;
     DevBuf slot[N_SLOTS];
     uint64_t slot_n[N_SLOTS] = {0, 0, 0, 0};
     int slot_mont[N_SLOTS] = {0, 0, 0, 0};
@@ -106,15 +117,16 @@ hipEvent_t prof_event(kzg_ctx* c) {
 struct Span {
     kzg_ctx* ctx;
     int idx = -1;
-    Span(kzg_ctx* c, int stage) : ctx(c) {
+    hipStream_t stream;
+    Span(kzg_ctx* c, int stage, hipStream_t st = nullptr) : ctx(c), stream(st ? st : c->stream) {
         if (!c->profiling) return;
         StageSpan s{stage, prof_event(c), prof_event(c)};
-        (void)hipEventRecord(s.a, c->stream);
+        (void)hipEventRecord(s.a, stream);
         c->spans.push_back(s);
         idx = (int)c->spans.size() - 1;
     }
     ~Span() {
-        if (idx >= 0) (void)hipEventRecord(ctx->spans[idx].b, ctx->stream);
+        if (idx >= 0) (void)hipEventRecord(ctx->spans[idx].b, stream);
     }
 };
 // opens the KZG_T_TOTAL span; finish() closes it just before the final synchronise
@@ -176,9 +188,11 @@ int ilog2_exact(uint64_t n) {
     return l;
 }
 
-// ---- the MSM pipeline on device-resident scalars -> one XYZZ point at out_xyzz (device)
-int msm_core(kzg_ctx* ctx, const uint32_t* scalars, int mont, uint64_t n, uint64_t srs_offset, g1_xyzz_t* out_xyzz) {
-    hipStream_t s = ctx->stream;
+// ---- the MSM pipeline on device-resident scalars -> one XYZZ point at out_xyzz (device), on lane `li`
+int msm_core(kzg_ctx* ctx, int li, const uint32_t* scalars, int mont, uint64_t n, uint64_t srs_offset,
+             g1_xyzz_t* out_xyzz) {
+    MsmLane& L = ctx->lane[li];
+    hipStream_t s = L.stream;
     if (n == 0) {
         HIPCHK(ctx, hipMemsetAsync(out_xyzz, 0, sizeof(g1_xyzz_t), s));
         return KZG_OK;
@@ -191,46 +205,46 @@ int msm_core(kzg_ctx* ctx, const uint32_t* scalars, int mont, uint64_t n, uint64
     sh.srs_offset = srs_offset; sh.srs_stride = ctx->stride; sh.chunk = pick_chunk(entries);
     const uint32_t nchunks = (uint32_t)((entries + sh.chunk - 1) / sh.chunk);
     const size_t B = ctx->nbuckets;
-    HIPCHK(ctx, ctx->rank.ensure(entries * 8));          // partitioned (key_low, value) pairs
-    HIPCHK(ctx, ctx->sorted.ensure(entries * 4));
-    HIPCHK(ctx, ctx->hist.ensure(4096 * 4));
-    HIPCHK(ctx, ctx->offsets.ensure((B + 1) * 4));
-    HIPCHK(ctx, ctx->bufA.ensure(B * sizeof(g1_xyzz_t)));
-    HIPCHK(ctx, ctx->bufB.ensure(B * sizeof(g1_xyzz_t)));
-    HIPCHK(ctx, ctx->carries.ensure((size_t)nchunks * sizeof(g1_xyzz_t)));
-    HIPCHK(ctx, ctx->carry_key.ensure((size_t)nchunks * 4));
+    HIPCHK(ctx, L.rank.ensure(entries * 8));          // partitioned (key_low, value) pairs
+    HIPCHK(ctx, L.sorted.ensure(entries * 4));
+    HIPCHK(ctx, L.hist.ensure(4096 * 4));
+    HIPCHK(ctx, L.offsets.ensure((B + 1) * 4));
+    HIPCHK(ctx, L.bufA.ensure(B * sizeof(g1_xyzz_t)));
+    HIPCHK(ctx, L.bufB.ensure(B * sizeof(g1_xyzz_t)));
+    HIPCHK(ctx, L.carries.ensure((size_t)nchunks * sizeof(g1_xyzz_t)));
+    HIPCHK(ctx, L.carry_key.ensure((size_t)nchunks * 4));
+    uint32_t* max_len_d = ctx->flags + 2 + li;
+    uint32_t* max_len_h = reinterpret_cast<uint32_t*>(ctx->host_pin + 32) + li;
     {
-        Span sp(ctx, KZG_T_DIGITS);
-        HIPCHK(ctx, hipMemsetAsync(ctx->bufA.p, 0, B * sizeof(g1_xyzz_t), s));
-        launch_msm_sort(s, sh, scalars, mont, ctx->hist.as<uint32_t>(), ctx->rank.as<uint2>(),
-                        ctx->offsets.as<uint32_t>(), ctx->sorted.as<uint32_t>());
-    }
-    {
-        Span sp(ctx, KZG_T_ACCUMULATE);
-        launch_msm_accumulate(s, sh, ctx->table.as<g1_affine_t>(), ctx->offsets.as<uint32_t>(),
-                              ctx->sorted.as<uint32_t>(), ctx->bufA.as<g1_xyzz_t>(), ctx->carries.as<g1_xyzz_t>(),
-                              ctx->carry_key.as<uint32_t>(), nchunks);
-    }
-    {
-        Span sp(ctx, KZG_T_FIXUP);
-        // longest run of carries decides how many tree steps are launched (one 4-byte read-back)
-        uint32_t* max_len_d = ctx->flags + 2;
+        Span sp(ctx, KZG_T_DIGITS, s);
+        HIPCHK(ctx, hipMemsetAsync(L.bufA.p, 0, B * sizeof(g1_xyzz_t), s));
+        launch_msm_sort(s, sh, scalars, mont, L.hist.as<uint32_t>(), L.rank.as<uint2>(), L.offsets.as<uint32_t>(),
+                        L.sorted.as<uint32_t>());
+        // the longest run of carries decides how many fold steps are launched; it depends on the offsets only, so
+        // its 4-byte read-back completes while the accumulate kernel runs and costs no bubble
         HIPCHK(ctx, hipMemsetAsync(max_len_d, 0, 4, s));
-        launch_fold_maxlen(s, ctx->offsets.as<uint32_t>(), ctx->carry_key.as<uint32_t>(), (uint32_t)sh.chunk, nchunks,
-                           max_len_d);
-        uint32_t* max_len_h = reinterpret_cast<uint32_t*>(ctx->host_pin + 32);
+        launch_fold_maxlen(s, L.offsets.as<uint32_t>(), sh.nbuckets, (uint32_t)sh.chunk, max_len_d);
         HIPCHK(ctx, hipMemcpyAsync(max_len_h, max_len_d, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(ctx, hipStreamSynchronize(s));
-        for (uint32_t d = 1; d < *max_len_h; d <<= 1)
-            launch_fold_step(s, ctx->offsets.as<uint32_t>(), ctx->carry_key.as<uint32_t>(), (uint32_t)sh.chunk, nchunks, d,
-                             ctx->carries.as<g1_xyzz_t>());
-        launch_fold_heads(s, ctx->offsets.as<uint32_t>(), ctx->carry_key.as<uint32_t>(), (uint32_t)sh.chunk, nchunks,
-                          ctx->carries.as<g1_xyzz_t>(), ctx->bufA.as<g1_xyzz_t>());
+        HIPCHK(ctx, hipEventRecord(L.ev_sorted, s));
     }
-    g1_xyzz_t* in = ctx->bufA.as<g1_xyzz_t>();
-    g1_xyzz_t* out = ctx->bufB.as<g1_xyzz_t>();
     {
-        Span sp(ctx, KZG_T_TREE);
+        Span sp(ctx, KZG_T_ACCUMULATE, s);
+        launch_msm_accumulate(s, sh, ctx->table.as<g1_affine_t>(), L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(),
+                              L.bufA.as<g1_xyzz_t>(), L.carries.as<g1_xyzz_t>(), L.carry_key.as<uint32_t>(), nchunks);
+    }
+    HIPCHK(ctx, hipEventSynchronize(L.ev_sorted));
+    {
+        Span sp(ctx, KZG_T_FIXUP, s);
+        for (uint32_t d = 1; d < *max_len_h; d <<= 1)
+            launch_fold_step(s, L.offsets.as<uint32_t>(), L.carry_key.as<uint32_t>(), (uint32_t)sh.chunk, nchunks, d,
+                             L.carries.as<g1_xyzz_t>());
+        launch_fold_heads(s, L.offsets.as<uint32_t>(), L.carry_key.as<uint32_t>(), (uint32_t)sh.chunk, nchunks,
+                          L.carries.as<g1_xyzz_t>(), L.bufA.as<g1_xyzz_t>());
+    }
+    g1_xyzz_t* in = L.bufA.as<g1_xyzz_t>();
+    g1_xyzz_t* out = L.bufB.as<g1_xyzz_t>();
+    {
+        Span sp(ctx, KZG_T_TREE, s);
         uint32_t n_in = ctx->nbuckets;
         for (int level = 0; n_in > 1; level++, n_in >>= 1) {
             launch_msm_tree_level(s, in, out, n_in, level);
@@ -238,7 +252,7 @@ int msm_core(kzg_ctx* ctx, const uint32_t* scalars, int mont, uint64_t n, uint64
         }
     }
     {
-        Span sp(ctx, KZG_T_FINAL);
+        Span sp(ctx, KZG_T_FINAL, s);
         launch_msm_final(s, in, ctx->c - 1, out_xyzz);
     }
     HIPCHK(ctx, hipGetLastError());
@@ -320,7 +334,9 @@ int upload_fr(kzg_ctx* ctx, const uint8_t* be32, uint64_t n, uint32_t* dst, int 
     return KZG_OK;
 }
 
-// commit and/or open on a device-resident Montgomery row
+// commit and/or open on a device-resident Montgomery row.  With both requested, the opening (evaluation, quotient,
+// MSM) runs on lane 1 concurrently with the commitment MSM on lane 0: the two only share the read-only coefficients.
+// Profiling keeps everything on lane 0 so that every stage time stays attributable to one kernel sequence.
 int commit_open_dev(kzg_ctx* ctx, uint32_t i, const uint32_t* row_dev, uint64_t T, int evaluation_form,
                     const uint8_t* alpha_be32, uint8_t* out_c48, uint8_t* out_eval32, uint8_t* out_p48) {
     hipStream_t s = ctx->stream;
@@ -331,8 +347,14 @@ int commit_open_dev(kzg_ctx* ctx, uint32_t i, const uint32_t* row_dev, uint64_t 
     HIPCHK(ctx, ctx->small.ensure(1024));
     uint8_t* small = ctx->small.as<uint8_t>();  // [0,48) commitment [64,112) proof [128,160) eval be [192..) alpha/y limbs
     const uint64_t offset = (uint64_t)i * ctx->T;
+    const int lo = (out_c48 && out_p48 && !ctx->profiling) ? 1 : 0;  // lane of the opening
+    hipStream_t so = ctx->lane[lo].stream;
+    if (lo) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_coeffs, s));
+        HIPCHK(ctx, hipStreamWaitEvent(so, ctx->ev_coeffs, 0));
+    }
     if (out_c48) {
-        rc = msm_core(ctx, coeffs, 1, T, offset, ctx->res.as<g1_xyzz_t>());
+        rc = msm_core(ctx, 0, coeffs, 1, T, offset, ctx->res.as<g1_xyzz_t>());
         if (rc) return rc;
         if (!out_p48) {  // commit only; with an opening the two points share one inversion below
             Span sp(ctx, KZG_T_FINAL);
@@ -342,20 +364,24 @@ int commit_open_dev(kzg_ctx* ctx, uint32_t i, const uint32_t* row_dev, uint64_t 
     if (out_p48) {
         uint32_t* alpha_m = reinterpret_cast<uint32_t*>(small + 192);
         uint32_t* y_m = reinterpret_cast<uint32_t*>(small + 256);
-        HIPCHK(ctx, hipMemcpyAsync(small + 320, alpha_be32, 32, hipMemcpyHostToDevice, s));
-        launch_fr_from_be(s, small + 320, alpha_m, 1, 1, ctx->flags);
+        HIPCHK(ctx, hipMemcpyAsync(small + 320, alpha_be32, 32, hipMemcpyHostToDevice, so));
+        launch_fr_from_be(so, small + 320, alpha_m, 1, 1, ctx->flags);
         const uint64_t nchunks = (T + 3) / 4;
         HIPCHK(ctx, ctx->hbuf.ensure(nchunks * 32));
         HIPCHK(ctx, ctx->hnext.ensure(nchunks * 32));
         HIPCHK(ctx, ctx->qbuf.ensure(T * 32));
         {
-            Span sp(ctx, KZG_T_POLY);
-            launch_poly_open(s, coeffs, T, alpha_m, ctx->hbuf.as<uint32_t>(), ctx->hnext.as<uint32_t>(), y_m,
+            Span sp(ctx, KZG_T_POLY, so);
+            launch_poly_open(so, coeffs, T, alpha_m, ctx->hbuf.as<uint32_t>(), ctx->hnext.as<uint32_t>(), y_m,
                              ctx->qbuf.as<uint32_t>());
-            launch_fr_to_be(s, y_m, small + 128, 1, 1);
+            launch_fr_to_be(so, y_m, small + 128, 1, 1);
         }
-        rc = msm_core(ctx, ctx->qbuf.as<uint32_t>(), 0, T - 1, offset, ctx->res.as<g1_xyzz_t>() + 1);
+        rc = msm_core(ctx, lo, ctx->qbuf.as<uint32_t>(), 0, T - 1, offset, ctx->res.as<g1_xyzz_t>() + 1);
         if (rc) return rc;
+        if (lo) {
+            HIPCHK(ctx, hipEventRecord(ctx->lane[lo].ev_done, so));
+            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->lane[lo].ev_done, 0));
+        }
         Span sp(ctx, KZG_T_FINAL);
         if (out_c48) launch_g1_compress_pair(s, ctx->res.as<g1_xyzz_t>(), ctx->res.as<g1_xyzz_t>() + 1, small, small + 64);
         else launch_g1_compress(s, ctx->res.as<g1_xyzz_t>() + 1, small + 64);
@@ -494,10 +520,19 @@ int kzg_create(int device_id, kzg_ctx** out) {
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) return KZG_E_HIP;  // built for gfx950 only
     kzg_ctx* ctx = new kzg_ctx();
     ctx->device = device_id;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void**)&ctx->flags, 16) != hipSuccess ||
-        hipHostMalloc((void**)&ctx->host_pin, 4096, hipHostMallocDefault) != hipSuccess) {
-        delete ctx;
+    bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc((void**)&ctx->flags, 16) == hipSuccess &&
+              hipHostMalloc((void**)&ctx->host_pin, 4096, hipHostMallocDefault) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_coeffs, hipEventDisableTiming) == hipSuccess;
+    for (int l = 0; ok && l < N_LANES; l++) {
+        MsmLane& L = ctx->lane[l];
+        if (l == 0) L.stream = ctx->stream;
+        else ok = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&L.ev_sorted, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) {
+        kzg_destroy(ctx);
         return KZG_E_HIP;
     }
     *out = ctx;
@@ -509,18 +544,26 @@ void kzg_destroy(kzg_ctx* ctx) {
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         (void)hipSetDevice(ctx->device);
-        (void)hipStreamSynchronize(ctx->stream);
-        DevBuf* bufs[] = {&ctx->table, &ctx->in_be, &ctx->scal, &ctx->rank, &ctx->sorted, &ctx->hist, &ctx->offsets,
-                          &ctx->bufA, &ctx->bufB, &ctx->carries, &ctx->carry_key, &ctx->res, &ctx->coeffA,
+        for (MsmLane& L : ctx->lane)
+            if (L.stream) (void)hipStreamSynchronize(L.stream);
+        DevBuf* bufs[] = {&ctx->table, &ctx->in_be, &ctx->scal, &ctx->res, &ctx->coeffA,
                           &ctx->coeffB, &ctx->qbuf, &ctx->hbuf, &ctx->hnext, &ctx->small, &ctx->out_be};
         for (DevBuf* b : bufs) b->release();
+        for (MsmLane& L : ctx->lane) {
+            for (DevBuf* b : {&L.rank, &L.sorted, &L.hist, &L.offsets, &L.bufA, &L.bufB, &L.carries, &L.carry_key})
+                b->release();
+            if (L.ev_sorted) (void)hipEventDestroy(L.ev_sorted);
+            if (L.ev_done) (void)hipEventDestroy(L.ev_done);
+            if (L.stream && L.stream != ctx->stream) (void)hipStreamDestroy(L.stream);
+        }
+        if (ctx->ev_coeffs) (void)hipEventDestroy(ctx->ev_coeffs);
         for (auto& b : ctx->slot) b.release();
         for (auto* m : {&ctx->tw_fwd, &ctx->tw_inv, &ctx->inv_n})
             for (auto& kv : *m) kv.second.release();
         for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
         if (ctx->flags) (void)hipFree(ctx->flags);
         if (ctx->host_pin) (void)hipHostFree(ctx->host_pin);
-        (void)hipStreamDestroy(ctx->stream);
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
 }
@@ -640,7 +683,7 @@ static int msm_host_common(kzg_ctx* ctx, const uint8_t* scalars_be32, uint64_t n
     HIPCHK(ctx, ctx->small.ensure(1024));
     rc = upload_fr(ctx, scalars_be32, n, ctx->scal.as<uint32_t>(), 0);
     if (rc) return rc;
-    rc = msm_core(ctx, ctx->scal.as<uint32_t>(), 0, n, srs_offset, ctx->res.as<g1_xyzz_t>());
+    rc = msm_core(ctx, 0, ctx->scal.as<uint32_t>(), 0, n, srs_offset, ctx->res.as<g1_xyzz_t>());
     if (rc) return rc;
     if (partial) {
         launch_xyzz_pack(ctx->stream, ctx->res.as<g1_xyzz_t>(), ctx->small.as<uint32_t>(), 1);
@@ -667,15 +710,15 @@ int kzg_g1_sum(kzg_ctx* ctx, const uint8_t* partials_xyzz192, uint32_t count, ui
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, ctx->in_be.ensure((size_t)count * 192 + 192));
-    HIPCHK(ctx, ctx->bufB.ensure(((size_t)count + 1) * sizeof(g1_xyzz_t)));
+    HIPCHK(ctx, ctx->lane[0].bufB.ensure(((size_t)count + 1) * sizeof(g1_xyzz_t)));
     HIPCHK(ctx, ctx->res.ensure(4 * sizeof(g1_xyzz_t)));
     HIPCHK(ctx, ctx->small.ensure(1024));
     int rc = clear_flags(ctx);
     if (rc) return rc;
     if (count) HIPCHK(ctx, hipMemcpyAsync(ctx->in_be.p, partials_xyzz192, (size_t)count * 192, hipMemcpyHostToDevice,
                                           ctx->stream));
-    launch_xyzz_unpack(ctx->stream, ctx->in_be.as<uint32_t>(), ctx->bufB.as<g1_xyzz_t>(), count);
-    launch_g1_sum(ctx->stream, ctx->bufB.as<g1_xyzz_t>(), count, ctx->res.as<g1_xyzz_t>());
+    launch_xyzz_unpack(ctx->stream, ctx->in_be.as<uint32_t>(), ctx->lane[0].bufB.as<g1_xyzz_t>(), count);
+    launch_g1_sum(ctx->stream, ctx->lane[0].bufB.as<g1_xyzz_t>(), count, ctx->res.as<g1_xyzz_t>());
     launch_g1_compress(ctx->stream, ctx->res.as<g1_xyzz_t>(), ctx->small.as<uint8_t>());
     HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, ctx->small.p, 48, hipMemcpyDeviceToHost, ctx->stream));
     rc = finish(ctx);
@@ -811,7 +854,7 @@ static int msm_resident_common(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_
     if (rc) return rc;
     HIPCHK(ctx, ctx->res.ensure(4 * sizeof(g1_xyzz_t)));
     HIPCHK(ctx, ctx->small.ensure(1024));
-    rc = msm_core(ctx, ctx->slot[slot].as<uint32_t>(), ctx->slot_mont[slot], n, srs_offset, ctx->res.as<g1_xyzz_t>());
+    rc = msm_core(ctx, 0, ctx->slot[slot].as<uint32_t>(), ctx->slot_mont[slot], n, srs_offset, ctx->res.as<g1_xyzz_t>());
     if (rc) return rc;
     if (partial) {
         launch_xyzz_pack(ctx->stream, ctx->res.as<g1_xyzz_t>(), ctx->small.as<uint32_t>(), 1);

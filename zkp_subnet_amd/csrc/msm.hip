@@ -48,6 +48,19 @@ struct SortShape {
     int mont, hbits, lbits;  // key = (part << lbits) | low
     uint32_t spb;            // scalars per workgroup in the two level-1 kernels
 };
+// h[key]++ in LDS, returning the old value.  When every active lane of the wave holds the same key (all scalars
+// equal, constant or sparse polynomials ...) one lane adds the whole count: same-address LDS atomics serialise.
+KZG_DEV uint32_t lds_bump(uint32_t* h, uint32_t key) {
+    const uint64_t act = __ballot(1);
+    const uint32_t k0 = __builtin_amdgcn_readfirstlane(key);
+    if (__ballot(key == k0) == act) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+        uint32_t base = 0;
+        if (rank == 0) base = atomicAdd(&h[k0], (uint32_t)__popcll(act));
+        return __builtin_amdgcn_readfirstlane(base) + rank;
+    }
+    return atomicAdd(&h[key], 1u);
+}
 template <class F>
 KZG_DEV void for_each_entry(const uint32_t* __restrict__ scalars, const SortShape& ss, const WinLayout& lay, F&& f) {
     const uint64_t base = (uint64_t)blockIdx.x * ss.spb;
@@ -69,7 +82,7 @@ __global__ void __launch_bounds__(256) k_sort_count(const uint32_t* __restrict__
     const uint32_t npart = 1u << ss.hbits;
     for (uint32_t i = threadIdx.x; i < npart; i += 256) h[i] = 0;
     __syncthreads();
-    for_each_entry(scalars, ss, lay, [&](uint32_t key, uint32_t) { atomicAdd(&h[key >> ss.lbits], 1u); });
+    for_each_entry(scalars, ss, lay, [&](uint32_t key, uint32_t) { lds_bump(h, key >> ss.lbits); });
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < npart; i += 256)
         if (h[i]) atomicAdd(&part_count[i], h[i]);
@@ -103,7 +116,7 @@ __global__ void __launch_bounds__(256) k_sort_partition(const uint32_t* __restri
     const uint32_t npart = 1u << ss.hbits;
     for (uint32_t i = threadIdx.x; i < npart; i += 256) h[i] = 0;
     __syncthreads();
-    for_each_entry(scalars, ss, lay, [&](uint32_t key, uint32_t) { atomicAdd(&h[key >> ss.lbits], 1u); });
+    for_each_entry(scalars, ss, lay, [&](uint32_t key, uint32_t) { lds_bump(h, key >> ss.lbits); });
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < npart; i += 256) {
         base[i] = h[i] ? part_base[i] + atomicAdd(&part_cursor[i], h[i]) : 0u;
@@ -113,7 +126,7 @@ __global__ void __launch_bounds__(256) k_sort_partition(const uint32_t* __restri
     const uint32_t lmask = (1u << ss.lbits) - 1u;
     for_each_entry(scalars, ss, lay, [&](uint32_t key, uint32_t val) {
         const uint32_t q = key >> ss.lbits;
-        const uint32_t pos = base[q] + atomicAdd(&h[q], 1u);
+        const uint32_t pos = base[q] + lds_bump(h, q);
         parted[pos] = make_uint2(key & lmask, val);
     });
 }
@@ -133,9 +146,9 @@ __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__
         uint32_t e = lo + t;
         for (; e + 3 * 1024 < hi; e += 4 * 1024) {
             const uint32_t k0 = parted[e].x, k1 = parted[e + 1024].x, k2 = parted[e + 2048].x, k3 = parted[e + 3072].x;
-            atomicAdd(&h[k0], 1u); atomicAdd(&h[k1], 1u); atomicAdd(&h[k2], 1u); atomicAdd(&h[k3], 1u);
+            lds_bump(h, k0); lds_bump(h, k1); lds_bump(h, k2); lds_bump(h, k3);
         }
-        for (; e < hi; e += 1024) atomicAdd(&h[parted[e].x], 1u);
+        for (; e < hi; e += 1024) lds_bump(h, parted[e].x);
     }
     __syncthreads();
     // exclusive scan of h[0..nb): each lane owns nb/1024 (>= 1 when nb >= 1024) consecutive bins
@@ -164,19 +177,28 @@ __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__
         uint32_t e = lo + t;
         for (; e + 3 * 1024 < hi; e += 4 * 1024) {
             const uint2 v0 = parted[e], v1 = parted[e + 1024], v2 = parted[e + 2048], v3 = parted[e + 3072];
-            sorted[atomicAdd(&h[v0.x], 1u)] = v0.y;
-            sorted[atomicAdd(&h[v1.x], 1u)] = v1.y;
-            sorted[atomicAdd(&h[v2.x], 1u)] = v2.y;
-            sorted[atomicAdd(&h[v3.x], 1u)] = v3.y;
+            sorted[lds_bump(h, v0.x)] = v0.y;
+            sorted[lds_bump(h, v1.x)] = v1.y;
+            sorted[lds_bump(h, v2.x)] = v2.y;
+            sorted[lds_bump(h, v3.x)] = v3.y;
         }
         for (; e < hi; e += 1024) {
             const uint2 v = parted[e];
-            sorted[atomicAdd(&h[v.x], 1u)] = v.y;
+            sorted[lds_bump(h, v.x)] = v.y;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ accumulate
+// largest b with offsets[b] <= e  (then offsets[b+1] > e: b is non-empty and contains sorted entry e)
+KZG_DEV uint32_t bucket_of(const uint32_t* __restrict__ offsets, uint32_t nbuckets, uint32_t e) {
+    uint32_t b_lo = 0, b_hi = nbuckets - 1;
+    while (b_lo < b_hi) {
+        uint32_t mid = (b_lo + b_hi + 1) >> 1;
+        if (offsets[mid] <= e) b_lo = mid; else b_hi = mid - 1;
+    }
+    return b_lo;
+}
 // Each lane owns sorted entries [t*K, (t+1)*K).  A bucket run that began in an earlier chunk is summed into
 // carries[t] (at most one per chunk: only the FIRST run of a chunk can have begun earlier); every run that
 // begins inside the chunk is stored straight to its bucket -- the lane that sees a run begin is its only writer.
@@ -196,13 +218,7 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t* __res
         return;
     }
     const uint32_t hi = min(lo + chunk, total);
-    // largest b with offsets[b] <= lo  (then offsets[b+1] > lo: b is non-empty and contains entry lo)
-    uint32_t b_lo = 0, b_hi = nbuckets - 1;
-    while (b_lo < b_hi) {
-        uint32_t mid = (b_lo + b_hi + 1) >> 1;
-        if (offsets[mid] <= lo) b_lo = mid; else b_hi = mid - 1;
-    }
-    uint32_t cur = b_lo;
+    uint32_t cur = bucket_of(offsets, nbuckets, lo);
     uint32_t boundary = offsets[cur + 1];
     bool pending_carry = offsets[cur] < lo;  // first run began in an earlier chunk
     uint32_t my_carry_key = NONE_KEY;
@@ -216,7 +232,7 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t* __res
         for (int i = 0; i < 6; i++) { uint4 t4 = q[i]; w_cur[4*i]=t4.x; w_cur[4*i+1]=t4.y; w_cur[4*i+2]=t4.z; w_cur[4*i+3]=t4.w; }
     }
     for (uint32_t e = lo; e < hi; e++) {
-        while (e == boundary) {  // run of `cur` is complete (also steps over empty buckets)
+        if (e == boundary) {  // run of `cur` is complete
             if (pending_carry) {
                 store_xyzz(&carries[t], acc);
                 my_carry_key = cur;
@@ -225,8 +241,18 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t* __res
                 store_xyzz(&buckets[cur], acc);
             }
             g1_set_inf(acc);
+            // next non-empty bucket (empty ones keep the zero = infinity of the memset): a short linear probe, then a
+            // binary search -- skewed inputs (all scalars equal ...) leave stretches of 10^4..10^5 empty buckets
             cur++;
             boundary = offsets[cur + 1];
+            for (int g = 0; g < 3 && boundary == e; g++) {
+                cur++;
+                boundary = offsets[cur + 1];
+            }
+            if (boundary == e) {
+                cur = bucket_of(offsets, nbuckets, e);
+                boundary = offsets[cur + 1];
+            }
         }
         // software pipeline: the packed words of the NEXT entry's point are requested before this entry's addition
         uint32_t wn[24];
@@ -267,13 +293,15 @@ KZG_DEV bool carry_pos(const uint32_t* __restrict__ offsets, const uint32_t* __r
     len = t1 - t0;
     return true;
 }
-__global__ void __launch_bounds__(256) k_fold_maxlen(const uint32_t* __restrict__ offsets,
-                                                      const uint32_t* __restrict__ carry_key, uint32_t chunk,
-                                                      uint32_t nchunks, uint32_t* __restrict__ max_len) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nchunks) return;
-    uint32_t key, i, len;
-    if (carry_pos(offsets, carry_key, chunk, t, key, i, len) && i == 0 && len > 1) atomicMax(max_len, len);
+// longest carry run, from the bucket offsets alone (so it can be read back while the accumulate kernel runs)
+__global__ void __launch_bounds__(256) k_fold_maxlen(const uint32_t* __restrict__ offsets, uint32_t nbuckets,
+                                                      uint32_t chunk, uint32_t* __restrict__ max_len) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbuckets) return;
+    const uint32_t lo = offsets[b], hi = offsets[b + 1];
+    if (hi == lo) return;
+    const uint32_t len = (hi - 1u) / chunk - lo / chunk;
+    if (len > 1) atomicMax(max_len, len);
 }
 __global__ void __launch_bounds__(256) k_fold_step(const uint32_t* __restrict__ offsets,
                                                     const uint32_t* __restrict__ carry_key, uint32_t chunk,
@@ -952,9 +980,8 @@ void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t*
     k_msm_accumulate<<<nblk(nchunks, 256), 256, 0, s>>>(table, offsets, sorted, sh.nbuckets, (uint32_t)sh.chunk,
                                                         nchunks, buckets, carries, carry_key);
 }
-void launch_fold_maxlen(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
-                        uint32_t nchunks, uint32_t* max_len) {
-    if (nchunks) k_fold_maxlen<<<nblk(nchunks, 256), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, max_len);
+void launch_fold_maxlen(hipStream_t s, const uint32_t* offsets, uint32_t nbuckets, uint32_t chunk, uint32_t* max_len) {
+    k_fold_maxlen<<<nblk(nbuckets, 256), 256, 0, s>>>(offsets, nbuckets, chunk, max_len);
 }
 void launch_fold_step(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
                       uint32_t nchunks, uint32_t d, g1_xyzz_t* carries) {
