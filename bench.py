@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--cpu-sample-log", type=int, default=19)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 16): the box's CPU share for one GPU")
+    ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
+                    help="msm20: MSM requests in flight per GPU in the timed region (1 = one request at a time, the "
+                         "default; 2 = the library's two lanes).  The other mode is reported in `pipelined`.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adversarial", action="store_true", help="skip the separately reported adversarial inputs")
     args = ap.parse_args()
@@ -126,47 +129,97 @@ def main():
     plan = eng.msm_plan(n)
 
     results = []
+    stage_sum = {}
+    step_ms = []
+    depth = args.in_flight if args.workload == "msm20" else 1
+    state = {"depth": depth}
 
-    def step():
+    def submit():
         if args.workload == "msm20":
-            if not use_dist:
-                results.append(eng.msm_resident(0, n, 0))
-            else:
-                part = eng.msm_partial_resident(0, n, 0)
-                results.append(eng.g1_sum(b"".join(all_gather_partials(part))))
-        else:
-            results.append(eng.commit_open_resident(0, 0, n, alpha, True))
+            return eng.msm_submit(0, n, 0, partial=use_dist)
+        return None
 
-    for _ in range(args.warmup):
-        step()
+    def complete(ticket, collect):
+        if args.workload == "msm20":
+            r = eng.msm_wait(ticket)
+            if collect:
+                for k, v in eng.timings().items():
+                    stage_sum[k] = stage_sum.get(k, 0.0) + v
+            if use_dist:
+                r = eng.g1_sum(b"".join(all_gather_partials(r)))
+        else:
+            r = eng.commit_open_resident(0, 0, n, alpha, True)
+            if collect:
+                for k, v in eng.timings().items():
+                    stage_sum[k] = stage_sum.get(k, 0.0) + v
+        results.append(r)
+
+    def run_steps(count, collect):
+        """`count` steps with up to `depth` requests in flight; every step's result reaches the host inside the loop."""
+        pending = []
+        last = time.perf_counter()
+        for _ in range(count):
+            pending.append(submit())
+            if len(pending) == state["depth"]:
+                complete(pending.pop(0), collect)
+                now = time.perf_counter()
+                step_ms.append((now - last) * 1e3)
+                last = now
+        while pending:
+            complete(pending.pop(0), collect)
+            now = time.perf_counter()
+            step_ms.append((now - last) * 1e3)
+            last = now
+
+    run_steps(args.warmup, False)
     results.clear()
+    step_ms.clear()
     # msm20: stage spans (HIP events on the library's stream) are recorded inside the timed region.  kzg22: the library
     # overlaps the two MSMs of a commit+open on two streams unless profiling is on, so the timed region runs
     # unprofiled and the stage times come from extra profiled (serialised) steps afterwards.
     profile_in_timed = args.workload == "msm20"
     eng.set_profiling(profile_in_timed)
-    stage_sum = {}
-    step_ms = []
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        step()
-        step_ms.append((time.perf_counter() - ts) * 1e3)
-        if profile_in_timed:
-            for k, v in eng.timings().items():
-                stage_sum[k] = stage_sum.get(k, 0.0) + v
+    run_steps(args.steps, profile_in_timed)
     barrier()
     elapsed = time.perf_counter() - t0
     n_prof = args.steps
+    timed_step_ms = list(step_ms)
     if not profile_in_timed:
         eng.set_profiling(True)
         n_prof = min(args.steps, 5)
-        for _ in range(n_prof):
-            step()
-            for k, v in eng.timings().items():
-                stage_sum[k] = stage_sum.get(k, 0.0) + v
+        run_steps(n_prof, True)
     eng.set_profiling(False)
+    # the same K steps with two requests in flight on the library's two lanes (MSM i+1's sort/accumulate overlaps the
+    # latency-bound tail of MSM i): reported beside the headline, never mixed into it
+    pipelined = None
+    if args.workload == "msm20" and depth == 1:
+        state["depth"] = 2
+        run_steps(args.warmup, False)
+        barrier()
+        tp = time.perf_counter()
+        run_steps(args.steps, False)
+        barrier()
+        pipe_s = time.perf_counter() - tp
+        state["depth"] = 1
+        if use_dist:
+            t = torch.tensor([pipe_s], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            pipe_s = float(t.item())
+        pipelined = {"requests_in_flight": 2, "value": n * world * args.steps / pipe_s, "unit": "points/s",
+                     "ms_per_step": pipe_s / args.steps * 1e3}
+    # single-request latency (one request at a time, result on the host before the next starts)
+    lat = []
+    for _ in range(min(args.steps, 10)):
+        tl = time.perf_counter()
+        if args.workload == "msm20":
+            results.append(eng.msm_resident(0, n, 0) if not use_dist else
+                           eng.g1_sum(b"".join(all_gather_partials(eng.msm_partial_resident(0, n, 0)))))
+        else:
+            results.append(eng.commit_open_resident(0, 0, n, alpha, True))
+        lat.append((time.perf_counter() - tl) * 1e3)
+    latency_ms = sorted(lat)[len(lat) // 2]
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -175,7 +228,7 @@ def main():
 
     if rank == 0:
         stages = {k: v / n_prof for k, v in stage_sum.items()}
-        sm = sorted(step_ms)
+        sm = sorted(timed_step_ms)
         pct = lambda q: sm[min(len(sm) - 1, int(q * len(sm)))]
         units = n * world * args.steps
         acc_ms = stages.get("accumulate", 0.0)
@@ -208,6 +261,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": wl, "points_per_gpu": n, "window_bits": eng.window, "windows": plan["windows"],
                        "buckets": plan["buckets"], "entries_per_lane": plan["chunk"], "lanes": plan["lanes"],
+                       "requests_in_flight": depth,
                        "parallelism": "single GPU" if world == 1 else
                        (f"SRS-sharded x{world}, all_gather of 192 B partials over RCCL" if args.workload == "msm20"
                         else f"Pianist segments x{world}, no exchange")},
@@ -219,11 +273,13 @@ def main():
                          "note": "integer-VALU-bound (14 x 28-bit-limb Montgomery products on v_mad_u64_u32: ~3.7k mads "
                                  "per mixed point addition), not HBM-bound; see DESIGN.md 3.3"},
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
+            "single_request_latency_ms": round(latency_ms, 4),
+            "pipelined": pipelined,
             "step_ms": {"median": round(pct(0.5), 4), "p10": round(pct(0.1), 4), "p90": round(pct(0.9), 4)},
             "setup_s": round(setup_s, 2),
         }
         if args.workload == "kzg22":
-            out["kzg_commit_open_latency_ms"] = elapsed / args.steps * 1e3
+            out["kzg_commit_open_latency_ms"] = latency_ms
         # ---- adversarial scalar distributions (SURVEY 8d cfg 2: reported separately, never part of `value`)
         if world == 1 and args.workload == "msm20" and not args.no_adversarial:
             import numpy as np

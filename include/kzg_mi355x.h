@@ -32,7 +32,8 @@ typedef enum {
     KZG_E_SCALAR = -2,  /* non-canonical Fr (>= r) */
     KZG_E_POINT = -3,   /* G1 input not reduced or not on the curve */
     KZG_E_HIP = -4,     /* HIP runtime failure or no usable device */
-    KZG_E_NOMEM = -5
+    KZG_E_NOMEM = -5,
+    KZG_E_BUSY = -6     /* an MSM ticket is outstanding (see kzg_msm_submit) */
 } kzg_status;
 
 /* ---- lifecycle: replaces Client(port, bin, ...) + Client.start()/stop()  (reference base/miner.py:73-84,155,181) */
@@ -96,6 +97,8 @@ int kzg_vk_pairing(const uint8_t p_be96[96], const uint8_t q_be192[192], uint8_t
 
 /* ---- multi-GPU: each rank reduces its SRS shard to ONE partial sum; the 192-byte partials are exchanged by
  *      the caller (RCCL all_gather over xGMI in zkp_subnet_amd.distributed) and summed on any rank. */
+/* (A partial is a projective XYZZ representative: two runs over the same input may return different bytes for the
+ *  same group element.  Only kzg_g1_sum's 48-byte output is canonical.) */
 int kzg_msm_partial(kzg_ctx* ctx, const uint8_t* scalars_be32, uint64_t n, uint64_t srs_offset,
                     uint8_t out_xyzz192[192]);
 int kzg_g1_sum(kzg_ctx* ctx, const uint8_t* partials_xyzz192, uint32_t count, uint8_t out48[48]);
@@ -105,6 +108,14 @@ int kzg_g1_sum(kzg_ctx* ctx, const uint8_t* partials_xyzz192, uint32_t count, ui
 int kzg_upload_fr(kzg_ctx* ctx, int slot, const uint8_t* be32, uint64_t n, int to_mont);
 int kzg_msm_resident(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint8_t out48[48]);
 int kzg_msm_partial_resident(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint8_t out_xyzz192[192]);
+/* Ticketed form of the two calls above, for a serving loop with several requests in flight (the reference miner's
+ * axon hands forward() to worker threads, neurons/miner.py:106-135): submit queues the MSM on one of two internal
+ * lanes (own stream + workspace) and returns; wait blocks for that ticket and writes 48 (partial=0) or 192 bytes.
+ * MSM i+1's sort/accumulate then overlaps the latency-bound tail of MSM i.  Results are identical to the blocking
+ * calls.  With both lanes taken submit fails with KZG_E_BUSY; while any ticket is outstanding only kzg_msm_submit,
+ * kzg_msm_wait and kzg_g1_sum are accepted on the context (everything else returns KZG_E_BUSY). */
+int kzg_msm_submit(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, int partial, int* out_ticket);
+int kzg_msm_wait(kzg_ctx* ctx, int ticket, uint8_t* out);
 int kzg_commit_open_resident(kzg_ctx* ctx, uint32_t i, int slot, uint64_t T, int evaluation_form,
                              const uint8_t alpha_be32[32], uint8_t out_commitment48[48], uint8_t out_eval32[32],
                              uint8_t out_proof48[48]);

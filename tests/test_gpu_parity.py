@@ -231,6 +231,51 @@ def test_msm_2_20_full_size_trapdoor_and_linearity(hip):
     assert eng.g1_sum(shards) == got
 
 
+def test_msm_tickets_pipeline_matches_blocking_calls(hip):
+    """kzg_msm_submit / kzg_msm_wait: several requests in flight on the two lanes give exactly the blocking results
+    (oracle-checked), in any interleaving; the documented E_BUSY rules hold."""
+    from zkp_subnet_amd._native import KzgError, KZG_E_BUSY
+    lg, n = 16, 1 << 16
+    eng = hip()
+    tx = 0x71C7E7
+    eng.gen_srs(tx, 1, lg, 0)
+    data = [rand_scalars_bytes(n, 40 + k) for k in range(3)]
+    # slot 2: adversarial (all equal) so that the two lanes run different numbers of fold steps
+    data[2] = data[2][:32] * n
+    for k in range(3):
+        eng.upload_fr(k, data[k], False)
+    want = [oc.g1_mul_gen(oc.fr_eval(d, tx.to_bytes(32, "big"))) for d in data]
+    assert [eng.msm_resident(k, n, 0) for k in range(3)] == want
+    order = [0, 2, 1, 2, 0, 1, 1, 0, 2, 2]
+    got, pending = [], []
+    for k in order:
+        pending.append(eng.msm_submit(k, n, 0))
+        if len(pending) == 2:
+            got.append(eng.msm_wait(pending.pop(0)))
+    got += [eng.msm_wait(t) for t in pending]
+    assert got == [want[k] for k in order]
+    # sub-ranges + partial form through tickets; g1_sum is legal while a ticket is outstanding
+    half = n // 2
+    want_half = eng.msm(data[0][:32 * half], 0)
+    ta = eng.msm_submit(0, half, 0, partial=True)
+    tb = eng.msm_submit(0, half, 0, partial=True)          # same range twice: 2 * MSM(first half)
+    with pytest.raises(KzgError) as ei:
+        eng.msm_submit(1, n, 0)
+    assert ei.value.code == KZG_E_BUSY
+    with pytest.raises(KzgError) as ei:
+        eng.msm_resident(1, n, 0)
+    assert ei.value.code == KZG_E_BUSY
+    pa = eng.msm_wait(ta)
+    assert eng.g1_sum(pa) == want_half                                                  # tb still outstanding
+    pb = eng.msm_wait(tb)
+    assert eng.g1_sum(pb) == want_half          # (the 192-byte partial is a projective form: only its sum is canonical)
+    assert eng.g1_sum(pa + pb) == eng.g1_sum(eng.msm_partial(data[0][:32 * half], 0) * 2)
+    with pytest.raises(KzgError):
+        eng.msm_wait(tb)                                                                # already collected
+    assert eng.msm_resident(1, n, 0) == want[1]                                        # idle again
+    eng.close()
+
+
 def test_msm_2_24_large_size_trapdoor(hip):
     """2^24 points on one GPU (12 window tables = 19 GB resident; the same kernels were checked up to 2^26 = 77 GB
     with tests/bringup_big.py): bit-exact against [f(tau)]G."""

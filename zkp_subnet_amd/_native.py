@@ -8,8 +8,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libkzg_mi355x.so")
 
-KZG_OK, KZG_E_ARG, KZG_E_SCALAR, KZG_E_POINT, KZG_E_HIP, KZG_E_NOMEM = 0, -1, -2, -3, -4, -5
-STATUS_NAMES = {0: "OK", -1: "E_ARG", -2: "E_SCALAR", -3: "E_POINT", -4: "E_HIP", -5: "E_NOMEM"}
+KZG_OK, KZG_E_ARG, KZG_E_SCALAR, KZG_E_POINT, KZG_E_HIP, KZG_E_NOMEM, KZG_E_BUSY = 0, -1, -2, -3, -4, -5, -6
+STATUS_NAMES = {0: "OK", -1: "E_ARG", -2: "E_SCALAR", -3: "E_POINT", -4: "E_HIP", -5: "E_NOMEM", -6: "E_BUSY"}
 TIMING_NAMES = ["decode", "ntt", "digits", "scan", "scatter", "accumulate", "fixup", "tree", "final", "poly", "total"]
 
 # every symbol include/kzg_mi355x.h declares: name -> (restype, argtypes)
@@ -45,6 +45,8 @@ SYMBOLS = {
     "kzg_upload_fr": (_I, [_P, _I, _B, _U64, _I]),
     "kzg_msm_resident": (_I, [_P, _I, _U64, _U64, _B]),
     "kzg_msm_partial_resident": (_I, [_P, _I, _U64, _U64, _B]),
+    "kzg_msm_submit": (_I, [_P, _I, _U64, _U64, _I, ctypes.POINTER(_I)]),
+    "kzg_msm_wait": (_I, [_P, _I, _B]),
     "kzg_commit_open_resident": (_I, [_P, _U32, _I, _U64, _I, _B, _B, _B, _B]),
     "kzg_ntt_resident": (_I, [_P, _I, _U64, _I]),
     "kzg_set_profiling": (_I, [_P, _I]),

@@ -57,7 +57,14 @@ struct StageSpan {
 struct MsmLane {
     hipStream_t stream = nullptr;
     DevBuf rank, sorted, hist, offsets, bufA, bufB, carries, carry_key;
+    DevBuf res, small;           // result point + its encoded form, for the ticketed (asynchronous) MSM
     hipEvent_t ev_sorted = nullptr, ev_done = nullptr;
+    bool busy = false;           // a ticket is outstanding on this lane
+    bool partial = false;
+    // profiling spans of the call running on this lane
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<StageSpan> spans;
 };
 #define N_LANES 2
 
@@ -85,11 +92,11 @@ struct kzg_ctx {
     std::map<int, DevBuf> tw_fwd, tw_inv, inv_n;
     uint32_t* flags = nullptr;   // device: [0] bad scalar, [1] bad point
     uint8_t* host_pin = nullptr; // pinned staging for small results
+    int next_lane = 0;
+    hipStream_t aux = nullptr;   // kzg_g1_sum: independent of the MSM lanes
+    DevBuf aux_in, aux_pts, aux_out;
     bool profiling = false;
-    std::vector<hipEvent_t> ev_pool;
-    size_t ev_used = 0;
-    std::vector<StageSpan> spans;
-    float tms[KZG_T_COUNT] = {0};
+    float tms[KZG_T_COUNT] = {0};  // stage times of the last completed hot-path call
 };
 
 namespace {
@@ -106,45 +113,53 @@ int fail(kzg_ctx* ctx, int code, const std::string& msg) {
                         std::string(#expr) + ": " + hipGetErrorString(_e));                                 \
     } while (0)
 
-hipEvent_t prof_event(kzg_ctx* c) {
-    if (c->ev_used == c->ev_pool.size()) {
+hipEvent_t prof_event(MsmLane& L) {
+    if (L.ev_used == L.ev_pool.size()) {
         hipEvent_t e;
         (void)hipEventCreate(&e);
-        c->ev_pool.push_back(e);
+        L.ev_pool.push_back(e);
     }
-    return c->ev_pool[c->ev_used++];
+    return L.ev_pool[L.ev_used++];
 }
 struct Span {
-    kzg_ctx* ctx;
+    MsmLane* lane = nullptr;
     int idx = -1;
     hipStream_t stream;
-    Span(kzg_ctx* c, int stage, hipStream_t st = nullptr) : ctx(c), stream(st ? st : c->stream) {
+    Span(kzg_ctx* c, int stage, hipStream_t st = nullptr, int li = 0) : stream(st ? st : c->stream) {
         if (!c->profiling) return;
-        StageSpan s{stage, prof_event(c), prof_event(c)};
+        lane = &c->lane[li];
+        StageSpan s{stage, prof_event(*lane), prof_event(*lane)};
         (void)hipEventRecord(s.a, stream);
-        c->spans.push_back(s);
-        idx = (int)c->spans.size() - 1;
+        lane->spans.push_back(s);
+        idx = (int)lane->spans.size() - 1;
     }
     ~Span() {
-        if (idx >= 0) (void)hipEventRecord(ctx->spans[idx].b, stream);
+        if (idx >= 0) (void)hipEventRecord(lane->spans[idx].b, stream);
     }
 };
-// opens the KZG_T_TOTAL span; finish() closes it just before the final synchronise
-void prof_begin(kzg_ctx* ctx) {
-    ctx->spans.clear();
-    ctx->ev_used = 0;
-    for (float& t : ctx->tms) t = 0.f;
+// opens the KZG_T_TOTAL span of the call on lane li; prof_close() ends it just before the last copy-back
+void prof_begin(kzg_ctx* ctx, int li = 0) {
+    MsmLane& L = ctx->lane[li];
+    L.spans.clear();
+    L.ev_used = 0;
     if (!ctx->profiling) return;
-    StageSpan s{KZG_T_TOTAL, prof_event(ctx), prof_event(ctx)};
-    (void)hipEventRecord(s.a, ctx->stream);
-    ctx->spans.push_back(s);
+    StageSpan s{KZG_T_TOTAL, prof_event(L), prof_event(L)};
+    (void)hipEventRecord(s.a, L.stream);
+    L.spans.push_back(s);
 }
-void prof_end(kzg_ctx* ctx) {  // stream already synchronised
-    if (!ctx->profiling) return;
-    for (auto& s : ctx->spans) {
+void prof_close(kzg_ctx* ctx, int li = 0) {
+    MsmLane& L = ctx->lane[li];
+    if (ctx->profiling && !L.spans.empty() && L.spans[0].stage == KZG_T_TOTAL) (void)hipEventRecord(L.spans[0].b, L.stream);
+}
+void prof_end(kzg_ctx* ctx, int li = 0) {  // lane stream already synchronised
+    MsmLane& L = ctx->lane[li];
+    if (L.spans.empty()) return;
+    for (float& t : ctx->tms) t = 0.f;
+    for (auto& s : L.spans) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) ctx->tms[s.stage] += ms;
     }
+    L.spans.clear();
 }
 
 int choose_window(uint64_t T) {
@@ -216,7 +231,7 @@ int msm_core(kzg_ctx* ctx, int li, const uint32_t* scalars, int mont, uint64_t n
     uint32_t* max_len_d = ctx->flags + 2 + li;
     uint32_t* max_len_h = reinterpret_cast<uint32_t*>(ctx->host_pin + 32) + li;
     {
-        Span sp(ctx, KZG_T_DIGITS, s);
+        Span sp(ctx, KZG_T_DIGITS, s, li);
         HIPCHK(ctx, hipMemsetAsync(L.bufA.p, 0, B * sizeof(g1_xyzz_t), s));
         launch_msm_sort(s, sh, scalars, mont, L.hist.as<uint32_t>(), L.rank.as<uint2>(), L.offsets.as<uint32_t>(),
                         L.sorted.as<uint32_t>());
@@ -228,13 +243,13 @@ int msm_core(kzg_ctx* ctx, int li, const uint32_t* scalars, int mont, uint64_t n
         HIPCHK(ctx, hipEventRecord(L.ev_sorted, s));
     }
     {
-        Span sp(ctx, KZG_T_ACCUMULATE, s);
+        Span sp(ctx, KZG_T_ACCUMULATE, s, li);
         launch_msm_accumulate(s, sh, ctx->table.as<g1_affine_t>(), L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(),
                               L.bufA.as<g1_xyzz_t>(), L.carries.as<g1_xyzz_t>(), L.carry_key.as<uint32_t>(), nchunks);
     }
     HIPCHK(ctx, hipEventSynchronize(L.ev_sorted));
     {
-        Span sp(ctx, KZG_T_FIXUP, s);
+        Span sp(ctx, KZG_T_FIXUP, s, li);
         for (uint32_t d = 1; d < *max_len_h; d <<= 1)
             launch_fold_step(s, L.offsets.as<uint32_t>(), L.carry_key.as<uint32_t>(), (uint32_t)sh.chunk, nchunks, d,
                              L.carries.as<g1_xyzz_t>());
@@ -244,7 +259,7 @@ int msm_core(kzg_ctx* ctx, int li, const uint32_t* scalars, int mont, uint64_t n
     g1_xyzz_t* in = L.bufA.as<g1_xyzz_t>();
     g1_xyzz_t* out = L.bufB.as<g1_xyzz_t>();
     {
-        Span sp(ctx, KZG_T_TREE, s);
+        Span sp(ctx, KZG_T_TREE, s, li);
         uint32_t n_in = ctx->nbuckets;
         for (int level = 0; n_in > 1; level++, n_in >>= 1) {
             launch_msm_tree_level(s, in, out, n_in, level);
@@ -252,13 +267,19 @@ int msm_core(kzg_ctx* ctx, int li, const uint32_t* scalars, int mont, uint64_t n
         }
     }
     {
-        Span sp(ctx, KZG_T_FINAL, s);
+        Span sp(ctx, KZG_T_FINAL, s, li);
         launch_msm_final(s, in, ctx->c - 1, out_xyzz);
     }
     HIPCHK(ctx, hipGetLastError());
     return KZG_OK;
 }
 
+// every entry point except kzg_msm_submit / kzg_msm_wait / kzg_g1_sum shares lane 0 and the context buffers
+int need_idle(kzg_ctx* ctx) {
+    for (const MsmLane& L : ctx->lane)
+        if (L.busy) return fail(ctx, KZG_E_BUSY, "an MSM ticket is outstanding: call kzg_msm_wait first");
+    return KZG_OK;
+}
 int need_srs(kzg_ctx* ctx) {
     if (!ctx->table.p || !ctx->stride) return fail(ctx, KZG_E_ARG, "no SRS resident: call kzg_load_srs / kzg_gen_srs");
     return KZG_OK;
@@ -269,8 +290,7 @@ int clear_flags(kzg_ctx* ctx) {
 }
 // results staged in host_pin: [0..16) flags, then payload
 int finish(kzg_ctx* ctx) {
-    if (ctx->profiling && !ctx->spans.empty() && ctx->spans[0].stage == KZG_T_TOTAL)
-        (void)hipEventRecord(ctx->spans[0].b, ctx->stream);
+    prof_close(ctx);
     HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin, ctx->flags, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     prof_end(ctx);
@@ -523,7 +543,8 @@ int kzg_create(int device_id, kzg_ctx** out) {
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
               hipMalloc((void**)&ctx->flags, 16) == hipSuccess &&
               hipHostMalloc((void**)&ctx->host_pin, 4096, hipHostMallocDefault) == hipSuccess &&
-              hipEventCreateWithFlags(&ctx->ev_coeffs, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&ctx->ev_coeffs, hipEventDisableTiming) == hipSuccess &&
+              hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) == hipSuccess;
     for (int l = 0; ok && l < N_LANES; l++) {
         MsmLane& L = ctx->lane[l];
         if (l == 0) L.stream = ctx->stream;
@@ -552,6 +573,9 @@ void kzg_destroy(kzg_ctx* ctx) {
         for (MsmLane& L : ctx->lane) {
             for (DevBuf* b : {&L.rank, &L.sorted, &L.hist, &L.offsets, &L.bufA, &L.bufB, &L.carries, &L.carry_key})
                 b->release();
+            L.res.release();
+            L.small.release();
+            for (hipEvent_t e : L.ev_pool) (void)hipEventDestroy(e);
             if (L.ev_sorted) (void)hipEventDestroy(L.ev_sorted);
             if (L.ev_done) (void)hipEventDestroy(L.ev_done);
             if (L.stream && L.stream != ctx->stream) (void)hipStreamDestroy(L.stream);
@@ -560,7 +584,11 @@ void kzg_destroy(kzg_ctx* ctx) {
         for (auto& b : ctx->slot) b.release();
         for (auto* m : {&ctx->tw_fwd, &ctx->tw_inv, &ctx->inv_n})
             for (auto& kv : *m) kv.second.release();
-        for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+        for (DevBuf* b : {&ctx->aux_in, &ctx->aux_pts, &ctx->aux_out}) b->release();
+        if (ctx->aux) {
+            (void)hipStreamSynchronize(ctx->aux);
+            (void)hipStreamDestroy(ctx->aux);
+        }
         if (ctx->flags) (void)hipFree(ctx->flags);
         if (ctx->host_pin) (void)hipHostFree(ctx->host_pin);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -590,6 +618,7 @@ int kzg_load_srs(kzg_ctx* ctx, const uint8_t* g1_affine_be96, uint64_t n_points,
     if (!ctx || !g1_affine_be96) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (int busy = need_idle(ctx)) return busy;
     int rc = alloc_table(ctx, n_points, scale, machines_scale);
     if (rc) return rc;
     rc = clear_flags(ctx);
@@ -618,6 +647,7 @@ int kzg_gen_srs(kzg_ctx* ctx, const uint8_t tau_be32[32], const uint8_t* s0_be32
     if (!ctx || !tau_be32 || !s0_be32 || !n_slices) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (int busy = need_idle(ctx)) return busy;
     if (machines_scale < 0 || scale < machines_scale || scale - machines_scale > 30)
         return fail(ctx, KZG_E_ARG, "bad scale / machines_scale");
     const uint64_t T = (uint64_t)1 << (scale - machines_scale);
@@ -656,6 +686,7 @@ int kzg_srs_read(kzg_ctx* ctx, int w, uint64_t first, uint64_t count, uint8_t* o
     if (!ctx || !out_be96) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (int busy = need_idle(ctx)) return busy;
     int rc = need_srs(ctx);
     if (rc) return rc;
     if (w < 0 || w >= ctx->nwin || first + count > ctx->stride) return fail(ctx, KZG_E_ARG, "srs_read out of range");
@@ -673,6 +704,7 @@ static int msm_host_common(kzg_ctx* ctx, const uint8_t* scalars_be32, uint64_t n
     if (!ctx || !out || (n && !scalars_be32)) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (int busy = need_idle(ctx)) return busy;
     int rc = need_srs(ctx);
     if (rc) return rc;
     prof_begin(ctx);
@@ -705,25 +737,26 @@ int kzg_msm_partial(kzg_ctx* ctx, const uint8_t* scalars_be32, uint64_t n, uint6
     return msm_host_common(ctx, scalars_be32, n, srs_offset, out_xyzz192, true);
 }
 
+// runs on its own stream and buffers: legal while MSM tickets are outstanding (a rank sums the gathered partials
+// of step i while its step i+1 is already on the GPU)
 int kzg_g1_sum(kzg_ctx* ctx, const uint8_t* partials_xyzz192, uint32_t count, uint8_t out48[48]) {
     if (!ctx || !out48 || (count && !partials_xyzz192)) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, ctx->in_be.ensure((size_t)count * 192 + 192));
-    HIPCHK(ctx, ctx->lane[0].bufB.ensure(((size_t)count + 1) * sizeof(g1_xyzz_t)));
-    HIPCHK(ctx, ctx->res.ensure(4 * sizeof(g1_xyzz_t)));
-    HIPCHK(ctx, ctx->small.ensure(1024));
-    int rc = clear_flags(ctx);
-    if (rc) return rc;
-    if (count) HIPCHK(ctx, hipMemcpyAsync(ctx->in_be.p, partials_xyzz192, (size_t)count * 192, hipMemcpyHostToDevice,
-                                          ctx->stream));
-    launch_xyzz_unpack(ctx->stream, ctx->in_be.as<uint32_t>(), ctx->lane[0].bufB.as<g1_xyzz_t>(), count);
-    launch_g1_sum(ctx->stream, ctx->lane[0].bufB.as<g1_xyzz_t>(), count, ctx->res.as<g1_xyzz_t>());
-    launch_g1_compress(ctx->stream, ctx->res.as<g1_xyzz_t>(), ctx->small.as<uint8_t>());
-    HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, ctx->small.p, 48, hipMemcpyDeviceToHost, ctx->stream));
-    rc = finish(ctx);
-    if (rc) return rc;
-    memcpy(out48, ctx->host_pin + 64, 48);
+    HIPCHK(ctx, ctx->aux_in.ensure((size_t)count * 192 + 192));
+    HIPCHK(ctx, ctx->aux_pts.ensure(((size_t)count + 2) * sizeof(g1_xyzz_t)));
+    HIPCHK(ctx, ctx->aux_out.ensure(64));
+    hipStream_t s = ctx->aux;
+    g1_xyzz_t* pts = ctx->aux_pts.as<g1_xyzz_t>();
+    if (count) HIPCHK(ctx, hipMemcpyAsync(ctx->aux_in.p, partials_xyzz192, (size_t)count * 192, hipMemcpyHostToDevice, s));
+    launch_xyzz_unpack(s, ctx->aux_in.as<uint32_t>(), pts + 1, count);
+    launch_g1_sum(s, pts + 1, count, pts);
+    launch_g1_compress(s, pts, ctx->aux_out.as<uint8_t>());
+    uint8_t* pin = ctx->host_pin + 1024;
+    HIPCHK(ctx, hipMemcpyAsync(pin, ctx->aux_out.p, 48, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    HIPCHK(ctx, hipGetLastError());
+    memcpy(out48, pin, 48);
     return KZG_OK;
 }
 
@@ -732,6 +765,7 @@ static int commit_open_host(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, u
     if (!ctx || !row_be32 || (p48 && (!alpha || !e32))) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (int busy = need_idle(ctx)) return busy;
     int rc = check_worker(ctx, i, T);
     if (rc) return rc;
     prof_begin(ctx);
@@ -778,6 +812,7 @@ int kzg_ntt(kzg_ctx* ctx, uint8_t* inout_be32, uint64_t n, int inverse) {
     if (!ctx || !inout_be32 || !n) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (int busy = need_idle(ctx)) return busy;
     prof_begin(ctx);
     int rc = clear_flags(ctx);
     if (rc) return rc;
@@ -797,6 +832,7 @@ int kzg_eval(kzg_ctx* ctx, const uint8_t* coeffs_be32, uint64_t n, const uint8_t
     if (!ctx || !x_be32 || !out_be32 || (n && !coeffs_be32)) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (int busy = need_idle(ctx)) return busy;
     if (n == 0) {
         memset(out_be32, 0, 32);
         return KZG_OK;
@@ -830,6 +866,7 @@ int kzg_upload_fr(kzg_ctx* ctx, int slot, const uint8_t* be32, uint64_t n, int t
     if (!ctx || slot < 0 || slot >= N_SLOTS || (n && !be32)) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (int busy = need_idle(ctx)) return busy;
     prof_begin(ctx);
     int rc = clear_flags(ctx);
     if (rc) return rc;
@@ -846,6 +883,7 @@ static int msm_resident_common(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_
     if (!ctx || !out || slot < 0 || slot >= N_SLOTS) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (int busy = need_idle(ctx)) return busy;
     int rc = need_srs(ctx);
     if (rc) return rc;
     if (n > ctx->slot_n[slot]) return fail(ctx, KZG_E_ARG, "slot holds fewer scalars than requested");
@@ -875,6 +913,60 @@ int kzg_msm_resident(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, ui
 int kzg_msm_partial_resident(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint8_t out_xyzz192[192]) {
     return msm_resident_common(ctx, slot, n, srs_offset, out_xyzz192, true);
 }
+// ---- ticketed MSM: submit returns once the work is queued on a free lane, wait returns the result.  Two lanes, so
+// MSM i+1 (sort, accumulate) overlaps the latency-bound tail (fold, bucket tree, final combination, inversion) of
+// MSM i.  While a ticket is outstanding only kzg_msm_submit / kzg_msm_wait / kzg_g1_sum may be called on the ctx.
+int kzg_msm_submit(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, int partial, int* out_ticket) {
+    if (!ctx || !out_ticket || slot < 0 || slot >= N_SLOTS) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = need_srs(ctx);
+    if (rc) return rc;
+    if (n > ctx->slot_n[slot]) return fail(ctx, KZG_E_ARG, "slot holds fewer scalars than requested");
+    int li = -1;
+    for (int k = 0; k < N_LANES && li < 0; k++)
+        if (!ctx->lane[(ctx->next_lane + k) % N_LANES].busy) li = (ctx->next_lane + k) % N_LANES;
+    if (li < 0) return fail(ctx, KZG_E_BUSY, "both MSM lanes hold an outstanding ticket: call kzg_msm_wait first");
+    MsmLane& L = ctx->lane[li];
+    HIPCHK(ctx, L.res.ensure(sizeof(g1_xyzz_t)));
+    HIPCHK(ctx, L.small.ensure(256));
+    prof_begin(ctx, li);
+    rc = msm_core(ctx, li, ctx->slot[slot].as<uint32_t>(), ctx->slot_mont[slot], n, srs_offset, L.res.as<g1_xyzz_t>());
+    if (rc) return rc;
+    uint8_t* pin = ctx->host_pin + 256 + 256 * li;
+    if (partial) {
+        launch_xyzz_pack(L.stream, L.res.as<g1_xyzz_t>(), L.small.as<uint32_t>(), 1);
+    } else {
+        Span sp(ctx, KZG_T_FINAL, L.stream, li);
+        launch_g1_compress(L.stream, L.res.as<g1_xyzz_t>(), L.small.as<uint8_t>());
+    }
+    prof_close(ctx, li);
+    HIPCHK(ctx, hipMemcpyAsync(pin, L.small.p, partial ? 192 : 48, hipMemcpyDeviceToHost, L.stream));
+    HIPCHK(ctx, hipEventRecord(L.ev_done, L.stream));
+    HIPCHK(ctx, hipGetLastError());
+    L.busy = true;
+    L.partial = partial != 0;
+    ctx->next_lane = (li + 1) % N_LANES;
+    *out_ticket = li;
+    return KZG_OK;
+}
+int kzg_msm_wait(kzg_ctx* ctx, int ticket, uint8_t* out) {
+    if (!ctx || !out || ticket < 0 || ticket >= N_LANES) return KZG_E_ARG;
+    MsmLane& L = ctx->lane[ticket];
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (!L.busy) return fail(ctx, KZG_E_ARG, "no outstanding MSM on this ticket");
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+    }
+    hipError_t e = hipEventSynchronize(L.ev_done);  // not under the lock: another thread may submit meanwhile
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    L.busy = false;
+    HIPCHK(ctx, e);
+    prof_end(ctx, ticket);
+    memcpy(out, ctx->host_pin + 256 + 256 * ticket, L.partial ? 192 : 48);
+    return KZG_OK;
+}
+
 int kzg_commit_open_resident(kzg_ctx* ctx, uint32_t i, int slot, uint64_t T, int evaluation_form,
                              const uint8_t alpha_be32[32], uint8_t out_commitment48[48], uint8_t out_eval32[32],
                              uint8_t out_proof48[48]) {
@@ -882,6 +974,7 @@ int kzg_commit_open_resident(kzg_ctx* ctx, uint32_t i, int slot, uint64_t T, int
         return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (int busy = need_idle(ctx)) return busy;
     int rc = check_worker(ctx, i, T);
     if (rc) return rc;
     if (T > ctx->slot_n[slot] || !ctx->slot_mont[slot])
@@ -896,6 +989,7 @@ int kzg_ntt_resident(kzg_ctx* ctx, int slot, uint64_t n, int inverse) {
     if (!ctx || slot < 0 || slot >= N_SLOTS || !n) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (int busy = need_idle(ctx)) return busy;
     if (n > ctx->slot_n[slot] || !ctx->slot_mont[slot]) return fail(ctx, KZG_E_ARG, "slot must hold >= n Montgomery elements");
     prof_begin(ctx);
     int rc = clear_flags(ctx);
@@ -971,6 +1065,7 @@ int kzg_test_field(kzg_ctx* ctx, int field, int op, const uint8_t* a_be, const u
     if (!ctx || !a_be || !b_be || !out_be || !n) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (int busy = need_idle(ctx)) return busy;
     const size_t w = field == 0 ? 48 : 32;
     HIPCHK(ctx, ctx->in_be.ensure(2 * n * w));
     HIPCHK(ctx, ctx->out_be.ensure(n * w));
@@ -990,6 +1085,7 @@ int kzg_test_g1(kzg_ctx* ctx, int op, const uint8_t* a_be96, const uint8_t* b_be
     if (!ctx || !a_be96 || !b_be96 || !out_be96 || !n) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (int busy = need_idle(ctx)) return busy;
     HIPCHK(ctx, ctx->in_be.ensure(2 * n * 96));
     HIPCHK(ctx, ctx->out_be.ensure(n * 96));
     uint8_t* da = ctx->in_be.as<uint8_t>();

@@ -183,6 +183,17 @@ class HipEngine:
         self._chk(self._lib.kzg_msm_partial_resident(self._h, slot, n, srs_offset, out))
         return out.raw
 
+    def msm_submit(self, slot: int, n: int, srs_offset: int = 0, partial: bool = False) -> Tuple[int, bool]:
+        """Queue an MSM on a free lane and return its ticket; at most two tickets may be outstanding (E_BUSY)."""
+        t = ctypes.c_int(-1)
+        self._chk(self._lib.kzg_msm_submit(self._h, slot, n, srs_offset, int(partial), ctypes.byref(t)))
+        return t.value, partial
+
+    def msm_wait(self, ticket: Tuple[int, bool]) -> bytes:
+        out = ctypes.create_string_buffer(192 if ticket[1] else 48)
+        self._chk(self._lib.kzg_msm_wait(self._h, ticket[0], out))
+        return out.raw
+
     def commit_open_resident(self, i: int, slot: int, T: int, alpha_be32: bytes,
                              evaluation_form: bool = True) -> Tuple[bytes, bytes, bytes]:
         c, ev, pf = ctypes.create_string_buffer(48), ctypes.create_string_buffer(32), ctypes.create_string_buffer(48)
