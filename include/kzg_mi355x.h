@@ -121,6 +121,12 @@ int kzg_commit_open_resident(kzg_ctx* ctx, uint32_t i, int slot, uint64_t T, int
                              uint8_t out_proof48[48]);
 int kzg_ntt_resident(kzg_ctx* ctx, int slot, uint64_t n, int inverse); /* in place on the slot */
 
+/* ---- pinned host staging.  Returns a page-locked buffer of at least `bytes` bytes owned by the ctx (valid until the
+ *      next call asking for more, or kzg_destroy).  A host that decodes the synapse's base64 text itself
+ *      (zkp_subnet_amd/csrc/wire_py.c) writes the 32-byte scalars straight into it and passes the pointer as
+ *      row_be32 / scalars_be32: the upload then runs at PCIe speed with no pageable bounce and no page faults. */
+int kzg_staging_buffer(kzg_ctx* ctx, uint64_t bytes, void** out_ptr);
+
 /* ---- per-stage HIP-event timings of the last hot-path call (events recorded on the ctx's own stream) */
 enum {
     KZG_T_DECODE = 0, KZG_T_NTT, KZG_T_DIGITS, KZG_T_SCAN, KZG_T_SCATTER, KZG_T_ACCUMULATE, KZG_T_FIXUP,

@@ -83,3 +83,33 @@ def test_b64_codec_rejects_garbage(lib):
         codec.fr_list_to_be32(["A" * 42 + "B"])  # non-zero padding bits: not the encoding of 32 bytes
     with pytest.raises(codec.CodecError):
         codec.g1_from_b64("AAAA")
+
+
+def test_wire_extension_matches_python_base64():
+    """csrc/wire_py.c (the List[str] fast path of the synapse codec): same bytes as Python's base64, same rejections."""
+    import base64
+    import os as _os
+
+    from zkp_subnet_amd import codec
+    from zkp_subnet_amd.build import build_wire
+
+    build_wire()
+    import importlib
+
+    importlib.reload(codec)
+    assert codec._wire is not None
+    for n in (0, 1, 7, 40000):                         # 40000 > the threading threshold
+        raw = _os.urandom(32 * n)
+        lst = codec.be32_to_fr_list(raw)
+        assert lst == [base64.b64encode(raw[32 * i:32 * i + 32]).decode().rstrip("=") for i in range(n)]
+        assert codec.fr_list_to_be32(lst) == raw
+        assert codec.fr_list_to_be32(tuple(lst)) == raw
+        if n:
+            assert codec._wire.decode_fr_list(lst, 3) == raw
+    good = codec.be32_to_fr(bytes(range(32)))
+    for bad in ([good[:-1]], [good + "A"], [good[:-1] + "B"], ["\u00e9" * 43], [good.encode()], [good, 5], [good[:20] + "=" + good[21:]],
+                [good] * 20000 + [good[:5] + "*" + good[6:]] + [good] * 20000):
+        with pytest.raises(codec.CodecError):
+            codec.fr_list_to_be32(bad)
+    with pytest.raises(ValueError):
+        codec._wire.encode_fr_list(b"\x00" * 33)

@@ -49,6 +49,7 @@ SYMBOLS = {
     "kzg_msm_wait": (_I, [_P, _I, _B]),
     "kzg_commit_open_resident": (_I, [_P, _U32, _I, _U64, _I, _B, _B, _B, _B]),
     "kzg_ntt_resident": (_I, [_P, _I, _U64, _I]),
+    "kzg_staging_buffer": (_I, [_P, _U64, ctypes.POINTER(_P)]),
     "kzg_set_profiling": (_I, [_P, _I]),
     "kzg_get_timings": (_I, [_P, ctypes.POINTER(ctypes.c_float), _I]),
     "kzg_msm_plan": (_I, [_P, _U64, ctypes.POINTER(ctypes.c_int32)]),

@@ -33,7 +33,25 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_wire(force: bool = False) -> str:
+    """The CPython text codec of the synapse (csrc/wire_py.c): plain C, built with gcc against this interpreter."""
+    import sysconfig
+
+    src = os.path.join(CSRC, "wire_py.c")
+    out = os.path.join(HERE, "_wire" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+    if force or _stale(out, [src]):
+        cc = shutil.which("gcc") or shutil.which("cc")
+        if not cc:
+            raise RuntimeError("gcc not found: cannot build the wire codec extension")
+        res = subprocess.run([cc, "-O3", "-shared", "-fPIC", "-pthread", "-I" + sysconfig.get_paths()["include"], src,
+                              "-o", out], capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("wire codec build failed:\n" + res.stderr[-4000:])
+    return out
+
+
 def build(force: bool = False, extra_flags=()) -> str:
+    build_wire(force)
     hipcc = _hipcc()
     extra_flags = tuple(extra_flags) + tuple(os.environ.get("KZG_EXTRA_HIPCC_FLAGS", "").split())
     os.makedirs(OBJ, exist_ok=True)

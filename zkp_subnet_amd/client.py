@@ -128,20 +128,24 @@ class Client:
     # ------------------------------------------------------------------ miner side (neurons/miner.py:38-61)
     @_guard
     def worker_commit(self, i: int, poly: Sequence[str]):
-        row = codec.fr_list_to_be32(poly)
-        return {"commitment": codec.g1_to_b64(self.engine.commit(self._slice(i), row, True))}
+        fast = getattr(self.engine, "commit_list", None)      # HipEngine: text decoded straight into pinned staging
+        c = fast(self._slice(i), poly, True) if fast and codec._wire else \
+            self.engine.commit(self._slice(i), codec.fr_list_to_be32(poly), True)
+        return {"commitment": codec.g1_to_b64(c)}
 
     @_guard
     def worker_open(self, i: int, poly: Sequence[str], x: str):
-        row = codec.fr_list_to_be32(poly)
-        ev, pf = self.engine.open(self._slice(i), row, codec.fr_to_be32(x), True)
+        fast = getattr(self.engine, "open_list", None)
+        ev, pf = fast(self._slice(i), poly, codec.fr_to_be32(x), True) if fast and codec._wire else \
+            self.engine.open(self._slice(i), codec.fr_list_to_be32(poly), codec.fr_to_be32(x), True)
         return {"eval": codec.be32_to_fr(ev), "proof": codec.g1_to_b64(pf)}
 
     @_guard
     def worker_commit_and_open(self, i: int, poly: Sequence[str], x: str):
         """Fused extension (one upload, one IFFT): what Miner.rpc_commit_and_open needs (neurons/miner.py:56-61)."""
-        row = codec.fr_list_to_be32(poly)
-        c, ev, pf = self.engine.commit_open(self._slice(i), row, codec.fr_to_be32(x), True)
+        fast = getattr(self.engine, "commit_open_list", None)
+        c, ev, pf = fast(self._slice(i), poly, codec.fr_to_be32(x), True) if fast and codec._wire else \
+            self.engine.commit_open(self._slice(i), codec.fr_list_to_be32(poly), codec.fr_to_be32(x), True)
         return {"commitment": codec.g1_to_b64(c), "eval": codec.be32_to_fr(ev), "proof": codec.g1_to_b64(pf)}
 
     # ------------------------------------------------------------------ validator side (neurons/validator.py:58-104)

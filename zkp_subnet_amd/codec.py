@@ -13,6 +13,11 @@ from typing import List, Sequence
 
 from . import _native
 
+try:                                    # csrc/wire_py.c, built by zkp_subnet_amd.build
+    from . import _wire
+except ImportError:                     # not built yet: the C-ABI codec (kzg_b64_*_fr) below does the same job, slower
+    _wire = None
+
 R_MODULUS = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 
 
@@ -25,6 +30,11 @@ def fr_list_to_be32(poly: Sequence[str]) -> bytes:
     n = len(poly)
     if n == 0:
         return b""
+    if _wire is not None:               # no join, no intermediate copy, threaded decode with the GIL released
+        try:
+            return _wire.decode_fr_list(poly)
+        except ValueError as e:
+            raise CodecError(str(e)) from e
     if _native.lib_available():
         try:
             packed = "".join(poly).encode("ascii")
@@ -59,6 +69,8 @@ def be32_to_fr(b: bytes) -> str:
 
 def be32_to_fr_list(b: bytes) -> List[str]:
     n = len(b) // 32
+    if n and _wire is not None:
+        return _wire.encode_fr_list(b)
     if n and _native.lib_available():
         out = ctypes.create_string_buffer(43 * n)
         _native.load().kzg_b64_encode_fr(b, n, out)

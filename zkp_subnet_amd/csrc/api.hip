@@ -92,6 +92,8 @@ struct kzg_ctx {
     std::map<int, DevBuf> tw_fwd, tw_inv, inv_n;
     uint32_t* flags = nullptr;   // device: [0] bad scalar, [1] bad point
     uint8_t* host_pin = nullptr; // pinned staging for small results
+    void* stage_host = nullptr;  // pinned staging for a caller-decoded polynomial (kzg_staging_buffer)
+    size_t stage_cap = 0;
     int next_lane = 0;
     hipStream_t aux = nullptr;   // kzg_g1_sum: independent of the MSM lanes
     DevBuf aux_in, aux_pts, aux_out;
@@ -591,6 +593,7 @@ void kzg_destroy(kzg_ctx* ctx) {
         }
         if (ctx->flags) (void)hipFree(ctx->flags);
         if (ctx->host_pin) (void)hipHostFree(ctx->host_pin);
+        if (ctx->stage_host) (void)hipHostFree(ctx->stage_host);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -997,6 +1000,26 @@ int kzg_ntt_resident(kzg_ctx* ctx, int slot, uint64_t n, int inverse) {
     rc = ntt_dev(ctx, ctx->slot[slot].as<uint32_t>(), n, inverse);
     if (rc) return rc;
     return finish(ctx);
+}
+
+int kzg_staging_buffer(kzg_ctx* ctx, uint64_t bytes, void** out_ptr) {
+    if (!ctx || !out_ptr) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (bytes > ctx->stage_cap) {
+        if (ctx->stage_host) (void)hipHostFree(ctx->stage_host);
+        ctx->stage_host = nullptr;
+        ctx->stage_cap = 0;
+        const size_t want = (size_t)bytes + ((size_t)bytes >> 3) + 4096;
+        hipError_t e = hipHostMalloc(&ctx->stage_host, want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            ctx->stage_host = nullptr;
+            return fail(ctx, KZG_E_NOMEM, std::string("hipHostMalloc(staging): ") + hipGetErrorString(e));
+        }
+        ctx->stage_cap = want;
+    }
+    *out_ptr = ctx->stage_host;
+    return KZG_OK;
 }
 
 int kzg_set_profiling(kzg_ctx* ctx, int enable) {

@@ -6,6 +6,7 @@ methods to exercise the host logic on machines without a GPU."""
 from __future__ import annotations
 
 import ctypes
+import threading
 from typing import Dict, List, Optional, Sequence, Tuple
 
 from . import _native
@@ -43,6 +44,7 @@ class HipEngine:
         self.device = device
         self.scale = self.machines_scale = 0
         self.verifier = None          # host-side pairing verifier (zkp_subnet_amd.verifier.Verifier)
+        self._stage_lock = threading.Lock()   # one decoded polynomial at a time in the pinned staging buffer
         if window:
             self._chk(self._lib.kzg_set_window(self._h, window))
 
@@ -142,6 +144,45 @@ class HipEngine:
         c, ev, pf = ctypes.create_string_buffer(48), ctypes.create_string_buffer(32), ctypes.create_string_buffer(48)
         self._chk(self._lib.kzg_commit_open(self._h, i, row_be32, len(row_be32) // 32, int(evaluation_form),
                                             alpha_be32, c, ev, pf))
+        return c.raw, ev.raw, pf.raw
+
+    # ---- the same three calls fed from the synapse's List[str] (reference neurons/miner.py:38-61): the text is decoded
+    # by csrc/wire_py.c straight into the library's pinned staging buffer (no bytes object, no pageable bounce)
+    def _stage_poly(self, poly: Sequence[str]):
+        from . import codec
+
+        if codec._wire is None:
+            raise RuntimeError("zkp_subnet_amd._wire is not built: run `python -m zkp_subnet_amd.build`")
+        n = len(poly)
+        ptr = ctypes.c_void_p()
+        self._chk(self._lib.kzg_staging_buffer(self._h, 32 * max(n, 1), ctypes.byref(ptr)))
+        try:
+            got = codec._wire.decode_fr_list_into(poly, ptr.value, 32 * max(n, 1))
+        except ValueError as e:
+            raise codec.CodecError(str(e)) from e
+        assert got == n
+        return ctypes.cast(ptr, ctypes.c_char_p), n
+
+    def commit_list(self, i: int, poly: Sequence[str], evaluation_form: bool = True) -> bytes:
+        out = ctypes.create_string_buffer(48)
+        with self._stage_lock:
+            row, n = self._stage_poly(poly)
+            self._chk(self._lib.kzg_commit(self._h, i, row, n, int(evaluation_form), out))
+        return out.raw
+
+    def open_list(self, i: int, poly: Sequence[str], alpha_be32: bytes, evaluation_form: bool = True) -> Tuple[bytes, bytes]:
+        ev, pf = ctypes.create_string_buffer(32), ctypes.create_string_buffer(48)
+        with self._stage_lock:
+            row, n = self._stage_poly(poly)
+            self._chk(self._lib.kzg_open(self._h, i, row, n, int(evaluation_form), alpha_be32, ev, pf))
+        return ev.raw, pf.raw
+
+    def commit_open_list(self, i: int, poly: Sequence[str], alpha_be32: bytes,
+                         evaluation_form: bool = True) -> Tuple[bytes, bytes, bytes]:
+        c, ev, pf = ctypes.create_string_buffer(48), ctypes.create_string_buffer(32), ctypes.create_string_buffer(48)
+        with self._stage_lock:
+            row, n = self._stage_poly(poly)
+            self._chk(self._lib.kzg_commit_open(self._h, i, row, n, int(evaluation_form), alpha_be32, c, ev, pf))
         return c.raw, ev.raw, pf.raw
 
     def msm(self, scalars_be32: bytes, srs_offset: int = 0) -> bytes:
