@@ -389,8 +389,8 @@ int commit_open_dev(kzg_ctx* ctx, uint32_t i, const uint32_t* row_dev, uint64_t 
         HIPCHK(ctx, hipMemcpyAsync(small + 320, alpha_be32, 32, hipMemcpyHostToDevice, so));
         launch_fr_from_be(so, small + 320, alpha_m, 1, 1, ctx->flags);
         const uint64_t nchunks = (T + 3) / 4;
-        HIPCHK(ctx, ctx->hbuf.ensure(nchunks * 32));
-        HIPCHK(ctx, ctx->hnext.ensure(nchunks * 32));
+        HIPCHK(ctx, ctx->hbuf.ensure((nchunks + (nchunks >> 3) + 64) * 32));
+        HIPCHK(ctx, ctx->hnext.ensure((nchunks + (nchunks >> 3) + 64) * 32));
         HIPCHK(ctx, ctx->qbuf.ensure(T * 32));
         {
             Span sp(ctx, KZG_T_POLY, so);
@@ -846,8 +846,8 @@ int kzg_eval(kzg_ctx* ctx, const uint8_t* coeffs_be32, uint64_t n, const uint8_t
     HIPCHK(ctx, ctx->coeffA.ensure(n * 32));
     HIPCHK(ctx, ctx->small.ensure(1024));
     const uint64_t nchunks = (n + 3) / 4;
-    HIPCHK(ctx, ctx->hbuf.ensure(nchunks * 32));
-    HIPCHK(ctx, ctx->hnext.ensure(nchunks * 32));
+    HIPCHK(ctx, ctx->hbuf.ensure((nchunks + (nchunks >> 3) + 64) * 32));
+    HIPCHK(ctx, ctx->hnext.ensure((nchunks + (nchunks >> 3) + 64) * 32));
     rc = upload_fr(ctx, coeffs_be32, n, ctx->coeffA.as<uint32_t>(), 1);
     if (rc) return rc;
     uint8_t* small = ctx->small.as<uint8_t>();

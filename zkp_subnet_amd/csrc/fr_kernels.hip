@@ -98,66 +98,114 @@ __global__ void k_fr_inv_pow2(uint32_t* __restrict__ out, int log_n) {
 }
 
 // ------------------------------------------------------------------------------------------------ NTT
-__global__ void __launch_bounds__(256) k_fr_bitrev(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                    int log_n) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >> log_n) return;
-    uint64_t j = log_n ? (__brevll(i) >> (64 - log_n)) : 0;
-    fr_t v;
-    fr_load(v, in + 8 * i);
-    fr_store(out + 8 * j, v);
-}
+// Radix-2 DIT network (bit-reversed input order -> natural output), run as a few PASSES of up to 8 stages; a pass
+// stages a tile of 2^S "rows" x C "columns" (at most 1024 elements = 32 KB) in LDS, so every pass costs one HBM read
+// and one HBM write of the vector: 3 passes at 2^22 (8+7+7) instead of bit reversal + 1 LDS pass + 12 global stages.
+//   * first pass (stages 0..S-1): the bit reversal is folded into its load.  Output tile t (2^S contiguous elements)
+//     is in[brev_S(r) * NT + brev(t)], NT = n / 2^S tiles; a workgroup takes the C tiles whose brev(t) are adjacent,
+//     so that each source row is C contiguous elements (C x 32 B = 128 B), runs C independent 2^S-point networks and
+//     writes C contiguous tiles.
+//   * later passes (stages s0..s0+S-1), in place: row r of a tile = bits [s0, s0+S) of the index, the C columns are
+//     adjacent values of the low bits, the remaining high bits are fixed: again C x 32 B contiguous per row.
+// Stage s pairs i and i + 2^s with twiddle w_n^((i mod 2^s) << (log_n - s - 1)) from the n/2-entry table.  The last
+// pass also applies the 1/n of the inverse transform.
+#define NTT_PASS_LOG 8      // stages per pass (tile rows 2^S <= 256)
+#define NTT_TILE_ELEMS 1024 // rows x columns
+KZG_DEV uint32_t brev_bits(uint32_t v, int bits) { return bits ? (__brev(v) >> (32 - bits)) : 0u; }
 
-#define NTT_TILE_LOG 10
-#define NTT_TILE (1 << NTT_TILE_LOG)
-// Stages 0 .. S-1 (S = min(log_n, 10)) of the DIT network on a contiguous 2^S tile staged in LDS:
-// one HBM read + one HBM write for up to ten butterfly stages.
-__global__ void __launch_bounds__(256) k_fr_ntt_lds(uint32_t* __restrict__ data, int log_n,
-                                                     const uint32_t* __restrict__ tw) {
-    __shared__ uint4 sm[NTT_TILE * 2];  // 1024 x 32 B
-    const int S = log_n < NTT_TILE_LOG ? log_n : NTT_TILE_LOG;
-    const uint32_t tile = 1u << S;
-    const uint64_t base = (uint64_t)blockIdx.x * tile;
-    const uint4* src = reinterpret_cast<const uint4*>(data + 8 * base);
-    for (uint32_t i = threadIdx.x; i < tile * 2; i += blockDim.x) sm[i] = src[i];
+__global__ void __launch_bounds__(256) k_fr_ntt_pass(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                      int log_n, int s0, int S, int logC,
+                                                      const uint32_t* __restrict__ tw,
+                                                      const uint32_t* __restrict__ scale_or_null) {
+    __shared__ uint4 sm[NTT_TILE_ELEMS * 2];
+    const uint32_t R = 1u << S, C = 1u << logC, E = R << logC;
+    const bool first = s0 == 0;
+    const int log_nt = log_n - S;  // first pass: tiles
+    // ---- load
+    if (first) {
+        const uint64_t NT = (uint64_t)1 << log_nt;
+        const uint64_t u = blockIdx.x;
+        for (uint32_t e = threadIdx.x; e < E; e += 256) {
+            const uint32_t rp = e >> logC, c = e & (C - 1);  // source row, tile
+            const uint4* src = reinterpret_cast<const uint4*>(in + 8 * ((uint64_t)rp * NT + u * C + c));
+            const uint32_t slot = (c << S) + brev_bits(rp, S);  // LDS layout [tile][row]
+            sm[2 * slot] = src[0];
+            sm[2 * slot + 1] = src[1];
+        }
+    } else {
+        const uint64_t groups = ((uint64_t)1 << s0) >> logC;  // column groups per block of 2^(s0+S) elements
+        const uint64_t h = blockIdx.x / groups, cg = blockIdx.x - h * groups;
+        const uint64_t base = (h << (s0 + S)) + (cg << logC);
+        for (uint32_t e = threadIdx.x; e < E; e += 256) {
+            const uint32_t r = e >> logC, c = e & (C - 1);
+            const uint4* src = reinterpret_cast<const uint4*>(out + 8 * (base + ((uint64_t)r << s0) + c));
+            sm[2 * e] = src[0];  // LDS layout [row][column]
+            sm[2 * e + 1] = src[1];
+        }
+    }
     __syncthreads();
-    for (int s = 0; s < S; s++) {
-        const uint32_t half = 1u << s;
-        for (uint32_t b = threadIdx.x; b < tile / 2; b += blockDim.x) {
-            const uint32_t k = b & (half - 1);
-            const uint32_t i = ((b >> s) << (s + 1)) + k, j = i + half;
+    // ---- butterflies
+    const uint64_t col0 = first ? 0 : ((uint64_t)(blockIdx.x % (((uint64_t)1 << s0) >> logC)) << logC);
+    for (int l = 0; l < S; l++) {
+        const uint32_t half = 1u << l;
+        const int s = s0 + l;
+        for (uint32_t b = threadIdx.x; b < E / 2; b += 256) {
+            uint32_t ei, ej;
+            uint64_t k;
+            if (first) {
+                const uint32_t c = b >> (S - 1), bb = b & ((R >> 1) - 1);
+                const uint32_t kk = bb & (half - 1);
+                const uint32_t i = ((bb >> l) << (l + 1)) + kk;
+                ei = (c << S) + i;
+                ej = ei + half;
+                k = kk;
+            } else {
+                const uint32_t c = b & (C - 1), bb = b >> logC;
+                const uint32_t kk = bb & (half - 1);
+                const uint32_t i = ((bb >> l) << (l + 1)) + kk;
+                ei = (i << logC) + c;
+                ej = ei + (half << logC);
+                k = ((uint64_t)kk << s0) + col0 + c;
+            }
             fr_t u, v, w, t;
-            fr_load(u, reinterpret_cast<const uint32_t*>(&sm[2 * i]));
-            fr_load(v, reinterpret_cast<const uint32_t*>(&sm[2 * j]));
-            fr_load(w, tw + 8 * ((uint64_t)k << (log_n - s - 1)));
+            fr_load(u, reinterpret_cast<const uint32_t*>(&sm[2 * ei]));
+            fr_load(v, reinterpret_cast<const uint32_t*>(&sm[2 * ej]));
+            fr_load(w, tw + 8 * (k << (log_n - s - 1)));
             f_mul(t, v, w);
             f_add(v, u, t);
             f_sub(w, u, t);
-            fr_store(reinterpret_cast<uint32_t*>(&sm[2 * i]), v);
-            fr_store(reinterpret_cast<uint32_t*>(&sm[2 * j]), w);
+            fr_store(reinterpret_cast<uint32_t*>(&sm[2 * ei]), v);
+            fr_store(reinterpret_cast<uint32_t*>(&sm[2 * ej]), w);
         }
         __syncthreads();
     }
-    uint4* dst = reinterpret_cast<uint4*>(data + 8 * base);
-    for (uint32_t i = threadIdx.x; i < tile * 2; i += blockDim.x) dst[i] = sm[i];
-}
-// one global radix-2 stage s >= 10
-__global__ void __launch_bounds__(256) k_fr_ntt_stage(uint32_t* __restrict__ data, int log_n, int s,
-                                                       const uint32_t* __restrict__ tw) {
-    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >> (log_n - 1)) return;
-    const uint64_t half = (uint64_t)1 << s;
-    const uint64_t k = b & (half - 1);
-    const uint64_t i = ((b >> s) << (s + 1)) + k, j = i + half;
-    fr_t u, v, w, t;
-    fr_load(u, data + 8 * i);
-    fr_load(v, data + 8 * j);
-    fr_load(w, tw + 8 * (k << (log_n - s - 1)));
-    f_mul(t, v, w);
-    f_add(v, u, t);
-    f_sub(w, u, t);
-    fr_store(data + 8 * i, v);
-    fr_store(data + 8 * j, w);
+    // ---- store (+ 1/n on the last pass of an inverse transform)
+    fr_t f;
+    if (scale_or_null) fr_load(f, scale_or_null);
+    if (first) {
+        const uint32_t u = blockIdx.x;
+        const uint64_t tiles_per_c = ((uint64_t)1 << log_nt) >> logC;
+        const uint64_t t_low = brev_bits(u, log_nt - logC);
+        for (uint32_t e = threadIdx.x; e < E; e += 256) {
+            const uint32_t c = e >> S, r = e & (R - 1);
+            const uint64_t t = (uint64_t)brev_bits(c, logC) * tiles_per_c + t_low;
+            fr_t v;
+            fr_load(v, reinterpret_cast<const uint32_t*>(&sm[2 * e]));
+            if (scale_or_null) f_mul(v, v, f);
+            fr_store(out + 8 * ((t << S) + r), v);
+        }
+    } else {
+        const uint64_t groups = ((uint64_t)1 << s0) >> logC;
+        const uint64_t h = blockIdx.x / groups, cg = blockIdx.x - h * groups;
+        const uint64_t base = (h << (s0 + S)) + (cg << logC);
+        for (uint32_t e = threadIdx.x; e < E; e += 256) {
+            const uint32_t r = e >> logC, c = e & (C - 1);
+            fr_t v;
+            fr_load(v, reinterpret_cast<const uint32_t*>(&sm[2 * e]));
+            if (scale_or_null) f_mul(v, v, f);
+            fr_store(out + 8 * (base + ((uint64_t)r << s0) + c), v);
+        }
+    }
 }
 __global__ void __launch_bounds__(256) k_fr_scale(uint32_t* __restrict__ data, uint64_t n,
                                                    const uint32_t* __restrict__ factor) {
@@ -171,16 +219,16 @@ __global__ void __launch_bounds__(256) k_fr_scale(uint32_t* __restrict__ data, u
 }
 
 // ------------------------------------------------------------------------------------------------ eval + quotient
-// Chunk length L = 2^lchunk coefficients per lane: 64 for large polynomials (throughput), down to 4 for small rows
-// where the chunk loops are pure latency (a 2^12 row: 64-long serial Horner loops cost 0.2 ms, 8-long ones 0.03 ms).
+// Chunk length L = 2^lchunk coefficients per lane: 16 for large polynomials, down to 4 for small rows: the chunk loops
+// are chains of dependent Fr products (a lone wave needs ~1 us each), so short chunks + more levels beat long ones.
 static inline int poly_lchunk(uint64_t n) {
     int l = 2;
-    while (l < 6 && (n >> (l + 1)) >= 16384) l++;
+    while (l < 4 && (n >> (l + 1)) >= 16384) l++;
     return l;
 }
-// h[t] = sum_k f[t*L + k] alpha^k
+// h[t] = sum_k f[t*L + k] a^k with a = alpha^(2^sq)  (sq > 0: f is itself an array of chunk values, second level)
 __global__ void __launch_bounds__(256) k_poly_chunk_eval(const uint32_t* __restrict__ f, uint64_t n, int lchunk,
-                                                          const uint32_t* __restrict__ alpha_mont,
+                                                          const uint32_t* __restrict__ alpha_mont, int sq,
                                                           uint32_t* __restrict__ h) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t L = (uint64_t)1 << lchunk;
@@ -189,6 +237,7 @@ __global__ void __launch_bounds__(256) k_poly_chunk_eval(const uint32_t* __restr
     uint64_t hi = lo + L < n ? lo + L : n;
     fr_t a, s, c;
     fr_load(a, alpha_mont);
+    for (int i = 0; i < sq; i++) f_mul(a, a, a);
     f_zero(s);
     for (uint64_t j = hi; j-- > lo;) {
         fr_load(c, f + 8 * j);
@@ -251,6 +300,27 @@ __global__ void __launch_bounds__(1024) k_poly_chunk_scan(const uint32_t* __rest
     }
     if (v == 0) fr_store(y_mont, s);
 }
+// second level back down: hnext2[g] = H_{(g+1) * L2} over groups of L2 = 2^l2 first-level chunks -> hnext[u] = H_{u+1}
+__global__ void __launch_bounds__(256) k_poly_chunk_expand(const uint32_t* __restrict__ h, uint64_t nchunks, int l2,
+                                                            const uint32_t* __restrict__ alpha_mont, int sq,
+                                                            const uint32_t* __restrict__ hnext2,
+                                                            uint32_t* __restrict__ hnext) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t L = (uint64_t)1 << l2;
+    uint64_t lo = g * L;
+    if (lo >= nchunks) return;
+    uint64_t hi = lo + L < nchunks ? lo + L : nchunks;
+    fr_t beta, s, c;
+    fr_load(beta, alpha_mont);
+    for (int i = 0; i < sq; i++) f_mul(beta, beta, beta);
+    fr_load(s, hnext2 + 8 * g);
+    for (uint64_t u = hi; u-- > lo;) {
+        fr_store(hnext + 8 * u, s);
+        fr_load(c, h + 8 * u);
+        f_mul(s, s, beta);
+        f_add(s, s, c);
+    }
+}
 // q[j-1] = sum_{k>=j} f_k alpha^(k-j), written canonical (ready to be MSM scalars); q has n-1 entries
 __global__ void __launch_bounds__(256) k_poly_quotient(const uint32_t* __restrict__ f, uint64_t n, int lchunk,
                                                         const uint32_t* __restrict__ alpha_mont,
@@ -294,21 +364,55 @@ void launch_fr_inv_pow2(hipStream_t s, uint32_t* out, int log_n) { k_fr_inv_pow2
 void launch_fr_ntt(hipStream_t s, const uint32_t* in, uint32_t* out, int log_n, const uint32_t* tw,
                    const uint32_t* scale_or_null) {
     const uint64_t n = (uint64_t)1 << log_n;
-    k_fr_bitrev<<<nblk(n, 256), 256, 0, s>>>(in, out, log_n);
-    if (log_n >= 1) {
-        const int S = log_n < NTT_TILE_LOG ? log_n : NTT_TILE_LOG;
-        k_fr_ntt_lds<<<(uint32_t)(n >> S), 256, 0, s>>>(out, log_n, tw);
-        for (int st = S; st < log_n; st++) k_fr_ntt_stage<<<nblk(n / 2, 256), 256, 0, s>>>(out, log_n, st, tw);
+    if (log_n == 0) {  // length 1: the transform is the identity (1/1 = 1)
+        (void)hipMemcpyAsync(out, in, 32, hipMemcpyDeviceToDevice, s);
+        return;
     }
-    if (scale_or_null) k_fr_scale<<<nblk(n, 256), 256, 0, s>>>(out, n, scale_or_null);
+    // split log_n into ceil(log_n / 8) passes of near-equal depth (22 -> 8 + 7 + 7)
+    const int passes = (log_n + NTT_PASS_LOG - 1) / NTT_PASS_LOG;
+    int s0 = 0;
+    for (int p = 0; p < passes; p++) {
+        const int S = (log_n - s0 + (passes - p) - 1) / (passes - p);
+        // columns: as many as the 1024-element tile allows, bounded by what exists (tiles / low-bit range)
+        int logC = 10 - S;
+        const int avail = p == 0 ? log_n - S : s0;
+        if (logC > avail) logC = avail;
+        if (p == 0 && logC > 2) logC = 2;  // first pass: 4 tiles (128 B source rows) keep the tiles' stores long
+        const uint64_t blocks = n >> (S + logC);
+        k_fr_ntt_pass<<<(uint32_t)blocks, 256, 0, s>>>(in, out, log_n, s0, S, logC, tw,
+                                                       p == passes - 1 ? scale_or_null : nullptr);
+        s0 += S;
+    }
 }
 void launch_poly_open(hipStream_t s, const uint32_t* f_mont, uint64_t n, const uint32_t* alpha_mont, uint32_t* h,
                       uint32_t* hnext, uint32_t* y_mont, uint32_t* q_canon_or_null) {
     if (!n) return;
-    const int lchunk = poly_lchunk(n);
-    const uint64_t nchunks = (n + ((uint64_t)1 << lchunk) - 1) >> lchunk;
-    k_poly_chunk_eval<<<nblk(nchunks, 256), 256, 0, s>>>(f_mont, n, lchunk, alpha_mont, h);
-    k_poly_chunk_scan<<<1, 1024, 0, s>>>(h, nchunks, lchunk, alpha_mont, hnext, y_mont);
+    // Level 0 folds 2^l0 coefficients per lane, every further level 16 values of the level below, until at most 2048
+    // values are left for the single-workgroup scan; then the suffix values H are expanded back down level by
+    // level.  Every serial loop is <= 16 long (each step is one dependent Fr product, ~1 us for a lone wave), and
+    // all levels but the scan fill the GPU.  The level arrays are stacked in h / hnext (api.hip sizes them for
+    // (n+3)/4 * 9/8 + 64 entries; the levels above the first sum to < 1/15 of it).
+    const int l0 = poly_lchunk(n);
+    int lv_l[12], lv_sq[12];
+    uint64_t lv_n[12], lv_off[12];
+    int K = 1;
+    lv_l[0] = l0; lv_sq[0] = 0; lv_n[0] = n; lv_off[0] = 0;           // level 0 = f itself (offset unused)
+    lv_n[1] = (n + ((uint64_t)1 << l0) - 1) >> l0; lv_sq[1] = l0; lv_off[1] = 0;
+    k_poly_chunk_eval<<<nblk(lv_n[1], 256), 256, 0, s>>>(f_mont, n, l0, alpha_mont, 0, h);
+    while (lv_n[K] > 2048 && K < 10) {
+        lv_l[K] = 4;
+        lv_n[K + 1] = (lv_n[K] + 15) >> 4;
+        lv_sq[K + 1] = lv_sq[K] + 4;
+        lv_off[K + 1] = lv_off[K] + lv_n[K];
+        k_poly_chunk_eval<<<nblk(lv_n[K + 1], 256), 256, 0, s>>>(h + 8 * lv_off[K], lv_n[K], 4, alpha_mont, lv_sq[K],
+                                                                 h + 8 * lv_off[K + 1]);
+        K++;
+    }
+    k_poly_chunk_scan<<<1, 1024, 0, s>>>(h + 8 * lv_off[K], lv_n[K], lv_sq[K], alpha_mont, hnext + 8 * lv_off[K], y_mont);
+    for (int k = K - 1; k >= 1; k--)
+        k_poly_chunk_expand<<<nblk(lv_n[k + 1], 256), 256, 0, s>>>(h + 8 * lv_off[k], lv_n[k], lv_l[k], alpha_mont,
+                                                                   lv_sq[k], hnext + 8 * lv_off[k + 1],
+                                                                   hnext + 8 * lv_off[k]);
     if (q_canon_or_null)
-        k_poly_quotient<<<nblk(nchunks, 256), 256, 0, s>>>(f_mont, n, lchunk, alpha_mont, hnext, q_canon_or_null);
+        k_poly_quotient<<<nblk(lv_n[1], 256), 256, 0, s>>>(f_mont, n, l0, alpha_mont, hnext, q_canon_or_null);
 }
