@@ -189,13 +189,18 @@ void set_window(kzg_ctx* ctx, int c) {
     ctx->c = base + (extra ? 1 : 0);
     ctx->nbuckets = 1u << (ctx->c - 1);
 }
-// sorted entries per accumulate lane: the grid is a whole number of "rounds" of 131072 lanes (2 waves per SIMD on
-// 256 CUs) so that the last round is not a partially filled tail; chunks stay <= 512 entries
+// sorted entries per accumulate lane.  Large MSMs (throughput-bound): the grid is a whole number of "rounds" of 131072
+// lanes (2 waves per SIMD on 256 CUs: the second wave hides the point loads) so that the last round is not a partially
+// filled tail; chunks stay <= 512 entries.  Small MSMs (latency-bound: one wave already saturates a SIMD's integer
+// issue, ~10.5 us per mixed addition): 65536 lanes = one wave per SIMD, which halves the number of carries to fold.
 int pick_chunk(uint64_t entries) {
     const uint64_t lanes = 131072;
+    if (entries <= lanes * 16) {
+        const uint64_t k = (entries + lanes / 2 - 1) / (lanes / 2);
+        return (int)(k < 8 ? 8 : k);
+    }
     const uint64_t rounds = (entries + lanes * 512 - 1) / (lanes * 512);
-    uint64_t k = (entries + lanes * rounds - 1) / (lanes * (rounds ? rounds : 1));
-    if (k < 8) k = 8;
+    const uint64_t k = (entries + lanes * rounds - 1) / (lanes * rounds);
     return (int)k;
 }
 int ilog2_exact(uint64_t n) {
