@@ -72,7 +72,11 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 16): the box's CPU share for one GPU")
     ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
                     help="msm20: MSM requests in flight per GPU in the timed region (1 = one request at a time, the "
-                         "default; 2 = the library's two lanes).  The other mode is reported in `pipelined`.")
+                         "default; 2 = the library's two lanes)")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="msm20: after the timed region, time the same K steps again with two requests in flight and "
+                         "report them as `pipelined` (off by default so that every k_msm_accumulate launch of the "
+                         "default run is an uncontended one and rocprofv3's average matches `roofline.kernel_ms`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adversarial", action="store_true", help="skip the separately reported adversarial inputs")
     args = ap.parse_args()
@@ -194,7 +198,7 @@ def main():
     # the same K steps with two requests in flight on the library's two lanes (MSM i+1's sort/accumulate overlaps the
     # latency-bound tail of MSM i): reported beside the headline, never mixed into it
     pipelined = None
-    if args.workload == "msm20" and depth == 1:
+    if args.workload == "msm20" and depth == 1 and args.pipelined:
         state["depth"] = 2
         run_steps(args.warmup, False)
         barrier()

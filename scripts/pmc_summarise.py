@@ -1,0 +1,37 @@
+"""Average the rocprofv3 --pmc counter values per kernel and dispatch (input: the directory scripts/pmc_round.sh
+fills) into one CSV, and derive profiles/pmc_traffic.json for the dominant kernel (2 x FETCH_SIZE + WRITE_SIZE,
+the gfx950 correction of MI355X_MICROARCH.md's HBM section)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+src, out_csv = sys.argv[1], sys.argv[2]
+acc = {}
+for path in glob.glob(os.path.join(src, "*", "*counter_collection.csv")):
+    for r in csv.DictReader(open(path)):
+        k = (r["Kernel_Name"].split("(")[0], r["Counter_Name"])
+        d = acc.setdefault(k, {})
+        d[r["Dispatch_Id"]] = d.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+with open(out_csv, "w") as f:
+    f.write("# rocprofv3 --pmc <group> --kernel-trace, one pass per counter group (scripts/pmc_round.sh): python3 bench.py "
+            "--steps 3 --warmup 1 --no-cpu-baseline --no-adversarial (2^20 MSM, c=20)\n")
+    f.write("# raw counter values per dispatch, averaged over dispatches; FETCH_SIZE/WRITE_SIZE in KB; gfx950: FETCH_SIZE "
+            "under-reports wide coalesced reads by 2x\n")
+    f.write("kernel,counter,dispatches,avg_per_dispatch\n")
+    for (kern, ctr), d in sorted(acc.items()):
+        f.write(f"{kern},{ctr},{len(d)},{sum(d.values()) / len(d):.1f}\n")
+fs = acc.get(("k_msm_accumulate", "FETCH_SIZE"))
+ws = acc.get(("k_msm_accumulate", "WRITE_SIZE"))
+if fs and ws:
+    fkb, wkb = sum(fs.values()) / len(fs), sum(ws.values()) / len(ws)
+    cfg = json.loads(open(glob.glob(os.path.join(src, "FETCH_SIZE.json"))[0]).read().strip().splitlines()[-1])["config"]
+    json.dump({"workload": "msm20", "points_per_gpu": cfg["points_per_gpu"], "window_bits": cfg["window_bits"],
+               "kernel": "k_msm_accumulate", "fetch_size_kb_raw": fkb, "write_size_kb_raw": wkb,
+               "traffic_bytes_per_launch": 2 * fkb * 1024 + wkb * 1024,
+               "correction": "2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE counts 128-B requests as 64 B; "
+                             "MI355X_MICROARCH.md HBM section)",
+               "source": os.path.relpath(out_csv)},
+              open(os.path.join(os.path.dirname(out_csv), "pmc_traffic.json"), "w"), indent=1)
+    print("traffic bytes/launch", 2 * fkb * 1024 + wkb * 1024)

@@ -2,6 +2,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/prof
 cd $R
+python bench.py --pipelined --no-cpu-baseline --no-adversarial > gpurun_out/prof/bench_msm20_pipelined.json 2>/dev/null
 python bench.py > gpurun_out/prof/bench_msm20.json 2> gpurun_out/prof/bench_msm20.err
 python bench.py --workload kzg22 > gpurun_out/prof/bench_kzg22.json 2> gpurun_out/prof/bench_kzg22.err
 python bench.py --workload kzg22 --log-n 12 > gpurun_out/prof/bench_kzg12.json 2>/dev/null
