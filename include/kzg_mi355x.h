@@ -52,6 +52,12 @@ int kzg_get_window_layout(kzg_ctx* ctx, int32_t* out_offsets, int max);
  *      T = 2^(scale-machines_scale) points each, slice k at points [k*T, (k+1)*T).  Points stay resident
  *      ("cached SRS") together with their window multiples 2^off[w] P. */
 int kzg_load_srs(kzg_ctx* ctx, const uint8_t* g1_affine_be96, uint64_t n_points, int scale, int machines_scale);
+/* Same, from a ZCash-compressed file (48 bytes per point: flags 0x80 compressed | 0x40 infinity | 0x20 y-sign, x
+ * big-endian) -- the reference's `uncompressed=False` setup files (base/miner.py:75-81, utils/config.py:131-150).
+ * The y coordinates are recovered on the GPU (one Fp square root per point); a non-residue, x >= p or malformed flags
+ * fail the load with KZG_E_POINT. */
+int kzg_load_srs_compressed(kzg_ctx* ctx, const uint8_t* g1_c48, uint64_t n_points, int scale, int machines_scale);
+
 /* synthetic SRS with known discrete logs (tests / benches; stands in for `fourier setup --generate-setup`,
  * reference tests/conftest.py:50-65): slice k, point j = [s0_k * tau^j] G.  s0_be32: n_slices x 32 bytes. */
 int kzg_gen_srs(kzg_ctx* ctx, const uint8_t tau_be32[32], const uint8_t* s0_be32, uint32_t n_slices, int scale,
@@ -59,6 +65,7 @@ int kzg_gen_srs(kzg_ctx* ctx, const uint8_t tau_be32[32], const uint8_t* s0_be32
 uint64_t kzg_srs_points(kzg_ctx* ctx);
 /* read back resident points: window w multiple of points [first, first+count) as affine be96 */
 int kzg_srs_read(kzg_ctx* ctx, int w, uint64_t first, uint64_t count, uint8_t* out_be96);
+int kzg_srs_read_compressed(kzg_ctx* ctx, int w, uint64_t first, uint64_t count, uint8_t* out_c48);
 
 /* ---- hot path.  worker index i selects slice i of the resident SRS. */
 /* replaces Client.worker_commit(i, poly)            (reference neurons/miner.py:38-45) */

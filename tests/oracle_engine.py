@@ -21,8 +21,10 @@ class OracleEngine:
     def slice_len(self):
         return 1 << (self.scale - self.machines_scale)
 
-    def load_srs(self, g1_be96, scale, machines_scale):
-        self.srs, self.scale, self.machines_scale = g1_be96, scale, machines_scale
+    def load_srs(self, points, scale, machines_scale, compressed=False):
+        if compressed:
+            points = b"".join(o.g1_to_be96(o.g1_decompress(points[48 * k:48 * k + 48])) for k in range(len(points) // 48))
+        self.srs, self.scale, self.machines_scale = points, scale, machines_scale
 
     def gen_srs(self, tau_x, tau_y, scale, machines_scale, workers=None):
         if workers is None:

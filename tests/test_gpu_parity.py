@@ -452,6 +452,38 @@ def test_client_and_miner_on_hip_engine(hip, fr_kat):
     miner.stop()
 
 
+def test_compressed_srs_load_and_read(hip):
+    """ZCash-compressed setup files (reference `uncompressed=False`, base/miner.py:75-81): the GPU recovers every y by
+    a square root; result identical to loading the uncompressed points; malformed encodings fail the load."""
+    from zkp_subnet_amd._native import KzgError, KZG_E_POINT
+    tx = 0xC0FFEE
+    n = 256
+    pts = [o.g1_table().mul(pow(tx, j, o.R)) for j in range(n - 1)] + [None]         # last record: infinity
+    unc = b"".join(o.g1_to_be96(p) for p in pts)
+    cmp_ = b"".join(o.g1_compress(p) for p in pts)
+    assert sum(c[0] & 0x20 != 0 for c in (cmp_[48 * k:48 * k + 48] for k in range(n))) > 20   # both y signs occur
+    a, b = hip(), hip()
+    a.load_srs(unc, 8, 0)
+    b.load_srs(cmp_, 8, 0, compressed=True)
+    assert b.srs_read(0, n) == unc == a.srs_read(0, n)
+    assert a.srs_read(0, n, compressed=True) == cmp_ == b.srs_read(0, n, compressed=True)
+    s_b = rand_scalars_bytes(n, 91)
+    assert a.msm(s_b, 0) == b.msm(s_b, 0) == oc.msm(unc[:96 * (n - 1)], s_b[:32 * (n - 1)])   # infinity adds nothing
+    # an x with no point above it, an unreduced x, a missing compression flag, a dirty infinity
+    x = 1
+    while o.fp_sqrt((x ** 3 + 4) % o.P) is not None:
+        x += 1
+    no_point = bytearray(x.to_bytes(48, "big")); no_point[0] |= 0x80
+    unreduced = bytearray(o.P.to_bytes(48, "big")); unreduced[0] |= 0x80
+    no_flag = bytearray(cmp_[:48]); no_flag[0] &= 0x7F
+    dirty_inf = bytearray(48); dirty_inf[0] = 0xC0; dirty_inf[47] = 1
+    for bad in (no_point, unreduced, no_flag, dirty_inf):
+        with pytest.raises(KzgError) as ei:
+            hip().load_srs(bytes(bad) + cmp_[48:], 8, 0, compressed=True)
+        assert ei.value.code == KZG_E_POINT
+    a.close(); b.close()
+
+
 def test_setup_cli_file_roundtrip_through_client(hip, tmp_path, fr_kat):
     """`setup` writes the SRS + verifier key files on the GPU; a fresh Client loads them (the reference's
     tests/conftest.py:50-65 flow) and commit / open / verify agree with a Client that generated the same SRS in memory."""
@@ -476,5 +508,17 @@ def test_setup_cli_file_roundtrip_through_client(hip, tmp_path, fr_kat):
             assert r.json()["valid"] is True
         with from_file.worker_verify((i + 1) % 4, body["proof"], fr_kat["point"], body["eval"], body["commitment"]) as r:
             assert r.json()["valid"] is False
+    # the same setup written compressed and loaded with the reference's uncompressed=False flag
+    cpath = str(tmp_path / "test_setup.compressed")
+    assert setup_cli.main(["setup", "--setup-path", cpath, "--scale", "6", "--machines-scale", "2", "--generate-setup",
+                           "--compressed", "--seed", "42"]) == 0
+    assert os.path.getsize(cpath) == 64 * 48
+    from_c = Client(setup_path=cpath, uncompressed=False)
+    from_c.start(scale=6, machines_scale=2)
+    with from_c.worker_commit_and_open(3, fr_kat["poly"], fr_kat["point"]) as c:
+        assert c.status_code == 200 and c.json() == body
+    with from_c.worker_verify(3, body["proof"], fr_kat["point"], body["eval"], body["commitment"]) as r:
+        assert r.json()["valid"] is True
+    from_c.stop()
     from_file.stop()
     in_memory.stop()

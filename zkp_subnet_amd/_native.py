@@ -25,9 +25,11 @@ SYMBOLS = {
     "kzg_get_window": (_I, [_P]),
     "kzg_get_window_layout": (_I, [_P, ctypes.POINTER(ctypes.c_int32), _I]),
     "kzg_load_srs": (_I, [_P, _B, _U64, _I, _I]),
+    "kzg_load_srs_compressed": (_I, [_P, _B, _U64, _I, _I]),
     "kzg_gen_srs": (_I, [_P, _B, _B, _U32, _I, _I]),
     "kzg_srs_points": (_U64, [_P]),
     "kzg_srs_read": (_I, [_P, _I, _U64, _U64, _B]),
+    "kzg_srs_read_compressed": (_I, [_P, _I, _U64, _U64, _B]),
     "kzg_commit": (_I, [_P, _U32, _B, _U64, _I, _B]),
     "kzg_open": (_I, [_P, _U32, _B, _U64, _I, _B, _B, _B]),
     "kzg_commit_open": (_I, [_P, _U32, _B, _U64, _I, _B, _B, _B, _B]),

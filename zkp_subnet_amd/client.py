@@ -65,8 +65,8 @@ def _guard(fn):
 
 class Client:
     """Drop-in for fourier.Client.  `port` and `bin` are accepted and ignored (there is no child process);
-    `setup_path` names a file of uncompressed affine G1 points (x||y, 96 B each, big-endian) holding the
-    2^scale-point SRS; when it does not exist a synthetic tau-derived SRS is generated on the GPU from `seed`
+    `setup_path` names a file holding the 2^scale-point SRS as uncompressed affine G1 points (x||y, 96 B each,
+    big-endian) or, with `uncompressed=False`, as 48-byte ZCash-compressed points (decompressed on the GPU); when it does not exist a synthetic tau-derived SRS is generated on the GPU from `seed`
     (tests / benches -- mirrors `fourier setup --generate-setup`, reference tests/conftest.py:50-65)."""
 
     def __init__(self, port: int = 1337, bin: str = "", uncompressed: bool = True, setup_path: str = "",
@@ -93,9 +93,11 @@ class Client:
         if self.setup_path and os.path.exists(self.setup_path):
             with open(self.setup_path, "rb") as f:
                 data = f.read()
-            if len(data) % 96:
-                raise ValueError("setup file must be a whole number of 96-byte affine G1 points")
-            self.engine.load_srs(data, scale, machines_scale)
+            rec = 96 if self.uncompressed else 48      # the reference's `uncompressed` flag (base/miner.py:77)
+            if len(data) % rec:
+                raise ValueError(f"setup file must be a whole number of {rec}-byte G1 points "
+                                 f"(uncompressed={self.uncompressed})")
+            self.engine.load_srs(data, scale, machines_scale, compressed=not self.uncompressed)
             self._slice_of = None
             vk_path = self.setup_path + ".vk"   # 192 B [tau_x]_2 (uncompressed) + one 96 B [L_i(tau_y)]_1 per slice
             if os.path.exists(vk_path) and hasattr(self.engine, "set_verifier_key"):

@@ -622,8 +622,9 @@ int kzg_get_window_layout(kzg_ctx* ctx, int32_t* out_offsets, int max) {
 }
 uint64_t kzg_srs_points(kzg_ctx* ctx) { return ctx ? ctx->stride : 0; }
 
-int kzg_load_srs(kzg_ctx* ctx, const uint8_t* g1_affine_be96, uint64_t n_points, int scale, int machines_scale) {
-    if (!ctx || !g1_affine_be96) return KZG_E_ARG;
+static int load_srs_common(kzg_ctx* ctx, const uint8_t* data, uint64_t n_points, int scale, int machines_scale,
+                           bool compressed) {
+    if (!ctx || !data) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (int busy = need_idle(ctx)) return busy;
@@ -632,13 +633,17 @@ int kzg_load_srs(kzg_ctx* ctx, const uint8_t* g1_affine_be96, uint64_t n_points,
     rc = clear_flags(ctx);
     if (rc) return rc;
     const uint64_t tile = (uint64_t)1 << 20;
-    HIPCHK(ctx, ctx->in_be.ensure((n_points < tile ? n_points : tile) * 96));
+    const size_t rec = compressed ? 48 : 96;
+    HIPCHK(ctx, ctx->in_be.ensure((n_points < tile ? n_points : tile) * rec));
     for (uint64_t first = 0; first < n_points; first += tile) {
         uint64_t cnt = n_points - first < tile ? n_points - first : tile;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->in_be.p, g1_affine_be96 + 96 * first, cnt * 96, hipMemcpyHostToDevice,
-                                   ctx->stream));
-        launch_srs_from_be96(ctx->stream, ctx->in_be.as<uint8_t>(), ctx->table.as<g1_affine_t>() + first, cnt,
-                             ctx->flags + 1);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->in_be.p, data + rec * first, cnt * rec, hipMemcpyHostToDevice, ctx->stream));
+        if (compressed)
+            launch_srs_from_c48(ctx->stream, ctx->in_be.as<uint8_t>(), ctx->table.as<g1_affine_t>() + first, cnt,
+                                ctx->flags + 1);
+        else
+            launch_srs_from_be96(ctx->stream, ctx->in_be.as<uint8_t>(), ctx->table.as<g1_affine_t>() + first, cnt,
+                                 ctx->flags + 1);
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     rc = finish(ctx);
@@ -648,6 +653,12 @@ int kzg_load_srs(kzg_ctx* ctx, const uint8_t* g1_affine_be96, uint64_t n_points,
         return rc;
     }
     return precompute_tables(ctx);
+}
+int kzg_load_srs(kzg_ctx* ctx, const uint8_t* g1_affine_be96, uint64_t n_points, int scale, int machines_scale) {
+    return load_srs_common(ctx, g1_affine_be96, n_points, scale, machines_scale, false);
+}
+int kzg_load_srs_compressed(kzg_ctx* ctx, const uint8_t* g1_c48, uint64_t n_points, int scale, int machines_scale) {
+    return load_srs_common(ctx, g1_c48, n_points, scale, machines_scale, true);
 }
 
 int kzg_gen_srs(kzg_ctx* ctx, const uint8_t tau_be32[32], const uint8_t* s0_be32, uint32_t n_slices, int scale,
@@ -690,8 +701,8 @@ int kzg_gen_srs(kzg_ctx* ctx, const uint8_t tau_be32[32], const uint8_t* s0_be32
     return precompute_tables(ctx);
 }
 
-int kzg_srs_read(kzg_ctx* ctx, int w, uint64_t first, uint64_t count, uint8_t* out_be96) {
-    if (!ctx || !out_be96) return KZG_E_ARG;
+static int srs_read_common(kzg_ctx* ctx, int w, uint64_t first, uint64_t count, uint8_t* out, bool compressed) {
+    if (!ctx || !out) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (int busy = need_idle(ctx)) return busy;
@@ -699,12 +710,20 @@ int kzg_srs_read(kzg_ctx* ctx, int w, uint64_t first, uint64_t count, uint8_t* o
     if (rc) return rc;
     if (w < 0 || w >= ctx->nwin || first + count > ctx->stride) return fail(ctx, KZG_E_ARG, "srs_read out of range");
     if (!count) return KZG_OK;
-    HIPCHK(ctx, ctx->out_be.ensure(count * 96));
-    launch_srs_to_be96(ctx->stream, ctx->table.as<g1_affine_t>() + (uint64_t)w * ctx->stride + first,
-                       ctx->out_be.as<uint8_t>(), count);
-    HIPCHK(ctx, hipMemcpyAsync(out_be96, ctx->out_be.p, count * 96, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t rec = compressed ? 48 : 96;
+    HIPCHK(ctx, ctx->out_be.ensure(count * rec));
+    const g1_affine_t* src = ctx->table.as<g1_affine_t>() + (uint64_t)w * ctx->stride + first;
+    if (compressed) launch_srs_to_c48(ctx->stream, src, ctx->out_be.as<uint8_t>(), count);
+    else launch_srs_to_be96(ctx->stream, src, ctx->out_be.as<uint8_t>(), count);
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->out_be.p, count * rec, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return KZG_OK;
+}
+int kzg_srs_read(kzg_ctx* ctx, int w, uint64_t first, uint64_t count, uint8_t* out_be96) {
+    return srs_read_common(ctx, w, first, count, out_be96, false);
+}
+int kzg_srs_read_compressed(kzg_ctx* ctx, int w, uint64_t first, uint64_t count, uint8_t* out_c48) {
+    return srs_read_common(ctx, w, first, count, out_c48, true);
 }
 
 static int msm_host_common(kzg_ctx* ctx, const uint8_t* scalars_be32, uint64_t n, uint64_t srs_offset, uint8_t* out,

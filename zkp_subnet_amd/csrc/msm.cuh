@@ -62,6 +62,8 @@ void launch_xyzz_unpack(hipStream_t s, const uint32_t* in48w, g1_xyzz_t* out, ui
 
 // SRS plumbing
 void launch_srs_from_be96(hipStream_t s, const uint8_t* be96, g1_affine_t* out, uint64_t n, uint32_t* bad_flag);
+void launch_srs_from_c48(hipStream_t s, const uint8_t* c48, g1_affine_t* out, uint64_t n, uint32_t* bad_flag);
+void launch_srs_to_c48(hipStream_t s, const g1_affine_t* in, uint8_t* c48, uint64_t n);
 void launch_srs_to_be96(hipStream_t s, const g1_affine_t* in, uint8_t* be96, uint64_t n);
 // window tables for points [first, first+count): tmp holds (nwin-1)*count XYZZ values
 void launch_srs_precompute(hipStream_t s, g1_affine_t* table, uint64_t stride, uint64_t first, uint64_t count,

@@ -751,6 +751,80 @@ __global__ void __launch_bounds__(256) k_srs_from_be96(const uint8_t* __restrict
     if (!fp_is_zero_n(chk)) atomicOr(bad, 2u);
     g1_store_aff(&out[j], p);
 }
+// ---- ZCash-compressed SRS files (the reference's `uncompressed=False` setup files: base/miner.py:75-81,
+// utils/config.py:131-150): 48 bytes per point, flags compressed 0x80 | infinity 0x40 | y-sign 0x20, x big-endian.
+// y = (x^3 + 4)^((p+1)/4) (p = 3 mod 4); a non-residue, x >= p or malformed flags fail the load.
+KZG_DEV void fp_pow_p_plus_1_over_4(fp_t& r, const fp_t& a) {
+    fp_t acc;
+    fp_one(acc);
+    for (int i = 378; i >= 0; i--) {  // (p+1)/4 has 379 bits; bit i of it is bit i+2 of p+1
+        fp_sqr(acc, acc);
+        const int b = i + 2;
+        uint32_t w = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) w = (k == (b >> 5)) ? (k == 0 ? FpParams::mod(0) + 1u : FpParams::mod(k)) : w;
+        if ((w >> (b & 31)) & 1u) fp_mul(acc, acc, a);
+    }
+    r = acc;
+}
+KZG_DEV bool fp_mont_is_larger(const fp_t& y_mont) {  // y > (p-1)/2 for the canonical integer behind y_mont
+    fp_t yc;
+    fp_from_mont(yc, y_mont);
+    uint32_t y[12], t[12], pm[12];
+    fp_pack(y, yc);
+    const uint32_t c = bi_add<12>(t, y, y);
+#pragma unroll
+    for (int i = 0; i < 12; i++) pm[i] = FpParams::mod(i);
+    return c || bi_ge<12>(t, pm);
+}
+__global__ void __launch_bounds__(256) k_srs_from_c48(const uint8_t* __restrict__ c48, g1_affine_t* __restrict__ out,
+                                                       uint64_t n, uint32_t* __restrict__ bad) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t w[12], pm[12];
+    limbs_from_be<12>(w, c48 + 48 * j);  // w[11] holds the flag bits
+    const uint32_t flags = w[11] >> 29;
+    w[11] &= 0x1fffffffu;
+    g1_aff28 p;
+    fp_zero(p.x); fp_zero(p.y);
+    if (!(flags & 4u)) atomicOr(bad, 1u);  // not a compressed encoding
+    if (flags & 2u) {                      // infinity: every other bit must be clear
+        uint32_t any = flags & 1u;
+#pragma unroll
+        for (int i = 0; i < 12; i++) any |= w[i];
+        if (any) atomicOr(bad, 1u);
+        g1_store_aff(&out[j], p);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) pm[i] = FpParams::mod(i);
+    if (bi_ge<12>(w, pm)) atomicOr(bad, 1u);
+    fp_t xr, x3, four, y2, y, t, one, chk;
+    fp_unpack(xr, w);
+    fp_to_mont(p.x, xr);
+    fp_canon(p.x, p.x);
+    fp_sqr(x3, p.x); fp_mul(x3, x3, p.x);
+    fp_one(one);
+    fp_dbl(four, one); fp_dbl(four, four);
+    fp_add(t, x3, four);
+    fp_mul(y2, t, one);                    // normalised x^3 + 4
+    fp_pow_p_plus_1_over_4(y, y2);
+    fp_sqr(t, y);
+    fp_sub4(t, t, y2);
+    fp_mul(chk, t, one);
+    if (!fp_is_zero_n(chk)) atomicOr(bad, 2u);  // x^3 + 4 is not a square: no such point
+    fp_canon(p.y, y);
+    if (fp_mont_is_larger(p.y) != ((flags & 1u) != 0)) fp_neg_canon(p.y, p.y);
+    g1_store_aff(&out[j], p);
+}
+__global__ void __launch_bounds__(256) k_srs_to_c48(const g1_affine_t* __restrict__ in, uint8_t* __restrict__ c48,
+                                                     uint64_t n) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    g1_aff28 p;
+    g1_load_aff(p, &in[j]);
+    g1_compress(c48 + 48 * j, p);
+}
 __global__ void __launch_bounds__(256) k_srs_to_be96(const g1_affine_t* __restrict__ in, uint8_t* __restrict__ be,
                                                       uint64_t n) {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1024,6 +1098,14 @@ void launch_xyzz_unpack(hipStream_t s, const uint32_t* in48w, g1_xyzz_t* out, ui
 void launch_srs_from_be96(hipStream_t s, const uint8_t* be96, g1_affine_t* out, uint64_t n, uint32_t* bad_flag) {
     if (!n) return;
     k_srs_from_be96<<<nblk(n, 256), 256, 0, s>>>(be96, out, n, bad_flag);
+}
+void launch_srs_from_c48(hipStream_t s, const uint8_t* c48, g1_affine_t* out, uint64_t n, uint32_t* bad_flag) {
+    if (!n) return;
+    k_srs_from_c48<<<nblk(n, 256), 256, 0, s>>>(c48, out, n, bad_flag);
+}
+void launch_srs_to_c48(hipStream_t s, const g1_affine_t* in, uint8_t* c48, uint64_t n) {
+    if (!n) return;
+    k_srs_to_c48<<<nblk(n, 256), 256, 0, s>>>(in, c48, n);
 }
 void launch_srs_to_be96(hipStream_t s, const g1_affine_t* in, uint8_t* be96, uint64_t n) {
     if (!n) return;

@@ -86,8 +86,12 @@ class HipEngine:
         return 1 << (self.scale - self.machines_scale)
 
     # ------------------------------------------------------------------ SRS
-    def load_srs(self, g1_be96: bytes, scale: int, machines_scale: int) -> None:
-        self._chk(self._lib.kzg_load_srs(self._h, g1_be96, len(g1_be96) // 96, scale, machines_scale))
+    def load_srs(self, points: bytes, scale: int, machines_scale: int, compressed: bool = False) -> None:
+        """`points`: 96-byte uncompressed affine records, or 48-byte ZCash-compressed ones (`compressed=True`)."""
+        if compressed:
+            self._chk(self._lib.kzg_load_srs_compressed(self._h, points, len(points) // 48, scale, machines_scale))
+        else:
+            self._chk(self._lib.kzg_load_srs(self._h, points, len(points) // 96, scale, machines_scale))
         self.scale, self.machines_scale = scale, machines_scale
         self.verifier = None
 
@@ -123,9 +127,10 @@ class HipEngine:
             raise NotImplementedError("no verifier key: call set_verifier_key() after load_srs()")
         return self.verifier.verify(i, proof48, alpha32, eval32, commitment48)
 
-    def srs_read(self, first: int, count: int, window: int = 0) -> bytes:
-        out = ctypes.create_string_buffer(96 * count)
-        self._chk(self._lib.kzg_srs_read(self._h, window, first, count, out))
+    def srs_read(self, first: int, count: int, window: int = 0, compressed: bool = False) -> bytes:
+        out = ctypes.create_string_buffer((48 if compressed else 96) * count)
+        fn = self._lib.kzg_srs_read_compressed if compressed else self._lib.kzg_srs_read
+        self._chk(fn(self._h, window, first, count, out))
         return out.raw
 
     # ------------------------------------------------------------------ hot path

@@ -3,7 +3,8 @@
 --generate-precompute --overwrite` (reference tests/conftest.py:50-65, Makefile:30-48).
 
 Generates a tau-derived SRS **on the GPU** and writes
-  <setup-path>      2^scale affine G1 points, x||y, 2 x 48 B big-endian each (worker slice i at points [i*T, (i+1)*T))
+  <setup-path>      2^scale affine G1 points, x||y, 2 x 48 B big-endian each (worker slice i at points [i*T, (i+1)*T));
+                    with --compressed: 48-byte ZCash-compressed points instead
   <setup-path>.vk   192 B [tau_x]_2 (uncompressed G2, x.c1||x.c0||y.c1||y.c0) + 96 B [L_i(tau_y)]_1 per worker
 which is what `Client(setup_path=...)` loads.  The window tables the reference keeps in --precompute-path are rebuilt on
 the GPU at Client.start(); --precompute-path is accepted for command-line compatibility and only receives a small
@@ -31,6 +32,8 @@ def main(argv=None) -> int:
     sp.add_argument("--generate-setup", action="store_true")
     sp.add_argument("--generate-precompute", action="store_true")
     sp.add_argument("--overwrite", action="store_true")
+    sp.add_argument("--compressed", action="store_true",
+                    help="write 48-byte ZCash-compressed points (load with Client(uncompressed=False))")
     sp.add_argument("--seed", type=int, default=None)
     sp.add_argument("--device", type=int, default=0)
     a = ap.parse_args(argv)
@@ -49,7 +52,7 @@ def main(argv=None) -> int:
     with open(a.setup_path, "wb") as f:
         step = max(1, (1 << 20) // T)
         for i in range(0, m, step):
-            f.write(eng.srs_read(i * T, min(step, m - i) * T))
+            f.write(eng.srs_read(i * T, min(step, m - i) * T, compressed=a.compressed))
     vk = Verifier.synthetic(tau_x, [lagrange_factor(i, a.machines_scale, tau_y) for i in range(m)])
     with open(a.setup_path + ".vk", "wb") as f:
         f.write(vk.export(m))
