@@ -149,3 +149,30 @@ def test_config1_plumbing_degree_4096_commit_under_mock_loop():
     assert o.fr_from_b64(ret.eval) == y and codec.g1_from_b64(ret.proof) == o.g1_compress(pi)
     with c.worker_verify(1, ret.proof, syn.alpha, ret.eval, ret.commitment) as r:
         assert r.json()["valid"] is True
+
+
+def test_commitment_api_shape(fr_kat):
+    """reference api/commit.py:34-100: poly -> Prove -> k random axons -> first str commitment, "" when none answers."""
+    import random
+
+    from zkp_subnet_amd.api import CommitmentAPI, CommitOnlyAxon, commit
+    from zkp_subnet_amd.miner import Miner, default_config
+
+    client = Client(engine=OracleEngine(), seed=9)
+    faithful = Miner(default_config(scale=6, machines_scale=2, seed=9), client=client)
+    assert commit(fr_kat["poly"], [faithful], index=2) == ""      # the reference miner rejects an alpha-less synapse
+    miner = CommitOnlyAxon(faithful)
+
+    class Dead:
+        def forward(self, synapse):
+            return synapse                              # what a failing miner returns (neurons/miner.py:133-135)
+
+    with client.worker_commit(2, fr_kat["poly"]) as r:
+        want = r.json()["commitment"]
+    assert commit(fr_kat["poly"], [miner], index=2) == want
+    assert commit(fr_kat["poly"], [Dead(), miner, Dead()], index=2, k=8, rng=random.Random(1)) == want
+    assert commit(fr_kat["poly"], [Dead()], index=2) == "" and commit(fr_kat["poly"], []) == ""
+    api = CommitmentAPI([miner])
+    syn = api.prepare_synapse(fr_kat["poly"], 1)
+    assert syn.poly == fr_kat["poly"] and syn.alpha is None and syn.index == 1
+    assert api.select_commitment([None, 3, "", "abc", "def"]) == "abc" and api.select_commitment([]) is None
