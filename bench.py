@@ -53,6 +53,36 @@ def uniform_fr(n, seed):
     return np.concatenate(out)[:n].tobytes()
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def measured_copy_peak_gbs(torch):
+    """STREAM-style device copy (1 GiB read + 1 GiB written per pass) on torch's stream: the achievable-HBM yardstick
+    SURVEY 8d asks for beside the 8 TB/s spec figure."""
+    a = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    gbs = 5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del a, b
+    torch.cuda.empty_cache()
+    return gbs
+
+
 def host_cores():
     try:
         return len(os.sched_getaffinity(0))
@@ -246,6 +276,7 @@ def main():
             launches = 2
             metric, unit, value = "KZG commit+open coefficients/sec at 2^22", "coefficients/s", units / elapsed
             wl = f"degree-2^{lg} KZG commit+open per GPU (INTT + 2 MSM + quotient), evaluation-form input"
+        copy_gbs = measured_copy_peak_gbs(torch) if world == 1 else None
         per_launch_s = acc_ms / 1e3 / launches if acc_ms else float("nan")
         achieved = alg_bytes / per_launch_s / 1e9 if acc_ms else None
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the value is
@@ -272,7 +303,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel_ms": per_launch_s * 1e3 if acc_ms else None, "algorithmic_bytes": alg_bytes,
-                         "frac_of_measured_copy_peak": (achieved / HBM_COPY_GBS) if achieved else None,
+                         "measured_copy_peak_gbs": round(copy_gbs, 1) if copy_gbs else None,
+                         "frac_of_measured_copy_peak": (achieved / (copy_gbs or HBM_COPY_GBS)) if achieved else None,
                          "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc, 2 x FETCH_SIZE + WRITE_SIZE)" if traffic else None,
                          "note": "integer-VALU-bound (14 x 28-bit-limb Montgomery products on v_mad_u64_u32: ~3.7k mads "
                                  "per mixed point addition), not HBM-bound; see DESIGN.md 3.3"},
@@ -284,6 +316,11 @@ def main():
         }
         if args.workload == "kzg22":
             out["kzg_commit_open_latency_ms"] = latency_ms
+            if world == 1:      # the same call fed from host memory: + H2D of the row (never part of `value`)
+                tp = time.perf_counter()
+                for _ in range(3):
+                    assert eng.commit_open(0, scal, alpha, True) == results[0]
+                out["pcie_inclusive_latency_ms"] = round((time.perf_counter() - tp) / 3 * 1e3, 4)
         # ---- adversarial scalar distributions (SURVEY 8d cfg 2: reported separately, never part of `value`)
         if world == 1 and args.workload == "msm20" and not args.no_adversarial:
             import numpy as np
@@ -320,7 +357,7 @@ def main():
             out["cpu_baseline"] = {
                 "value": m / cpu_s, "unit": "points/s", "cores": cores, "kind": "port",
                 "sample": f"first 2^{m.bit_length() - 1} points/scalars of the same workload, one Pippenger MSM split over "
-                          f"{cores} threads ({cpu_s:.2f} s wall, {host_cores()} host cores visible); 1 thread on "
+                          f"{cores} threads ({cpu_s:.2f} s wall, {host_cores()} host cores visible, {cpu_model()}); 1 thread on "
                           f"2^{(m >> 3).bit_length() - 1}: {(m >> 3) / cpu1_s:.0f} points/s",
                 "single_thread_points_per_s": (m >> 3) / cpu1_s,
                 "matches_gpu_bit_exact": cpu_res == gpu_same,

@@ -452,6 +452,60 @@ def test_client_and_miner_on_hip_engine(hip, fr_kat):
     miner.stop()
 
 
+def test_concurrent_host_threads_and_contexts(hip):
+    """The axon calls forward() from worker threads (SURVEY 8b threading): four threads hammer ONE context (serialised by
+    its mutex, staging buffer guarded by the engine lock) while a fifth drives a second context on the same GPU; every
+    answer equals the oracle's."""
+    import threading
+
+    from zkp_subnet_amd import codec
+    from zkp_subnet_amd.client import Client, derive_taus
+
+    lg = 10
+    T = 1 << lg
+    cl = Client(seed=21, workers=[0, 1])
+    cl.start(scale=lg + 1, machines_scale=1)
+    other = Client(seed=22, workers=[0])
+    other.start(scale=lg, machines_scale=0)
+    rows = [rand_scalars_bytes(T, 300 + k) for k in range(6)]
+    alphas = [rand_scalars_bytes(1, 400 + k) for k in range(6)]
+    want = {}
+    for c_, seed, ms in ((cl, 21, 1), (other, 22, 0)):
+        tx, ty = (t.to_bytes(32, "big") for t in derive_taus(seed))
+        for w in ((0, 1) if c_ is cl else (0,)):
+            srs = oc.srs_gen(tx, ty, lg + ms, ms, w)
+            for k in range(6):
+                ev, pf = oc.open_(srs, rows[k], alphas[k], True)
+                want[(id(c_), w, k)] = (codec.g1_to_b64(oc.commit(srs, rows[k], True)), codec.be32_to_fr(ev), codec.g1_to_b64(pf))
+    polys = [codec.be32_to_fr_list(r) for r in rows]
+    xs = [codec.be32_to_fr(a) for a in alphas]
+    errors = []
+
+    def work(c_, workers, tid):
+        try:
+            for it in range(6):
+                k, w = (it + tid) % 6, workers[(it + tid) % len(workers)]
+                with c_.worker_commit_and_open(w, polys[k], xs[k]) as r:
+                    b = r.json()
+                    if r.status_code != 200 or (b["commitment"], b["eval"], b["proof"]) != want[(id(c_), w, k)]:
+                        errors.append((tid, it, r.status_code))
+                with c_.worker_commit(w, polys[k]) as r:
+                    if r.json().get("commitment") != want[(id(c_), w, k)][0]:
+                        errors.append((tid, it, "commit"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(cl, [0, 1], t)) for t in range(4)]
+    threads.append(threading.Thread(target=work, args=(other, [0], 4)))
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    cl.stop()
+    other.stop()
+
+
 def test_compressed_srs_load_and_read(hip):
     """ZCash-compressed setup files (reference `uncompressed=False`, base/miner.py:75-81): the GPU recovers every y by
     a square root; result identical to loading the uncompressed points; malformed encodings fail the load."""
