@@ -52,8 +52,8 @@ struct StageSpan {
 };
 
 // One MSM in flight: its own stream and sort / bucket workspace.  Lane 0 runs on the context's main stream; lane 1
-// lets the opening MSM of commit+open start while the latency-bound tail (carry fold, bucket tree, final
-// combination) of the commitment MSM is still running.
+// takes the opening MSM of a long row's commit+open and every second ticket of kzg_msm_submit, so that one MSM's sort
+// and latency-bound tail (carry fold, bucket tree, final combination) hide under the other's accumulate.
 struct MsmLane {
     hipStream_t stream = nullptr;
     DevBuf rank, sorted, hist, offsets, bufA, bufB, carries, carry_key;
@@ -170,8 +170,9 @@ int choose_window(uint64_t T) {
     // measured on MI355X (bench.py --window sweep): the bucket tree costs ~log2(B) dependent point additions of
     // latency, the accumulate n*ceil(256/c) mixed additions of throughput
     if (lg <= 9) return 8;
-    if (lg <= 12) return 10;
+    if (lg <= 11) return 10;
     if (lg <= 13) return 12;
+    if (lg <= 15) return 14;
     if (lg <= 19) return 16;
     if (lg <= 22) return 20;
     return 22;
@@ -210,23 +211,28 @@ int ilog2_exact(uint64_t n) {
     return l;
 }
 
-// ---- the MSM pipeline on device-resident scalars -> one XYZZ point at out_xyzz (device), on lane `li`
+// ---- the MSM pipeline on device-resident scalars -> one XYZZ point at out_xyzz (device), on lane `li`.
+// With scalars2 != null: TWO MSMs over the same n points in one pass (the commitment and the opening of one row):
+// set b is sorted into bucket set b, the sort / accumulate / fold / tree kernels simply see twice the buckets, the
+// tree stops at two roots and out_xyzz[0..1] receive the two sums.  One kernel sequence, one latency-bound tail.
 int msm_core(kzg_ctx* ctx, int li, const uint32_t* scalars, int mont, uint64_t n, uint64_t srs_offset,
-             g1_xyzz_t* out_xyzz) {
+             g1_xyzz_t* out_xyzz, const uint32_t* scalars2 = nullptr, int mont2 = 0) {
     MsmLane& L = ctx->lane[li];
     hipStream_t s = L.stream;
+    const int nbatch = scalars2 ? 2 : 1;
     if (n == 0) {
-        HIPCHK(ctx, hipMemsetAsync(out_xyzz, 0, sizeof(g1_xyzz_t), s));
+        HIPCHK(ctx, hipMemsetAsync(out_xyzz, 0, nbatch * sizeof(g1_xyzz_t), s));
         return KZG_OK;
     }
     if (srs_offset + n > ctx->stride) return fail(ctx, KZG_E_ARG, "MSM range exceeds the resident SRS");
-    const uint64_t entries = n * (uint64_t)ctx->nwin;
+    const uint64_t entries = n * (uint64_t)ctx->nwin * nbatch;
     if (entries >= ((uint64_t)1 << 32)) return fail(ctx, KZG_E_ARG, "MSM too large for 32-bit entry indices");
     MsmShape sh;
-    sh.c = ctx->c; sh.nwin = ctx->nwin; sh.lay = ctx->lay; sh.nbuckets = ctx->nbuckets; sh.n = n;
+    sh.c = ctx->c; sh.nwin = ctx->nwin; sh.lay = ctx->lay; sh.nbuckets = ctx->nbuckets * nbatch; sh.n = n;
+    sh.nbatch = nbatch;
     sh.srs_offset = srs_offset; sh.srs_stride = ctx->stride; sh.chunk = pick_chunk(entries);
     const uint32_t nchunks = (uint32_t)((entries + sh.chunk - 1) / sh.chunk);
-    const size_t B = ctx->nbuckets;
+    const size_t B = sh.nbuckets;
     HIPCHK(ctx, L.rank.ensure(entries * 8));          // partitioned (key_low, value) pairs
     HIPCHK(ctx, L.sorted.ensure(entries * 4));
     HIPCHK(ctx, L.hist.ensure(4096 * 4));
@@ -240,8 +246,8 @@ int msm_core(kzg_ctx* ctx, int li, const uint32_t* scalars, int mont, uint64_t n
     {
         Span sp(ctx, KZG_T_DIGITS, s, li);
         HIPCHK(ctx, hipMemsetAsync(L.bufA.p, 0, B * sizeof(g1_xyzz_t), s));
-        launch_msm_sort(s, sh, scalars, mont, L.hist.as<uint32_t>(), L.rank.as<uint2>(), L.offsets.as<uint32_t>(),
-                        L.sorted.as<uint32_t>());
+        launch_msm_sort(s, sh, scalars, mont, scalars2, mont2, L.hist.as<uint32_t>(), L.rank.as<uint2>(),
+                        L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>());
         // the longest run of carries decides how many fold steps are launched; it depends on the offsets only, so
         // its 4-byte read-back completes while the accumulate kernel runs and costs no bubble
         HIPCHK(ctx, hipMemsetAsync(max_len_d, 0, 4, s));
@@ -267,15 +273,15 @@ int msm_core(kzg_ctx* ctx, int li, const uint32_t* scalars, int mont, uint64_t n
     g1_xyzz_t* out = L.bufB.as<g1_xyzz_t>();
     {
         Span sp(ctx, KZG_T_TREE, s, li);
-        uint32_t n_in = ctx->nbuckets;
-        for (int level = 0; n_in > 1; level++, n_in >>= 1) {
+        uint32_t n_in = sh.nbuckets;
+        for (int level = 0; n_in > (uint32_t)nbatch; level++, n_in >>= 1) {
             launch_msm_tree_level(s, in, out, n_in, level);
             std::swap(in, out);
         }
     }
     {
         Span sp(ctx, KZG_T_FINAL, s, li);
-        launch_msm_final(s, in, ctx->c - 1, out_xyzz);
+        launch_msm_final(s, in, ctx->c - 1, nbatch, out_xyzz);
     }
     HIPCHK(ctx, hipGetLastError());
     return KZG_OK;
@@ -361,9 +367,16 @@ int upload_fr(kzg_ctx* ctx, const uint8_t* be32, uint64_t n, uint32_t* dst, int 
     return KZG_OK;
 }
 
-// commit and/or open on a device-resident Montgomery row.  With both requested, the opening (evaluation, quotient,
-// MSM) runs on lane 1 concurrently with the commitment MSM on lane 0: the two only share the read-only coefficients.
-// Profiling keeps everything on lane 0 so that every stage time stays attributable to one kernel sequence.
+// commit and/or open on a device-resident Montgomery row.  With both requested:
+//  * rows up to 2^17 (latency-bound: dozens of small dependent kernels): the commitment MSM(U_i, f) and the opening
+//    MSM(U_i, q) run as ONE batched pass over the slice's window tables (msm_core with two scalar sets) -- one sort,
+//    one accumulate launch, one bucket tree with two roots, one shared inversion: a single tail instead of two;
+//  * longer rows (throughput-bound): the opening (evaluation, quotient, MSM) runs on lane 1 concurrently with the
+//    commitment MSM on lane 0 -- they share only the read-only coefficients -- so that each one's sort and tail hide
+//    under the other's accumulate.  Profiling keeps everything on lane 0 so that stage times stay attributable.
+#ifndef KZG_BATCHED_ROW_MAX
+#define KZG_BATCHED_ROW_MAX ((uint64_t)1 << 17)
+#endif
 int commit_open_dev(kzg_ctx* ctx, uint32_t i, const uint32_t* row_dev, uint64_t T, int evaluation_form,
                     const uint8_t* alpha_be32, uint8_t* out_c48, uint8_t* out_eval32, uint8_t* out_p48) {
     hipStream_t s = ctx->stream;
@@ -374,18 +387,21 @@ int commit_open_dev(kzg_ctx* ctx, uint32_t i, const uint32_t* row_dev, uint64_t 
     HIPCHK(ctx, ctx->small.ensure(1024));
     uint8_t* small = ctx->small.as<uint8_t>();  // [0,48) commitment [64,112) proof [128,160) eval be [192..) alpha/y limbs
     const uint64_t offset = (uint64_t)i * ctx->T;
-    const int lo = (out_c48 && out_p48 && !ctx->profiling) ? 1 : 0;  // lane of the opening
+    g1_xyzz_t* res = ctx->res.as<g1_xyzz_t>();
+    const bool both = out_c48 && out_p48;
+    const bool batched = both && T <= KZG_BATCHED_ROW_MAX;
+    const int lo = (both && !batched && !ctx->profiling) ? 1 : 0;  // lane of the opening
     hipStream_t so = ctx->lane[lo].stream;
     if (lo) {
         HIPCHK(ctx, hipEventRecord(ctx->ev_coeffs, s));
         HIPCHK(ctx, hipStreamWaitEvent(so, ctx->ev_coeffs, 0));
     }
-    if (out_c48) {
-        rc = msm_core(ctx, 0, coeffs, 1, T, offset, ctx->res.as<g1_xyzz_t>());
+    if (out_c48 && !batched) {
+        rc = msm_core(ctx, 0, coeffs, 1, T, offset, res);
         if (rc) return rc;
         if (!out_p48) {  // commit only; with an opening the two points share one inversion below
             Span sp(ctx, KZG_T_FINAL);
-            launch_g1_compress(s, ctx->res.as<g1_xyzz_t>(), small);
+            launch_g1_compress(s, res, small);
         }
     }
     if (out_p48) {
@@ -403,15 +419,21 @@ int commit_open_dev(kzg_ctx* ctx, uint32_t i, const uint32_t* row_dev, uint64_t 
                              ctx->qbuf.as<uint32_t>());
             launch_fr_to_be(so, y_m, small + 128, 1, 1);
         }
-        rc = msm_core(ctx, lo, ctx->qbuf.as<uint32_t>(), 0, T - 1, offset, ctx->res.as<g1_xyzz_t>() + 1);
+        if (batched) {
+            // the quotient has T - 1 coefficients; a zero in slot T - 1 lets it ride as a second length-T scalar set
+            HIPCHK(ctx, hipMemsetAsync(ctx->qbuf.as<uint32_t>() + 8 * (T - 1), 0, 32, s));
+            rc = msm_core(ctx, 0, coeffs, 1, T, offset, res, ctx->qbuf.as<uint32_t>(), 0);
+        } else {
+            rc = msm_core(ctx, lo, ctx->qbuf.as<uint32_t>(), 0, T - 1, offset, res + 1);
+        }
         if (rc) return rc;
         if (lo) {
             HIPCHK(ctx, hipEventRecord(ctx->lane[lo].ev_done, so));
             HIPCHK(ctx, hipStreamWaitEvent(s, ctx->lane[lo].ev_done, 0));
         }
         Span sp(ctx, KZG_T_FINAL);
-        if (out_c48) launch_g1_compress_pair(s, ctx->res.as<g1_xyzz_t>(), ctx->res.as<g1_xyzz_t>() + 1, small, small + 64);
-        else launch_g1_compress(s, ctx->res.as<g1_xyzz_t>() + 1, small + 64);
+        if (out_c48) launch_g1_compress_pair(s, res, res + 1, small, small + 64);
+        else launch_g1_compress(s, res + 1, small + 64);
     }
     HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, small, 192, hipMemcpyDeviceToHost, s));
     rc = finish(ctx);
@@ -587,10 +609,10 @@ void kzg_destroy(kzg_ctx* ctx) {
             if (L.ev_done) (void)hipEventDestroy(L.ev_done);
             if (L.stream && L.stream != ctx->stream) (void)hipStreamDestroy(L.stream);
         }
-        if (ctx->ev_coeffs) (void)hipEventDestroy(ctx->ev_coeffs);
         for (auto& b : ctx->slot) b.release();
         for (auto* m : {&ctx->tw_fwd, &ctx->tw_inv, &ctx->inv_n})
             for (auto& kv : *m) kv.second.release();
+        if (ctx->ev_coeffs) (void)hipEventDestroy(ctx->ev_coeffs);
         for (DevBuf* b : {&ctx->aux_in, &ctx->aux_pts, &ctx->aux_out}) b->release();
         if (ctx->aux) {
             (void)hipStreamSynchronize(ctx->aux);

@@ -25,8 +25,9 @@ struct MsmShape {
     int c;               // widest window, bits
     int nwin;            // signed windows
     WinLayout lay;
-    uint32_t nbuckets;   // 2^(c-1)
-    uint64_t n;          // number of (scalar, point) pairs in this MSM
+    uint32_t nbuckets;   // 2^(c-1) per MSM; nbatch MSMs over the same points use nbatch consecutive bucket sets
+    uint64_t n;          // number of (scalar, point) pairs in each MSM of the batch
+    int nbatch;          // 1, or 2: commit + open as ONE pass (scalar set b -> bucket set b), see launch_msm_sort
     uint64_t srs_offset; // first point of the slice inside the resident SRS
     uint64_t srs_stride; // points per window table (= total resident SRS points)
     int chunk;           // sorted entries per lane in msm_accumulate
@@ -34,8 +35,11 @@ struct MsmShape {
 
 // signed-digit recode + two-level counting sort: fills offsets[0..nbuckets] and sorted[0..entries).
 // part_ws: 4096 u32 scratch; parted: one uint2 per entry
-void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars, int scalars_mont, uint32_t* part_ws,
-                     uint2* parted, uint32_t* offsets, uint32_t* sorted);
+// With sh.nbatch == 2 the second scalar set (scalars2, same length, same points) is sorted into the second bucket set:
+// the key gets one more high bit, everything downstream just sees 2 * nbuckets buckets.
+void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars, int scalars_mont,
+                     const uint32_t* scalars2, int scalars2_mont, uint32_t* part_ws, uint2* parted, uint32_t* offsets,
+                     uint32_t* sorted);
 void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t* table, const uint32_t* offsets,
                            const uint32_t* sorted, g1_xyzz_t* buckets, g1_xyzz_t* carries, uint32_t* carry_key,
                            uint32_t nchunks);
@@ -49,7 +53,9 @@ void launch_fold_heads(hipStream_t s, const uint32_t* offsets, const uint32_t* c
 // level i: in = nodes of (i+1) points, component-major; out = nodes of (i+2) points
 void launch_msm_tree_level(hipStream_t s, const g1_xyzz_t* in, g1_xyzz_t* out, uint32_t n_in_nodes, int level);
 // node = [P, T_0 .. T_{nbits-1}] ; out_xyzz = P + sum 2^i T_i
-void launch_msm_final(hipStream_t s, const g1_xyzz_t* node, int nbits, g1_xyzz_t* out_xyzz);
+// nodes: the bucket tree stopped at `nodes` roots (component-major: component k of root m at node[k * nodes + m]);
+// out_xyzz[m] = P_m + sum_i 2^i T_{i,m}
+void launch_msm_final(hipStream_t s, const g1_xyzz_t* node, int nbits, int nodes, g1_xyzz_t* out_xyzz);
 // sum `count` XYZZ points (count <= 1024) into out_xyzz[0]
 void launch_g1_sum(hipStream_t s, const g1_xyzz_t* in, uint32_t count, g1_xyzz_t* out_xyzz);
 // affine + ZCash compression of one point

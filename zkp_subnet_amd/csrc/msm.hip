@@ -44,9 +44,10 @@ KZG_DEV uint32_t signed_digit(const uint32_t* s, int w, const WinLayout& lay, ui
 // bits in LDS, emits the bucket offsets, and scatters inside its own (L2-resident) slice.  The previous version
 // issued one global atomic per entry (24 G/s chip-wide: 0.9 ms at 2^20, 8 ms at 2^22).
 struct SortShape {
-    uint64_t n, srs_offset, srs_stride;
-    int mont, hbits, lbits;  // key = (part << lbits) | low
-    uint32_t spb;            // scalars per workgroup in the two level-1 kernels
+    uint64_t n, total, srs_offset, srs_stride;  // n scalars per set, total = n * sets
+    const uint32_t* scalars2;                   // second scalar set (batch of two MSMs over the same points) or null
+    int mont, mont2, keybits, hbits, lbits;     // key = set << keybits | digit magnitude - 1 = (part << lbits) | low
+    uint32_t spb;                               // scalars per workgroup in the two level-1 kernels
 };
 // h[key]++ in LDS, returning the old value.  When every active lane of the wave holds the same key (all scalars
 // equal, constant or sparse polynomials ...) one lane adds the whole count: same-address LDS atomics serialise.
@@ -65,14 +66,17 @@ template <class F>
 KZG_DEV void for_each_entry(const uint32_t* __restrict__ scalars, const SortShape& ss, const WinLayout& lay, F&& f) {
     const uint64_t base = (uint64_t)blockIdx.x * ss.spb;
     for (uint32_t r = 0; r < ss.spb / 256; r++) {
-        const uint64_t j = base + r * 256 + threadIdx.x;
-        if (j >= ss.n) break;
+        const uint64_t g = base + r * 256 + threadIdx.x;
+        if (g >= ss.total) break;
+        const bool second = g >= ss.n;
+        const uint64_t j = second ? g - ss.n : g;
         uint32_t s[8];
-        load_scalar(s, scalars, j, ss.mont);
+        load_scalar(s, second ? ss.scalars2 : scalars, j, second ? ss.mont2 : ss.mont);
+        const uint32_t set_bit = second ? 1u << ss.keybits : 0u;
         uint32_t carry = 0, neg;
         for (int w = 0; w < lay.nwin; w++) {
             const uint32_t mag = signed_digit(s, w, lay, carry, neg);
-            if (mag) f(mag - 1, (uint32_t)((uint64_t)w * ss.srs_stride + ss.srs_offset + j) | (neg << 31));
+            if (mag) f((mag - 1) | set_bit, (uint32_t)((uint64_t)w * ss.srs_stride + ss.srs_offset + j) | (neg << 31));
         }
     }
 }
@@ -611,16 +615,17 @@ KZG_DEV void lds_tree_sum(g1_xyzz_t* sm, g1_xyzz_t& mine, uint32_t tid, uint32_t
 
 // node = [P, T_0..T_{nbits-1}]; operation i doubles T_i i times, then a 32- or 64-wide tree sum; every doubling and
 // addition is cooperative (one 256-thread workgroup = 64 operations).
-__global__ void __launch_bounds__(256) k_msm_final(const g1_xyzz_t* __restrict__ node, int nbits,
+__global__ void __launch_bounds__(256) k_msm_final(const g1_xyzz_t* __restrict__ node, int nbits, int nodes,
                                                     g1_xyzz_t* __restrict__ out) {
     __shared__ CoopLds sm;
     __shared__ g1_xyzz_t pts[64];
     const uint32_t l = threadIdx.x & 63;
+    const uint32_t m = blockIdx.x;  // root of this workgroup
     if (threadIdx.x < 64) {
         g1_xyzz_t v;
         g1_set_inf(v);
-        if ((int)l < nbits) load_xyzz(v, &node[1 + l]);
-        else if ((int)l == nbits) load_xyzz(v, &node[0]);
+        if ((int)l < nbits) load_xyzz(v, &node[(uint64_t)(1 + l) * nodes + m]);
+        else if ((int)l == nbits) load_xyzz(v, &node[m]);
         store_xyzz(&pts[l], v);
     }
     __syncthreads();
@@ -631,7 +636,7 @@ __global__ void __launch_bounds__(256) k_msm_final(const g1_xyzz_t* __restrict__
     if (threadIdx.x == 0) {
         g1_xyzz_t v;
         load_xyzz(v, &pts[0]);
-        store_xyzz(out, v);
+        store_xyzz(&out[m], v);
     }
 }
 
@@ -1027,21 +1032,24 @@ __global__ void __launch_bounds__(256) k_batch_affine(const g1_xyzz_t* __restric
 // ------------------------------------------------------------------------------------------------ launchers
 static inline uint32_t nblk(uint64_t n, uint32_t b) { return (uint32_t)((n + b - 1) / b); }
 
-void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars, int scalars_mont, uint32_t* part_ws,
-                     uint2* parted, uint32_t* offsets, uint32_t* sorted) {
-    const int keybits = sh.c - 1;
+void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars, int scalars_mont,
+                     const uint32_t* scalars2, int scalars2_mont, uint32_t* part_ws, uint2* parted, uint32_t* offsets,
+                     uint32_t* sorted) {
+    const int setbits = sh.nbatch > 1 ? 1 : 0;
+    const int keybits = sh.c - 1 + setbits;
     SortShape ss;
-    ss.n = sh.n; ss.srs_offset = sh.srs_offset; ss.srs_stride = sh.srs_stride; ss.mont = scalars_mont;
+    ss.n = sh.n; ss.total = sh.n << setbits; ss.srs_offset = sh.srs_offset; ss.srs_stride = sh.srs_stride;
+    ss.mont = scalars_mont; ss.scalars2 = scalars2; ss.mont2 = scalars2_mont; ss.keybits = sh.c - 1;
     // up to 1024 partitions: level 2 runs one workgroup per partition, so more partitions = more parallel level 2
     ss.lbits = keybits > 10 ? (keybits - 10 > 12 ? 12 : keybits - 10) : 0;
-    ss.hbits = keybits - ss.lbits;  // <= 10 for c <= 23
-    ss.spb = sh.n >= (1u << 21) ? 4096u : 1024u;
+    ss.hbits = keybits - ss.lbits;  // <= 10 for c <= 22 (+ 1 set bit)
+    ss.spb = ss.total >= (1u << 21) ? 4096u : 1024u;
     const uint32_t npart = 1u << ss.hbits;
     uint32_t* part_count = part_ws;              // [npart]
     uint32_t* part_base = part_ws + 1024;        // [npart + 1]
     uint32_t* part_cursor = part_ws + 2 * 1024 + 8;
-    hipMemsetAsync(part_count, 0, npart * 4, s);
-    const uint32_t blocks = nblk(sh.n, ss.spb);
+    (void)hipMemsetAsync(part_count, 0, npart * 4, s);
+    const uint32_t blocks = nblk(ss.total, ss.spb);
     k_sort_count<<<blocks, 256, 0, s>>>(scalars, ss, sh.lay, part_count);
     k_sort_part_scan<<<1, 1024, 0, s>>>(part_count, npart, part_base, part_cursor);
     k_sort_partition<<<blocks, 256, 0, s>>>(scalars, ss, sh.lay, part_base, part_cursor, parted);
@@ -1077,8 +1085,8 @@ void launch_msm_tree_level(hipStream_t s, const g1_xyzz_t* in, g1_xyzz_t* out, u
     if (ops > 32768) k_msm_tree_level<<<nblk(ops, 256), 256, 0, s>>>(in, out, n_in_nodes, level);
     else k_msm_tree_level_coop<<<nblk(ops, 64), 256, 0, s>>>(in, out, n_in_nodes, level);
 }
-void launch_msm_final(hipStream_t s, const g1_xyzz_t* node, int nbits, g1_xyzz_t* out_xyzz) {
-    k_msm_final<<<1, 256, 0, s>>>(node, nbits, out_xyzz);
+void launch_msm_final(hipStream_t s, const g1_xyzz_t* node, int nbits, int nodes, g1_xyzz_t* out_xyzz) {
+    k_msm_final<<<nodes, 256, 0, s>>>(node, nbits, nodes, out_xyzz);
 }
 void launch_g1_sum(hipStream_t s, const g1_xyzz_t* in, uint32_t count, g1_xyzz_t* out_xyzz) {
     k_g1_sum<<<1, 64, 0, s>>>(in, count, out_xyzz);
