@@ -206,7 +206,10 @@ KZG_DEV uint32_t bucket_of(const uint32_t* __restrict__ offsets, uint32_t nbucke
 // Each lane owns sorted entries [t*K, (t+1)*K).  A bucket run that began in an earlier chunk is summed into
 // carries[t] (at most one per chunk: only the FIRST run of a chunk can have begun earlier); every run that
 // begins inside the chunk is stored straight to its bucket -- the lane that sees a run begin is its only writer.
-__global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t* __restrict__ table,
+#ifndef KZG_ACC_MIN_WAVES
+#define KZG_ACC_MIN_WAVES 2
+#endif
+__global__ void __launch_bounds__(256, KZG_ACC_MIN_WAVES) k_msm_accumulate(const g1_affine_t* __restrict__ table,
                                                          const uint32_t* __restrict__ offsets,
                                                          const uint32_t* __restrict__ sorted, uint32_t nbuckets,
                                                          uint32_t chunk, uint32_t nchunks,
@@ -284,6 +287,13 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t* __res
     carry_key[t] = my_carry_key;
 }
 
+// The kernels after the accumulate (fold, bucket tree, final combination, encoding) are chains of dependent point
+// operations with little work.  When they share the GPU with another lane's accumulate kernel (two requests in flight,
+// or the two MSMs of a long row's commit+open) they must (a) FIT next to it -- k_msm_accumulate is held to 256
+// registers (launch bound 2 waves/SIMD; 280 with AGPR spill space otherwise) so that a 250-register tail wave can be
+// resident on the same SIMD -- and (b) win the issue arbitration against a wave that saturates the integer pipe.
+KZG_DEV void tail_priority() { __builtin_amdgcn_s_setprio(3); }
+
 // ---- carries -> buckets.  The carries of bucket b sit at chunks t0+1 .. t1 with t0 = offsets[b] / K and
 // t1 = (offsets[b+1] - 1) / K, so carry t knows its position i = t - t0 - 1 inside its run of len = t1 - t0 carries
 // without any scan.  A per-run binary tree (step d: element i adds element i + d when i % 2d == 0) folds every run
@@ -310,6 +320,7 @@ __global__ void __launch_bounds__(256) k_fold_maxlen(const uint32_t* __restrict_
 __global__ void __launch_bounds__(256) k_fold_step(const uint32_t* __restrict__ offsets,
                                                     const uint32_t* __restrict__ carry_key, uint32_t chunk,
                                                     uint32_t nchunks, uint32_t d, g1_xyzz_t* __restrict__ carries) {
+    tail_priority();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nchunks) return;
     uint32_t key, i, len;
@@ -325,6 +336,7 @@ __global__ void __launch_bounds__(256) k_fold_heads(const uint32_t* __restrict__
                                                      const uint32_t* __restrict__ carry_key, uint32_t chunk,
                                                      uint32_t nchunks, const g1_xyzz_t* __restrict__ carries,
                                                      g1_xyzz_t* __restrict__ buckets) {
+    tail_priority();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nchunks) return;
     uint32_t key, i, len;
@@ -344,6 +356,7 @@ __global__ void __launch_bounds__(256) k_fold_heads(const uint32_t* __restrict__
 // and sum_k (k+1) B_k = P + sum_i 2^i T_i at the root.
 __global__ void __launch_bounds__(256) k_msm_tree_level(const g1_xyzz_t* __restrict__ in,
                                                          g1_xyzz_t* __restrict__ out, uint32_t n_in, int level) {
+    tail_priority();
     const uint32_t n_out = n_in >> 1;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n_out * (uint32_t)(level + 2)) return;
@@ -556,6 +569,7 @@ KZG_DEV void coop_dbl(CoopLds& sm, g1_xyzz_t* out, const g1_xyzz_t* p, bool acti
 __global__ void __launch_bounds__(256) k_fold_step_coop(const uint32_t* __restrict__ offsets,
                                                          const uint32_t* __restrict__ carry_key, uint32_t chunk,
                                                          uint32_t nchunks, uint32_t d, g1_xyzz_t* __restrict__ carries) {
+    tail_priority();
     __shared__ CoopLds sm;
     const uint32_t t = blockIdx.x * 64 + (threadIdx.x & 63);
     uint32_t key = 0, i = 0, len = 0;
@@ -568,6 +582,7 @@ __global__ void __launch_bounds__(256) k_fold_heads_coop(const uint32_t* __restr
                                                           const uint32_t* __restrict__ carry_key, uint32_t chunk,
                                                           uint32_t nchunks, const g1_xyzz_t* __restrict__ carries,
                                                           g1_xyzz_t* __restrict__ buckets) {
+    tail_priority();
     __shared__ CoopLds sm;
     const uint32_t t = blockIdx.x * 64 + (threadIdx.x & 63);
     uint32_t key = 0, i = 0, len = 0;
@@ -580,6 +595,7 @@ __global__ void __launch_bounds__(256) k_fold_heads_coop(const uint32_t* __restr
 // same merge as k_msm_tree_level, 64 operations per 256-thread workgroup, for the narrow (latency-bound) levels
 __global__ void __launch_bounds__(256) k_msm_tree_level_coop(const g1_xyzz_t* __restrict__ in,
                                                               g1_xyzz_t* __restrict__ out, uint32_t n_in, int level) {
+    tail_priority();
     __shared__ CoopLds sm;
     const uint32_t n_out = n_in >> 1;
     const uint32_t gid = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -617,6 +633,7 @@ KZG_DEV void lds_tree_sum(g1_xyzz_t* sm, g1_xyzz_t& mine, uint32_t tid, uint32_t
 // addition is cooperative (one 256-thread workgroup = 64 operations).
 __global__ void __launch_bounds__(256) k_msm_final(const g1_xyzz_t* __restrict__ node, int nbits, int nodes,
                                                     g1_xyzz_t* __restrict__ out) {
+    tail_priority();
     __shared__ CoopLds sm;
     __shared__ g1_xyzz_t pts[64];
     const uint32_t l = threadIdx.x & 63;
@@ -642,6 +659,7 @@ __global__ void __launch_bounds__(256) k_msm_final(const g1_xyzz_t* __restrict__
 
 __global__ void __launch_bounds__(64) k_g1_sum(const g1_xyzz_t* __restrict__ in, uint32_t count,
                                                 g1_xyzz_t* __restrict__ out) {
+    tail_priority();
     __shared__ g1_xyzz_t sm[64];
     const uint32_t tid = threadIdx.x;
     g1_xyzz_t acc, q, r;
@@ -658,6 +676,7 @@ __global__ void __launch_bounds__(64) k_g1_sum(const g1_xyzz_t* __restrict__ in,
 }
 
 __global__ void __launch_bounds__(64) k_g1_compress(const g1_xyzz_t* __restrict__ in, uint8_t* __restrict__ out48) {
+    tail_priority();
     if (threadIdx.x != 0) return;
     g1_xyzz_t p;
     load_xyzz(p, in);
@@ -669,6 +688,7 @@ __global__ void __launch_bounds__(64) k_g1_compress(const g1_xyzz_t* __restrict_
 __global__ void __launch_bounds__(64) k_g1_compress_pair(const g1_xyzz_t* __restrict__ in0,
                                                           const g1_xyzz_t* __restrict__ in1,
                                                           uint8_t* __restrict__ out0, uint8_t* __restrict__ out1) {
+    tail_priority();
     if (threadIdx.x != 0) return;
     g1_xyzz_t p0, p1;
     load_xyzz(p0, in0);
@@ -700,6 +720,7 @@ __global__ void __launch_bounds__(64) k_g1_compress_pair(const g1_xyzz_t* __rest
 // XYZZ working form <-> the 192-byte partial-sum format of the C-ABI (4 x 12 u32: canonical Montgomery residues)
 __global__ void __launch_bounds__(64) k_xyzz_pack(const g1_xyzz_t* __restrict__ in, uint32_t* __restrict__ out48w,
                                                    uint32_t count) {
+    tail_priority();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     g1_xyzz_t p;
