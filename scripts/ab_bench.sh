@@ -1,0 +1,15 @@
+#!/bin/bash
+# Same-box A/B of two builds of libkzg_mi355x.so (boxes of the pool differ by up to 10 % on this VALU-bound path, so
+# numbers from different gpurun calls are not comparable).  Put the candidates at zkp_subnet_amd/ab/A.so and B.so
+# (git-ignored), then:  gpurun -- 'bash scripts/ab_bench.sh "<bench.py args>" [rounds]'
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+ARGS=${1:---no-adversarial --no-cpu-baseline --steps 15}
+ROUNDS=${2:-3}
+cp zkp_subnet_amd/libkzg_mi355x.so /tmp/_orig.so
+for r in $(seq $ROUNDS); do
+  for v in A B; do
+    cp zkp_subnet_amd/ab/$v.so zkp_subnet_amd/libkzg_mi355x.so
+    echo -n "$v "; python bench.py $ARGS 2>&1 | tail -1 | grep -o "ms_per_step[^,]*\|\"accumulate[^,]*\|\"digits[^,]*\|\"tree[^,]*\|single_request_latency_ms[^,]*\|pipelined\": {[^}]*}" | tr "\n" " "; echo
+  done
+done
+cp /tmp/_orig.so zkp_subnet_amd/libkzg_mi355x.so

@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(256) k_msm_tree_level(const g1_xyzz_t* __restr
     } else {
         load_xyzz(a, &in[(uint64_t)k * n_in + 2 * m]);
         load_xyzz(b, &in[(uint64_t)k * n_in + 2 * m + 1]);
-        g1_add(r, a, b);
+        g1_add<true>(r, a, b);  // wide levels are throughput-bound: inlined products (-4 %, same-box A/B)
     }
     store_xyzz(&out[(uint64_t)k * n_out + m], r);
 }
