@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy peak
 HBM_COPY_GBS = 6290.0
+VALU_PEAK_GINST_S = 256 * 4 * 2.4 / 4   # wave64 VALU instructions per ns, chip-wide: one per 4 cycles per SIMD at 2.4 GHz
 TAU = 0x2F6C7A1D3B5E9F80412D6A7C93E1B5F7086A4D2C1E9B3F5A7D6C8E0F1A2B3C4D % R_MOD
 
 
@@ -284,11 +285,13 @@ def main():
         # the one measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 FETCH correction)
         # on this exact configuration and committed under profiles/; null for any other configuration.
         traffic = None
+        valu_insts = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pmc = json.load(f)
             if (pmc["workload"], pmc["points_per_gpu"], pmc["window_bits"]) == (args.workload, n, eng.window):
                 traffic = pmc["traffic_bytes_per_launch"]
+                valu_insts = pmc.get("sq_insts_valu_per_launch")
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -309,6 +312,14 @@ def main():
                          "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc, 2 x FETCH_SIZE + WRITE_SIZE)" if traffic else None,
                          "note": "integer-VALU-bound (14 x 28-bit-limb Montgomery products on v_mad_u64_u32: ~3.7k mads "
                                  "per mixed point addition), not HBM-bound; see DESIGN.md 3.3"},
+            # what actually bounds the kernel: VALU wave-instructions issued per second against one
+            # wave64 instruction per 4 cycles per SIMD (256 CUs x 4 SIMDs x 2.4 GHz / 4); SQ_INSTS_VALU from the same
+            # rocprofv3 --pmc passes as `traffic`
+            "valu_issue": ({"wave_insts_per_launch": valu_insts,
+                            "achieved_ginst_s": valu_insts / per_launch_s / 1e9,
+                            "peak_ginst_s": VALU_PEAK_GINST_S,
+                            "frac": valu_insts / per_launch_s / 1e9 / VALU_PEAK_GINST_S}
+                           if valu_insts and acc_ms else None),
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "single_request_latency_ms": round(latency_ms, 4),
             "pipelined": pipelined,

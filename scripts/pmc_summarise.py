@@ -27,7 +27,8 @@ ws = acc.get(("k_msm_accumulate", "WRITE_SIZE"))
 if fs and ws:
     fkb, wkb = sum(fs.values()) / len(fs), sum(ws.values()) / len(ws)
     cfg = json.loads(open(glob.glob(os.path.join(src, "FETCH_SIZE.json"))[0]).read().strip().splitlines()[-1])["config"]
-    json.dump({"workload": "msm20", "points_per_gpu": cfg["points_per_gpu"], "window_bits": cfg["window_bits"],
+    iv = acc.get(("k_msm_accumulate", "SQ_INSTS_VALU"))
+    json.dump({"workload": "msm20", "sq_insts_valu_per_launch": (sum(iv.values()) / len(iv)) if iv else None, "points_per_gpu": cfg["points_per_gpu"], "window_bits": cfg["window_bits"],
                "kernel": "k_msm_accumulate", "fetch_size_kb_raw": fkb, "write_size_kb_raw": wkb,
                "traffic_bytes_per_launch": 2 * fkb * 1024 + wkb * 1024,
                "correction": "2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE counts 128-B requests as 64 B; "
