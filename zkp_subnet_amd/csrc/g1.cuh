@@ -10,8 +10,10 @@
 #include "field.cuh"
 #include "fp28.cuh"
 
-struct alignas(16) g1_affine_t {
-    uint32_t x[12], y[12];
+// HBM form of a table point: one 128-byte line = x, y as 14 canonical 28-bit limbs each (the working representation:
+// no unpacking in the hot loop) + 16 bytes of padding.  A 96-byte packed row straddled two 128-B lines for 3 rows in 4.
+struct alignas(128) g1_affine_t {
+    uint32_t x[14], y[14], pad[4];
 };
 struct alignas(16) g1_xyzz_t {
     fp_t x, y, zz, zzz;
@@ -356,22 +358,22 @@ KZG_DEV void g1_to_aff(g1_aff28& r, const g1_xyzz_t& p) {
 // ---- HBM formats
 KZG_DEV void g1_load_aff(g1_aff28& p, const g1_affine_t* src) {
     const uint4* q = reinterpret_cast<const uint4*>(src);
-    uint32_t w[24];
+    uint32_t w[28];
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
+    for (int i = 0; i < 7; i++) {
         uint4 v = q[i];
         w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
     }
-    fp_unpack(p.x, w);
-    fp_unpack(p.y, w + 12);
+#pragma unroll
+    for (int i = 0; i < 14; i++) { p.x.l[i] = w[i]; p.y.l[i] = w[14 + i]; }
 }
 KZG_DEV void g1_store_aff(g1_affine_t* dst, const g1_aff28& p) {  // p canonical
-    uint32_t w[24];
-    fp_pack(w, p.x);
-    fp_pack(w + 12, p.y);
+    uint32_t w[28];
+#pragma unroll
+    for (int i = 0; i < 14; i++) { w[i] = p.x.l[i]; w[14 + i] = p.y.l[i]; }
     uint4* q = reinterpret_cast<uint4*>(dst);
 #pragma unroll
-    for (int i = 0; i < 6; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+    for (int i = 0; i < 7; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
 KZG_DEV void store_xyzz(g1_xyzz_t* dst, const g1_xyzz_t& p) {
     uint4* q = reinterpret_cast<uint4*>(dst);

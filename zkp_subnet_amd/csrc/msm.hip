@@ -232,11 +232,11 @@ __global__ void __launch_bounds__(256, KZG_ACC_MIN_WAVES) k_msm_accumulate(const
     g1_xyzz_t acc;
     g1_set_inf(acc);
     uint32_t v_cur = sorted[lo];
-    uint32_t w_cur[24];
+    uint32_t w_cur[28];
     {
         const uint4* q = reinterpret_cast<const uint4*>(table + (v_cur & 0x7fffffffu));
 #pragma unroll
-        for (int i = 0; i < 6; i++) { uint4 t4 = q[i]; w_cur[4*i]=t4.x; w_cur[4*i+1]=t4.y; w_cur[4*i+2]=t4.z; w_cur[4*i+3]=t4.w; }
+        for (int i = 0; i < 7; i++) { uint4 t4 = q[i]; w_cur[4*i]=t4.x; w_cur[4*i+1]=t4.y; w_cur[4*i+2]=t4.z; w_cur[4*i+3]=t4.w; }
     }
     for (uint32_t e = lo; e < hi; e++) {
         if (e == boundary) {  // run of `cur` is complete
@@ -262,20 +262,20 @@ __global__ void __launch_bounds__(256, KZG_ACC_MIN_WAVES) k_msm_accumulate(const
             }
         }
         // software pipeline: the packed words of the NEXT entry's point are requested before this entry's addition
-        uint32_t wn[24];
+        uint32_t wn[28];
         const uint32_t vn = (e + 1 < hi) ? sorted[e + 1] : v_cur;
         {
             const uint4* q = reinterpret_cast<const uint4*>(table + (vn & 0x7fffffffu));
 #pragma unroll
-            for (int i = 0; i < 6; i++) { uint4 t4 = q[i]; wn[4*i]=t4.x; wn[4*i+1]=t4.y; wn[4*i+2]=t4.z; wn[4*i+3]=t4.w; }
+            for (int i = 0; i < 7; i++) { uint4 t4 = q[i]; wn[4*i]=t4.x; wn[4*i+1]=t4.y; wn[4*i+2]=t4.z; wn[4*i+3]=t4.w; }
         }
         g1_aff28 p;
-        fp_unpack(p.x, w_cur);
-        fp_unpack(p.y, w_cur + 12);
+#pragma unroll
+        for (int i = 0; i < 14; i++) { p.x.l[i] = w_cur[i]; p.y.l[i] = w_cur[14 + i]; }
         g1_neg_aff(p, v_cur >> 31);
         g1_madd_checked<true>(acc, p);
 #pragma unroll
-        for (int i = 0; i < 24; i++) w_cur[i] = wn[i];
+        for (int i = 0; i < 28; i++) w_cur[i] = wn[i];
         v_cur = vn;
     }
     if (pending_carry) {
@@ -884,9 +884,13 @@ __global__ void __launch_bounds__(256) k_precomp_dbl(const g1_affine_t* __restri
 KZG_DEV void park_fp(g1_affine_t* slot, const fp_t& v_loose) {
     fp_t c;
     fp_canon_mont(c, v_loose);
-    fp_pack(slot->x, c);
+#pragma unroll
+    for (int i = 0; i < 14; i++) slot->x[i] = c.l[i];
 }
-KZG_DEV void unpark_fp(fp_t& v, const g1_affine_t* slot) { fp_unpack(v, slot->x); }
+KZG_DEV void unpark_fp(fp_t& v, const g1_affine_t* slot) {
+#pragma unroll
+    for (int i = 0; i < 14; i++) v.l[i] = slot->x[i];
+}
 KZG_DEV void xyzz_to_aff_with_inv(g1_aff28& o, const g1_xyzz_t& p, const fp_t& iw /* 1/(zz*zzz) */) {
     fp_t t;
     fp_mul(t, iw, p.zzz);   // 1/zz
