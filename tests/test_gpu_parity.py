@@ -363,7 +363,9 @@ def test_kzg_golden_vectors(hip, golden_kzg):
         eng.close()
 
 
-@pytest.mark.parametrize("scale,ms,i", [(10, 2, 3), (12, 0, 0), (16, 4, 9), (14, 0, 0)])
+# rows up to 2^17 take the batched two-set pass, longer ones the two-lane form (api.hip commit_open_dev): both sides of
+# the switch are covered, and the fused call must equal the two separate calls (single-MSM path)
+@pytest.mark.parametrize("scale,ms,i", [(10, 2, 3), (12, 0, 0), (16, 4, 9), (14, 0, 0), (17, 0, 0), (19, 1, 1)])
 def test_kzg_commit_open_matches_c_oracle(hip, scale, ms, i):
     eng = hip()
     tx, ty = 0xFEEDFACE + scale, 0xDEADBEEF
@@ -377,6 +379,7 @@ def test_kzg_commit_open_matches_c_oracle(hip, scale, ms, i):
     assert (ev, pf) == oc.open_(srs, row, alpha, True, threads=8)
     assert o.verify_trapdoor(tx, ty, ms, i, o.g1_decompress(c), o.g1_decompress(pf), int.from_bytes(alpha, "big"),
                              int.from_bytes(ev, "big"))
+    assert eng.commit(0, row, True) == c and eng.open(0, row, alpha, True) == (ev, pf)
 
 
 def test_kzg_2_22_commit_open_bit_exact(hip):
