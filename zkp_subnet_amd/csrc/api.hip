@@ -174,7 +174,7 @@ int choose_window(uint64_t T) {
     if (lg <= 13) return 12;
     if (lg <= 15) return 14;
     if (lg <= 19) return 16;
-    if (lg <= 22) return 20;
+    if (lg <= 23) return 20;
     return 22;
 }
 // nwin = ceil(256/c) windows of width base or base+1 (256 = nwin*base + extra): the widest is <= c bits
