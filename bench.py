@@ -375,6 +375,13 @@ def main():
                 "matches_gpu_bit_exact": cpu_res == gpu_same,
             }
             assert cpu_res == gpu_same, "GPU MSM differs from the CPU oracle on the baseline sample"
+        # RCCL writes its version banner through C stdio, which is flushed at exit: push it out now so that the JSON
+        # line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(out), flush=True)
     eng.close()
     if use_dist:
