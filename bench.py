@@ -210,9 +210,9 @@ def main():
     results.clear()
     step_ms.clear()
     # msm20 and short rows (one batched pass): stage spans (HIP events on the library's stream) are recorded inside the
-    # timed region.  Rows above 2^17: the library runs the two MSMs of a commit+open on two streams unless profiling is
+    # timed region.  Rows above 2^18: the library runs the two MSMs of a commit+open on two streams unless profiling is
     # on, so the timed region runs unprofiled and the stage times come from extra profiled (serialised) steps afterwards.
-    profile_in_timed = args.workload == "msm20" or n <= (1 << 17)
+    profile_in_timed = args.workload == "msm20" or n <= (1 << 18)
     eng.set_profiling(profile_in_timed)
     barrier()
     t0 = time.perf_counter()
@@ -273,7 +273,7 @@ def main():
             metric, unit, value = "BLS12-381 G1 MSM points/sec at 2^20", "points/s", units / elapsed
             wl = f"2^{lg}-point BLS12-381 G1 Pippenger MSM per GPU (uniform scalars in [0,r), cached SRS)"
         else:
-            batched = n <= (1 << 17)              # short rows: ONE accumulate launch carries both MSMs
+            batched = n <= (1 << 18)              # short rows: ONE accumulate launch carries both MSMs
             alg_bytes = (2 if batched else 1) * 128.0 * n   # per k_msm_accumulate launch (commit: n, open: n-1 scalars)
             launches = 1 if batched else 2
             metric, unit, value = "KZG commit+open coefficients/sec at 2^22", "coefficients/s", units / elapsed

@@ -368,14 +368,14 @@ int upload_fr(kzg_ctx* ctx, const uint8_t* be32, uint64_t n, uint32_t* dst, int 
 }
 
 // commit and/or open on a device-resident Montgomery row.  With both requested:
-//  * rows up to 2^17 (latency-bound: dozens of small dependent kernels): the commitment MSM(U_i, f) and the opening
+//  * rows up to 2^18 (latency-bound: dozens of small dependent kernels): the commitment MSM(U_i, f) and the opening
 //    MSM(U_i, q) run as ONE batched pass over the slice's window tables (msm_core with two scalar sets) -- one sort,
 //    one accumulate launch, one bucket tree with two roots, one shared inversion: a single tail instead of two;
 //  * longer rows (throughput-bound): the opening (evaluation, quotient, MSM) runs on lane 1 concurrently with the
 //    commitment MSM on lane 0 -- they share only the read-only coefficients -- so that each one's sort and tail hide
 //    under the other's accumulate.  Profiling keeps everything on lane 0 so that stage times stay attributable.
 #ifndef KZG_BATCHED_ROW_MAX
-#define KZG_BATCHED_ROW_MAX ((uint64_t)1 << 17)
+#define KZG_BATCHED_ROW_MAX ((uint64_t)1 << 18)
 #endif
 int commit_open_dev(kzg_ctx* ctx, uint32_t i, const uint32_t* row_dev, uint64_t T, int evaluation_form,
                     const uint8_t* alpha_be32, uint8_t* out_c48, uint8_t* out_eval32, uint8_t* out_p48) {
