@@ -579,3 +579,27 @@ def test_setup_cli_file_roundtrip_through_client(hip, tmp_path, fr_kat):
     from_c.stop()
     from_file.stop()
     in_memory.stop()
+
+
+def test_bench_contract_line(hip):
+    """bench.py prints ONE JSON line, last on stdout, with the driver's keys plus `roofline` and `cpu_baseline`."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--log-n", "14", "--steps", "3", "--warmup", "1",
+                          "--cpu-sample-log", "12"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    rec = json.loads(lines[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in rec, k
+    assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["higher_is_better"] is True
+    assert rec["scaling"] == "weak" and rec["data"] == "synthetic" and "workload" in rec["config"]
+    assert abs(rec["value"] - (1 << 14) * 3 / (rec["ms_per_step"] * 3e-3)) / rec["value"] < 1e-6
+    rf, cb = rec["roofline"], rec["cpu_baseline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["matches_gpu_bit_exact"] is True
