@@ -169,13 +169,26 @@ def main():
     depth = args.in_flight if args.workload == "msm20" else 1
     state = {"depth": depth}
 
+    # N > 1, one request at a time: partial -> RCCL all_gather -> sum entirely through device buffers
+    gather = None
+    if use_dist and args.workload == "msm20" and depth == 1:
+        from zkp_subnet_amd.distributed import DeviceGather
+
+        gather = DeviceGather(eng)
+    state["gather"] = gather
+
     def submit():
-        if args.workload == "msm20":
+        if args.workload == "msm20" and state["gather"] is None:
             return eng.msm_submit(0, n, 0, partial=use_dist)
         return None
 
     def complete(ticket, collect):
-        if args.workload == "msm20":
+        if state["gather"] is not None:
+            r = state["gather"].msm(0, n, 0)
+            if collect:
+                for k, v in eng.timings().items():
+                    stage_sum[k] = stage_sum.get(k, 0.0) + v
+        elif args.workload == "msm20":
             r = eng.msm_wait(ticket)
             if collect:
                 for k, v in eng.timings().items():
@@ -230,14 +243,14 @@ def main():
     # latency-bound tail of MSM i): reported beside the headline, never mixed into it
     pipelined = None
     if args.workload == "msm20" and depth == 1 and args.pipelined:
-        state["depth"] = 2
+        state["depth"], state["gather"] = 2, None
         run_steps(args.warmup, False)
         barrier()
         tp = time.perf_counter()
         run_steps(args.steps, False)
         barrier()
         pipe_s = time.perf_counter() - tp
-        state["depth"] = 1
+        state["depth"], state["gather"] = 1, gather
         if use_dist:
             t = torch.tensor([pipe_s], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -249,8 +262,12 @@ def main():
     for _ in range(min(args.steps, 10)):
         tl = time.perf_counter()
         if args.workload == "msm20":
-            results.append(eng.msm_resident(0, n, 0) if not use_dist else
-                           eng.g1_sum(b"".join(all_gather_partials(eng.msm_partial_resident(0, n, 0)))))
+            if not use_dist:
+                results.append(eng.msm_resident(0, n, 0))
+            elif gather is not None:
+                results.append(gather.msm(0, n, 0))
+            else:
+                results.append(eng.g1_sum(b"".join(all_gather_partials(eng.msm_partial_resident(0, n, 0)))))
         else:
             results.append(eng.commit_open_resident(0, 0, n, alpha, True))
         lat.append((time.perf_counter() - tl) * 1e3)
@@ -320,6 +337,7 @@ def main():
                             "peak_ginst_s": VALU_PEAK_GINST_S,
                             "frac": valu_insts / per_launch_s / 1e9 / VALU_PEAK_GINST_S}
                            if valu_insts and acc_ms else None),
+            "result_hex": results[0].hex() if isinstance(results[0], (bytes, bytearray)) else b"".join(results[0]).hex(),
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "single_request_latency_ms": round(latency_ms, 4),
             "pipelined": pipelined,

@@ -109,6 +109,12 @@ int kzg_vk_pairing(const uint8_t p_be96[96], const uint8_t q_be192[192], uint8_t
 int kzg_msm_partial(kzg_ctx* ctx, const uint8_t* scalars_be32, uint64_t n, uint64_t srs_offset,
                     uint8_t out_xyzz192[192]);
 int kzg_g1_sum(kzg_ctx* ctx, const uint8_t* partials_xyzz192, uint32_t count, uint8_t out48[48]);
+/* Device-pointer forms for the collective path: the partial is written into / the gathered partials are read from the
+ * CALLER's device memory (the tensors of an RCCL all_gather), so a step makes no host round trip for them.
+ * kzg_msm_partial_resident_dev returns after its stream has drained (dev_out is complete); the caller must have
+ * completed the collective (stream synchronised) before kzg_g1_sum_dev. */
+int kzg_msm_partial_resident_dev(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, void* dev_out_xyzz192);
+int kzg_g1_sum_dev(kzg_ctx* ctx, const void* dev_partials_xyzz192, uint32_t count, uint8_t out48[48]);
 
 /* ---- device-resident inputs (what a serving loop and bench.py use: inputs already in HBM when timing starts).
  *      slot in [0, 4).  to_mont=1 stores Montgomery form (rows for commit/open), 0 canonical (MSM scalars). */

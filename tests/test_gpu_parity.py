@@ -603,3 +603,12 @@ def test_bench_contract_line(hip):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["matches_gpu_bit_exact"] is True
+    # the collective path (1-rank RCCL group: partial -> all_gather -> sum through device buffers) gives the same point
+    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    out2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--log-n", "14", "--steps", "3", "--warmup", "1",
+                           "--no-cpu-baseline", "--no-adversarial", "--pipelined"], capture_output=True, text=True,
+                          timeout=600, cwd=root, env=env)
+    assert out2.returncode == 0, out2.stderr[-2000:]
+    rec2 = json.loads([ln for ln in out2.stdout.splitlines() if ln.strip()][-1])
+    assert rec2["result_hex"] == rec["result_hex"] and len(rec["result_hex"]) == 96
+    assert rec2["pipelined"]["value"] > 0 and "RCCL" in rec2["config"]["parallelism"] or rec2["n_gpus"] == 1

@@ -44,6 +44,8 @@ SYMBOLS = {
     "kzg_vk_pairing": (_I, [_B, _B, _B]),
     "kzg_msm_partial": (_I, [_P, _B, _U64, _U64, _B]),
     "kzg_g1_sum": (_I, [_P, _B, _U32, _B]),
+    "kzg_msm_partial_resident_dev": (_I, [_P, _I, _U64, _U64, _P]),
+    "kzg_g1_sum_dev": (_I, [_P, _P, _U32, _B]),
     "kzg_upload_fr": (_I, [_P, _I, _B, _U64, _I]),
     "kzg_msm_resident": (_I, [_P, _I, _U64, _U64, _B]),
     "kzg_msm_partial_resident": (_I, [_P, _I, _U64, _U64, _B]),

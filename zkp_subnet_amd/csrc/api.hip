@@ -787,9 +787,10 @@ int kzg_msm_partial(kzg_ctx* ctx, const uint8_t* scalars_be32, uint64_t n, uint6
 }
 
 // runs on its own stream and buffers: legal while MSM tickets are outstanding (a rank sums the gathered partials
-// of step i while its step i+1 is already on the GPU)
-int kzg_g1_sum(kzg_ctx* ctx, const uint8_t* partials_xyzz192, uint32_t count, uint8_t out48[48]) {
-    if (!ctx || !out48 || (count && !partials_xyzz192)) return KZG_E_ARG;
+// of step i while its step i+1 is already on the GPU).  `on_device`: the partials already sit in device memory
+// (the output tensor of the all_gather) and every prior writer has completed.
+static int g1_sum_common(kzg_ctx* ctx, const uint8_t* partials, uint32_t count, uint8_t out48[48], bool on_device) {
+    if (!ctx || !out48 || (count && !partials)) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, ctx->aux_in.ensure((size_t)count * 192 + 192));
@@ -797,8 +798,12 @@ int kzg_g1_sum(kzg_ctx* ctx, const uint8_t* partials_xyzz192, uint32_t count, ui
     HIPCHK(ctx, ctx->aux_out.ensure(64));
     hipStream_t s = ctx->aux;
     g1_xyzz_t* pts = ctx->aux_pts.as<g1_xyzz_t>();
-    if (count) HIPCHK(ctx, hipMemcpyAsync(ctx->aux_in.p, partials_xyzz192, (size_t)count * 192, hipMemcpyHostToDevice, s));
-    launch_xyzz_unpack(s, ctx->aux_in.as<uint32_t>(), pts + 1, count);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(partials);
+    if (!on_device) {
+        if (count) HIPCHK(ctx, hipMemcpyAsync(ctx->aux_in.p, partials, (size_t)count * 192, hipMemcpyHostToDevice, s));
+        src = ctx->aux_in.as<uint32_t>();
+    }
+    launch_xyzz_unpack(s, src, pts + 1, count);
     launch_g1_sum(s, pts + 1, count, pts);
     launch_g1_compress(s, pts, ctx->aux_out.as<uint8_t>());
     uint8_t* pin = ctx->host_pin + 1024;
@@ -807,6 +812,12 @@ int kzg_g1_sum(kzg_ctx* ctx, const uint8_t* partials_xyzz192, uint32_t count, ui
     HIPCHK(ctx, hipGetLastError());
     memcpy(out48, pin, 48);
     return KZG_OK;
+}
+int kzg_g1_sum(kzg_ctx* ctx, const uint8_t* partials_xyzz192, uint32_t count, uint8_t out48[48]) {
+    return g1_sum_common(ctx, partials_xyzz192, count, out48, false);
+}
+int kzg_g1_sum_dev(kzg_ctx* ctx, const void* dev_partials_xyzz192, uint32_t count, uint8_t out48[48]) {
+    return g1_sum_common(ctx, reinterpret_cast<const uint8_t*>(dev_partials_xyzz192), count, out48, true);
 }
 
 static int commit_open_host(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
@@ -928,8 +939,11 @@ int kzg_upload_fr(kzg_ctx* ctx, int slot, const uint8_t* be32, uint64_t n, int t
     ctx->slot_mont[slot] = to_mont ? 1 : 0;
     return KZG_OK;
 }
-static int msm_resident_common(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint8_t* out, bool partial) {
-    if (!ctx || !out || slot < 0 || slot >= N_SLOTS) return KZG_E_ARG;
+// dev_out != null: the 192-byte partial is left in the CALLER's device buffer (e.g. a torch tensor about to enter an
+// RCCL all_gather) instead of coming back to the host
+static int msm_resident_common(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint8_t* out, bool partial,
+                               void* dev_out = nullptr) {
+    if (!ctx || (!out && !dev_out) || slot < 0 || slot >= N_SLOTS) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (int busy = need_idle(ctx)) return busy;
@@ -943,7 +957,9 @@ static int msm_resident_common(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_
     HIPCHK(ctx, ctx->small.ensure(1024));
     rc = msm_core(ctx, 0, ctx->slot[slot].as<uint32_t>(), ctx->slot_mont[slot], n, srs_offset, ctx->res.as<g1_xyzz_t>());
     if (rc) return rc;
-    if (partial) {
+    if (dev_out) {
+        launch_xyzz_pack(ctx->stream, ctx->res.as<g1_xyzz_t>(), reinterpret_cast<uint32_t*>(dev_out), 1);
+    } else if (partial) {
         launch_xyzz_pack(ctx->stream, ctx->res.as<g1_xyzz_t>(), ctx->small.as<uint32_t>(), 1);
         HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, ctx->small.p, 192, hipMemcpyDeviceToHost, ctx->stream));
     } else {
@@ -951,10 +967,14 @@ static int msm_resident_common(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_
         launch_g1_compress(ctx->stream, ctx->res.as<g1_xyzz_t>(), ctx->small.as<uint8_t>());
         HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, ctx->small.p, 48, hipMemcpyDeviceToHost, ctx->stream));
     }
-    rc = finish(ctx);
+    rc = finish(ctx);  // synchronises the stream: dev_out is complete when the call returns
     if (rc) return rc;
-    memcpy(out, ctx->host_pin + 64, partial ? 192 : 48);
+    if (out) memcpy(out, ctx->host_pin + 64, partial ? 192 : 48);
     return KZG_OK;
+}
+int kzg_msm_partial_resident_dev(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, void* dev_out_xyzz192) {
+    if (!dev_out_xyzz192) return KZG_E_ARG;
+    return msm_resident_common(ctx, slot, n, srs_offset, nullptr, true, dev_out_xyzz192);
 }
 int kzg_msm_resident(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint8_t out48[48]) {
     return msm_resident_common(ctx, slot, n, srs_offset, out48, false);

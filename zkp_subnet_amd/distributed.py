@@ -38,6 +38,29 @@ def all_gather_partials(partial: bytes, group=None) -> List[bytes]:
     return [raw[i * PARTIAL_BYTES:(i + 1) * PARTIAL_BYTES] for i in range(world)]
 
 
+class DeviceGather:
+    """The collective step with no host round trip for the partials: the engine writes its 192-byte partial into a
+    torch device tensor, RCCL all_gathers device-to-device, the engine sums the gathered tensor on the GPU.  Tensors are
+    allocated once.  nccl (RCCL) backend only."""
+
+    def __init__(self, engine, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.engine, self.group, self.dist, self.torch = engine, group, dist, torch
+        self.world = dist.get_world_size(group)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.src = torch.zeros(PARTIAL_BYTES, dtype=torch.uint8, device=dev)
+        self.out = torch.zeros(self.world * PARTIAL_BYTES, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+
+    def msm(self, slot: int, n: int, srs_offset: int = 0) -> bytes:
+        self.engine.msm_partial_resident_dev(slot, n, srs_offset, self.src.data_ptr())   # complete on return
+        self.dist.all_gather_into_tensor(self.out, self.src, group=self.group)
+        self.torch.cuda.current_stream().synchronize()                                   # RCCL done before the sum reads
+        return self.engine.g1_sum_dev(self.out.data_ptr(), self.world)
+
+
 def sharded_msm(engine, scalars_shard_be32: Optional[bytes] = None, srs_offset: int = 0, slot: Optional[int] = None,
                 n: Optional[int] = None, group=None) -> bytes:
     """This rank's shard -> partial -> all_gather -> sum.  Every rank returns the same 48-byte compressed point.

@@ -240,6 +240,16 @@ class HipEngine:
         self._chk(self._lib.kzg_msm_wait(self._h, ticket[0], out))
         return out.raw
 
+    def msm_partial_resident_dev(self, slot: int, n: int, srs_offset: int, dev_ptr: int) -> None:
+        """The 192-byte partial goes to device address `dev_ptr` (e.g. `tensor.data_ptr()`); complete on return."""
+        self._chk(self._lib.kzg_msm_partial_resident_dev(self._h, slot, n, srs_offset, ctypes.c_void_p(dev_ptr)))
+
+    def g1_sum_dev(self, dev_ptr: int, count: int) -> bytes:
+        """Sum of `count` partials at device address `dev_ptr` (every writer must have completed) -> 48 bytes."""
+        out = ctypes.create_string_buffer(48)
+        self._chk(self._lib.kzg_g1_sum_dev(self._h, ctypes.c_void_p(dev_ptr), count, out))
+        return out.raw
+
     def commit_open_resident(self, i: int, slot: int, T: int, alpha_be32: bytes,
                              evaluation_form: bool = True) -> Tuple[bytes, bytes, bytes]:
         c, ev, pf = ctypes.create_string_buffer(48), ctypes.create_string_buffer(32), ctypes.create_string_buffer(48)
