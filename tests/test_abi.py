@@ -98,7 +98,7 @@ def test_wire_extension_matches_python_base64():
 
     importlib.reload(codec)
     assert codec._wire is not None
-    for n in (0, 1, 7, 40000):                         # 40000 > the threading threshold
+    for n in (0, 1, 7, 3000, 40000):                   # 3000 / 40000: 4 / 8 pool threads
         raw = _os.urandom(32 * n)
         lst = codec.be32_to_fr_list(raw)
         assert lst == [base64.b64encode(raw[32 * i:32 * i + 32]).decode().rstrip("=") for i in range(n)]
