@@ -235,7 +235,7 @@ int msm_core(kzg_ctx* ctx, int li, const uint32_t* scalars, int mont, uint64_t n
     const size_t B = sh.nbuckets;
     HIPCHK(ctx, L.rank.ensure(entries * 8));          // partitioned (key_low, value) pairs
     HIPCHK(ctx, L.sorted.ensure(entries * 4));
-    HIPCHK(ctx, L.hist.ensure(4096 * 4));
+    HIPCHK(ctx, L.hist.ensure(16384 * 4));
     HIPCHK(ctx, L.offsets.ensure((B + 1) * 4));
     HIPCHK(ctx, L.bufA.ensure(B * sizeof(g1_xyzz_t)));
     HIPCHK(ctx, L.bufB.ensure(B * sizeof(g1_xyzz_t)));

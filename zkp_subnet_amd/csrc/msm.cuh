@@ -34,7 +34,7 @@ struct MsmShape {
 };
 
 // signed-digit recode + two-level counting sort: fills offsets[0..nbuckets] and sorted[0..entries).
-// part_ws: 4096 u32 scratch; parted: one uint2 per entry
+// part_ws: 16384 u32 scratch; parted: one uint2 per entry
 // With sh.nbatch == 2 the second scalar set (scalars2, same length, same points) is sorted into the second bucket set:
 // the key gets one more high bit, everything downstream just sees 2 * nbuckets buckets.
 void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars, int scalars_mont,

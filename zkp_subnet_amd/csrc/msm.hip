@@ -43,6 +43,7 @@ KZG_DEV uint32_t signed_digit(const uint32_t* s, int w, const WinLayout& lay, ui
 // per block and partition to reserve room); level 2 gives each partition to one workgroup that histograms the low
 // bits in LDS, emits the bucket offsets, and scatters inside its own (L2-resident) slice.  The previous version
 // issued one global atomic per entry (24 G/s chip-wide: 0.9 ms at 2^20, 8 ms at 2^22).
+#define SORT_MAXPART 4096
 struct SortShape {
     uint64_t n, total, srs_offset, srs_stride;  // n scalars per set, total = n * sets
     const uint32_t* scalars2;                   // second scalar set (batch of two MSMs over the same points) or null
@@ -82,7 +83,7 @@ KZG_DEV void for_each_entry(const uint32_t* __restrict__ scalars, const SortShap
 }
 __global__ void __launch_bounds__(256) k_sort_count(const uint32_t* __restrict__ scalars, const SortShape ss,
                                                      const WinLayout lay, uint32_t* __restrict__ part_count) {
-    __shared__ uint32_t h[1024];
+    __shared__ uint32_t h[SORT_MAXPART];
     const uint32_t npart = 1u << ss.hbits;
     for (uint32_t i = threadIdx.x; i < npart; i += 256) h[i] = 0;
     __syncthreads();
@@ -91,13 +92,16 @@ __global__ void __launch_bounds__(256) k_sort_count(const uint32_t* __restrict__
     for (uint32_t i = threadIdx.x; i < npart; i += 256)
         if (h[i]) atomicAdd(&part_count[i], h[i]);
 }
-// part_base[0..npart] = exclusive scan of part_count; cursors zeroed
+// part_base[0..npart] = exclusive scan of part_count (npart <= 4096); cursors zeroed
 __global__ void __launch_bounds__(1024) k_sort_part_scan(const uint32_t* __restrict__ part_count, uint32_t npart,
                                                           uint32_t* __restrict__ part_base,
                                                           uint32_t* __restrict__ part_cursor) {
     __shared__ uint32_t part[1024];
     const uint32_t t = threadIdx.x;
-    const uint32_t v = t < npart ? part_count[t] : 0u;
+    const uint32_t per = (npart + 1023u) / 1024u;
+    const uint32_t lo = t * per, hi = min(lo + per, npart);
+    uint32_t v = 0;
+    for (uint32_t i = lo; i < hi; i++) v += part_count[i];
     part[t] = v;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -106,17 +110,19 @@ __global__ void __launch_bounds__(1024) k_sort_part_scan(const uint32_t* __restr
         part[t] += x;
         __syncthreads();
     }
-    if (t < npart) {
-        part_base[t] = part[t] - v;
-        part_cursor[t] = 0;
+    uint32_t run = part[t] - v;
+    for (uint32_t i = lo; i < hi; i++) {
+        part_base[i] = run;
+        part_cursor[i] = 0;
+        run += part_count[i];
     }
-    if (t == npart - 1) part_base[npart] = part[t];
+    if (t == 1023) part_base[npart] = part[1023];
 }
 __global__ void __launch_bounds__(256) k_sort_partition(const uint32_t* __restrict__ scalars, const SortShape ss,
                                                          const WinLayout lay, const uint32_t* __restrict__ part_base,
                                                          uint32_t* __restrict__ part_cursor, uint2* __restrict__ parted) {
-    __shared__ uint32_t h[1024];
-    __shared__ uint32_t base[1024];
+    __shared__ uint32_t h[SORT_MAXPART];
+    __shared__ uint32_t base[SORT_MAXPART];
     const uint32_t npart = 1u << ss.hbits;
     for (uint32_t i = threadIdx.x; i < npart; i += 256) h[i] = 0;
     __syncthreads();
@@ -134,12 +140,16 @@ __global__ void __launch_bounds__(256) k_sort_partition(const uint32_t* __restri
         parted[pos] = make_uint2(key & lmask, val);
     });
 }
+#define SORT_STAGE 14336  // 56 KB: two workgroups per CU still fit (2 x (56 + 16 + 4) KB)
 // one workgroup per partition: LDS histogram of the low bits -> bucket offsets -> scatter inside the partition
 __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__ parted, const uint32_t* __restrict__ part_base,
                                                         int lbits, uint32_t* __restrict__ offsets,
                                                         uint32_t* __restrict__ sorted, uint32_t npart) {
     __shared__ uint32_t h[4096];
     __shared__ uint32_t wsum[1024];
+    // a partition of up to SORT_STAGE entries is scattered inside LDS and leaves as whole lines (the 4-byte scatter
+    // straight to HBM wrote 3.7x the bytes: lines left L2 partly filled); larger (skewed) partitions scatter directly
+    __shared__ uint32_t stage[SORT_STAGE];
     const uint32_t q = blockIdx.x, t = threadIdx.x;
     const uint32_t nb = 1u << lbits;
     const uint32_t lo = part_base[q], hi = part_base[q + 1];
@@ -177,7 +187,22 @@ __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__
     }
     if (q == npart - 1 && t == 1023) offsets[(uint64_t)npart << lbits] = hi;
     __syncthreads();
-    {
+    if (hi - lo <= SORT_STAGE) {
+        uint32_t e = lo + t;
+        for (; e + 3 * 1024 < hi; e += 4 * 1024) {
+            const uint2 v0 = parted[e], v1 = parted[e + 1024], v2 = parted[e + 2048], v3 = parted[e + 3072];
+            stage[lds_bump(h, v0.x) - lo] = v0.y;
+            stage[lds_bump(h, v1.x) - lo] = v1.y;
+            stage[lds_bump(h, v2.x) - lo] = v2.y;
+            stage[lds_bump(h, v3.x) - lo] = v3.y;
+        }
+        for (; e < hi; e += 1024) {
+            const uint2 v = parted[e];
+            stage[lds_bump(h, v.x) - lo] = v.y;
+        }
+        __syncthreads();
+        for (uint32_t i = t; i < hi - lo; i += 1024) sorted[lo + i] = stage[i];
+    } else {
         uint32_t e = lo + t;
         for (; e + 3 * 1024 < hi; e += 4 * 1024) {
             const uint2 v0 = parted[e], v1 = parted[e + 1024], v2 = parted[e + 2048], v3 = parted[e + 3072];
@@ -1065,14 +1090,20 @@ void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars,
     SortShape ss;
     ss.n = sh.n; ss.total = sh.n << setbits; ss.srs_offset = sh.srs_offset; ss.srs_stride = sh.srs_stride;
     ss.mont = scalars_mont; ss.scalars2 = scalars2; ss.mont2 = scalars2_mont; ss.keybits = sh.c - 1;
-    // up to 1024 partitions: level 2 runs one workgroup per partition, so more partitions = more parallel level 2
-    ss.lbits = keybits > 10 ? (keybits - 10 > 12 ? 12 : keybits - 10) : 0;
-    ss.hbits = keybits - ss.lbits;  // <= 10 for c <= 22 (+ 1 set bit)
+    // 1024 partitions (level 2 runs one workgroup per partition), up to 4096 when that brings a partition down to what
+    // level 2 can stage in LDS (SORT_STAGE entries; ~13 k on average at 2^20 / 1024 and at 2^22 / 4096 partitions)
+    const uint64_t entries = ss.total * (uint64_t)sh.nwin;
+    int hbits = 10;
+    while (hbits < 12 && (entries >> hbits) > 12288) hbits++;
+    if (hbits > keybits) hbits = keybits;
+    if (keybits - hbits > 12) hbits = keybits - 12;  // level 2 histograms at most 4096 buckets
+    ss.hbits = hbits;
+    ss.lbits = keybits - hbits;
     ss.spb = ss.total >= (1u << 21) ? 4096u : 1024u;
     const uint32_t npart = 1u << ss.hbits;
-    uint32_t* part_count = part_ws;              // [npart]
-    uint32_t* part_base = part_ws + 1024;        // [npart + 1]
-    uint32_t* part_cursor = part_ws + 2 * 1024 + 8;
+    uint32_t* part_count = part_ws;                      // [npart]
+    uint32_t* part_base = part_ws + SORT_MAXPART;        // [npart + 1]
+    uint32_t* part_cursor = part_ws + 2 * SORT_MAXPART + 8;
     (void)hipMemsetAsync(part_count, 0, npart * 4, s);
     const uint32_t blocks = nblk(ss.total, ss.spb);
     k_sort_count<<<blocks, 256, 0, s>>>(scalars, ss, sh.lay, part_count);
