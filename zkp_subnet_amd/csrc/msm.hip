@@ -140,6 +140,94 @@ __global__ void __launch_bounds__(256) k_sort_partition(const uint32_t* __restri
         parted[pos] = make_uint2(key & lmask, val);
     });
 }
+// ---- level 1, staged: one scalar per lane (its <= 16 digits stay in registers: no second decode), the workgroup's
+// entries are ordered by partition inside LDS and leave as runs of consecutive addresses instead of 8-byte singles
+// (the direct scatter wrote 3.5x the bytes it stored).  Used when nwin <= 16; otherwise k_sort_partition.
+#define SORT1_MAXW 16
+#define SORT1_STAGE 10240  // entries per workgroup: 80 KB of (key_low, value) + 20 KB of partition ids
+__global__ void __launch_bounds__(1024) k_sort_partition_staged(const uint32_t* __restrict__ scalars, const SortShape ss,
+                                                                 const WinLayout lay, uint32_t spb,
+                                                                 const uint32_t* __restrict__ part_base,
+                                                                 uint32_t* __restrict__ part_cursor,
+                                                                 uint2* __restrict__ parted) {
+    __shared__ uint32_t h[SORT_MAXPART];     // counts, then (global base - local offset) per partition
+    __shared__ uint32_t loff[SORT_MAXPART];  // local exclusive offsets
+    __shared__ uint32_t wsum[1024];
+    __shared__ uint2 stage[SORT1_STAGE];
+    __shared__ uint16_t stq[SORT1_STAGE];
+    const uint32_t t = threadIdx.x;
+    const uint32_t npart = 1u << ss.hbits;
+    for (uint32_t i = t; i < npart; i += 1024) h[i] = 0;
+    __syncthreads();
+    // 1. digits -> registers, rank inside (workgroup, partition)
+    uint32_t keyn[SORT1_MAXW], rk[SORT1_MAXW];
+    const uint64_t g = (uint64_t)blockIdx.x * spb + t;
+    const bool live = t < spb && g < ss.total;
+    const bool second = live && g >= ss.n;
+    const uint64_t j = second ? g - ss.n : g;
+#pragma unroll
+    for (int w = 0; w < SORT1_MAXW; w++) keyn[w] = 0xffffffffu;
+    if (live) {
+        uint32_t sc[8];
+        load_scalar(sc, second ? ss.scalars2 : scalars, j, second ? ss.mont2 : ss.mont);
+        const uint32_t set_bit = second ? 1u << ss.keybits : 0u;
+        uint32_t carry = 0, neg;
+#pragma unroll
+        for (int w = 0; w < SORT1_MAXW; w++) {
+            if (w < lay.nwin) {
+                const uint32_t mag = signed_digit(sc, w, lay, carry, neg);
+                if (mag) {
+                    const uint32_t key = (mag - 1) | set_bit;
+                    keyn[w] = key | (neg << 31);
+                    rk[w] = lds_bump(h, key >> ss.lbits);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // 2. exclusive scan of the counts
+    const uint32_t per = (npart + 1023u) / 1024u;
+    const uint32_t b0 = t * per, b1 = min(b0 + per, npart);
+    uint32_t sum = 0;
+    for (uint32_t i = b0; i < b1; i++) sum += h[i];
+    wsum[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t x = (t >= d) ? wsum[t - d] : 0;
+        __syncthreads();
+        wsum[t] += x;
+        __syncthreads();
+    }
+    const uint32_t count = wsum[1023];
+    uint32_t run = wsum[t] - sum;
+    // 3. reserve the global run of every non-empty partition; h becomes (global position - local position)
+    for (uint32_t i = b0; i < b1; i++) {
+        const uint32_t c = h[i];
+        loff[i] = run;
+        if (c) h[i] = part_base[i] + atomicAdd(&part_cursor[i], c) - run;
+        run += c;
+    }
+    __syncthreads();
+    // 4. place the entries at their local sorted position
+    if (live) {
+        const uint32_t lmask = (1u << ss.lbits) - 1u;
+#pragma unroll
+        for (int w = 0; w < SORT1_MAXW; w++) {
+            if (keyn[w] != 0xffffffffu) {
+                const uint32_t key = keyn[w] & 0x7fffffffu;
+                const uint32_t q = key >> ss.lbits;
+                const uint32_t i = loff[q] + rk[w];
+                stage[i] = make_uint2(key & lmask,
+                                      (uint32_t)((uint64_t)w * ss.srs_stride + ss.srs_offset + j) | (keyn[w] & 0x80000000u));
+                stq[i] = (uint16_t)q;
+            }
+        }
+    }
+    __syncthreads();
+    // 5. copy out: consecutive lanes -> consecutive addresses inside each partition's run
+    for (uint32_t i = t; i < count; i += 1024) parted[h[stq[i]] + i] = stage[i];
+}
+
 #define SORT_STAGE 14336  // 56 KB: two workgroups per CU still fit (2 x (56 + 16 + 4) KB)
 // one workgroup per partition: LDS histogram of the low bits -> bucket offsets -> scatter inside the partition
 __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__ parted, const uint32_t* __restrict__ part_base,
@@ -1108,7 +1196,14 @@ void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars,
     const uint32_t blocks = nblk(ss.total, ss.spb);
     k_sort_count<<<blocks, 256, 0, s>>>(scalars, ss, sh.lay, part_count);
     k_sort_part_scan<<<1, 1024, 0, s>>>(part_count, npart, part_base, part_cursor);
-    k_sort_partition<<<blocks, 256, 0, s>>>(scalars, ss, sh.lay, part_base, part_cursor, parted);
+    if (sh.nwin <= SORT1_MAXW) {
+        uint32_t spb2 = (SORT1_STAGE / (uint32_t)sh.nwin) & ~63u;  // one scalar per lane, <= SORT1_STAGE entries
+        if (spb2 > 1024) spb2 = 1024;
+        k_sort_partition_staged<<<nblk(ss.total, spb2), 1024, 0, s>>>(scalars, ss, sh.lay, spb2, part_base, part_cursor,
+                                                                     parted);
+    } else {
+        k_sort_partition<<<blocks, 256, 0, s>>>(scalars, ss, sh.lay, part_base, part_cursor, parted);
+    }
     k_sort_buckets<<<npart, 1024, 0, s>>>(parted, part_base, ss.lbits, offsets, sorted, npart);
 }
 void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t* table, const uint32_t* offsets,
