@@ -74,7 +74,8 @@ int kzg_commit(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t T, in
 /* replaces Client.worker_open(i, poly, x)           (reference neurons/miner.py:47-54) */
 int kzg_open(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
              const uint8_t alpha_be32[32], uint8_t out_eval32[32], uint8_t out_proof48[48]);
-/* fused Miner.rpc_commit_and_open (reference neurons/miner.py:56-61): one upload, one IFFT, two MSMs */
+/* fused Miner.rpc_commit_and_open (reference neurons/miner.py:56-61): one upload, one IFFT, the two MSMs as one
+ * batched pass (rows <= 2^18) or on two streams */
 int kzg_commit_open(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
                     const uint8_t alpha_be32[32], uint8_t out_commitment48[48], uint8_t out_eval32[32],
                     uint8_t out_proof48[48]);
@@ -126,7 +127,7 @@ int kzg_msm_partial_resident(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_of
  * lanes (own stream + workspace) and returns; wait blocks for that ticket and writes 48 (partial=0) or 192 bytes.
  * MSM i+1's sort/accumulate then overlaps the latency-bound tail of MSM i.  Results are identical to the blocking
  * calls.  With both lanes taken submit fails with KZG_E_BUSY; while any ticket is outstanding only kzg_msm_submit,
- * kzg_msm_wait and kzg_g1_sum are accepted on the context (everything else returns KZG_E_BUSY). */
+ * kzg_msm_wait and kzg_g1_sum[_dev] are accepted on the context (everything else returns KZG_E_BUSY). */
 int kzg_msm_submit(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, int partial, int* out_ticket);
 int kzg_msm_wait(kzg_ctx* ctx, int ticket, uint8_t* out);
 int kzg_commit_open_resident(kzg_ctx* ctx, uint32_t i, int slot, uint64_t T, int evaluation_form,
@@ -155,7 +156,7 @@ int kzg_msm_plan(kzg_ctx* ctx, uint64_t n, int32_t out[4]);
 int kzg_b64_decode_fr(const char* packed43, uint64_t n, uint8_t* out_be32);
 int kzg_b64_encode_fr(const uint8_t* be32, uint64_t n, char* out_packed43);
 
-/* ---- unit-op hooks for the parity tests (tests/test_gpu_field.py); not part of the serving surface */
+/* ---- unit-op hooks for the parity tests (tests/test_gpu_parity.py); not part of the serving surface */
 int kzg_test_field(kzg_ctx* ctx, int field /*0 Fp,1 Fr*/, int op /*0 mul,1 add,2 sub,3 mul(plain C ref),4 sqr*/,
                    const uint8_t* a_be, const uint8_t* b_be, uint8_t* out_be, uint64_t n);
 int kzg_test_g1(kzg_ctx* ctx, int op /*0 a+b mixed,1 2a+b full,2 2a,3 4a,4 a+20a+20b chain*/, const uint8_t* a_be96,
