@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(1024) k_sort_partition_staged(const uint32_t* 
     for (uint32_t i = t; i < count; i += 1024) parted[h[stq[i]] + i] = stage[i];
 }
 
-#define SORT_STAGE 14336  // 56 KB: two workgroups per CU still fit (2 x (56 + 16 + 4) KB)
+#define SORT_STAGE 28672  // 112 KB: one 1024-thread workgroup per CU; fewer, larger partitions keep level 1's runs longer (A/B)
 // one workgroup per partition: LDS histogram of the low bits -> bucket offsets -> scatter inside the partition
 __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__ parted, const uint32_t* __restrict__ part_base,
                                                         int lbits, uint32_t* __restrict__ offsets,
@@ -1179,10 +1179,10 @@ void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars,
     ss.n = sh.n; ss.total = sh.n << setbits; ss.srs_offset = sh.srs_offset; ss.srs_stride = sh.srs_stride;
     ss.mont = scalars_mont; ss.scalars2 = scalars2; ss.mont2 = scalars2_mont; ss.keybits = sh.c - 1;
     // 1024 partitions (level 2 runs one workgroup per partition), up to 4096 when that brings a partition down to what
-    // level 2 can stage in LDS (SORT_STAGE entries; ~13 k on average at 2^20 / 1024 and at 2^22 / 4096 partitions)
+    // level 2 can stage in LDS (SORT_STAGE entries; ~13 k on average at 2^20 / 1024, ~27 k at 2^22 / 2048 and 2^23 / 4096)
     const uint64_t entries = ss.total * (uint64_t)sh.nwin;
     int hbits = 10;
-    while (hbits < 12 && (entries >> hbits) > 12288) hbits++;
+    while (hbits < 12 && (entries >> hbits) > 24576) hbits++;
     if (hbits > keybits) hbits = keybits;
     if (keybits - hbits > 12) hbits = keybits - 12;  // level 2 histograms at most 4096 buckets
     ss.hbits = hbits;
