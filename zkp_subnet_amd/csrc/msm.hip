@@ -81,15 +81,35 @@ KZG_DEV void for_each_entry(const uint32_t* __restrict__ scalars, const SortShap
         }
     }
 }
-__global__ void __launch_bounds__(256) k_sort_count(const uint32_t* __restrict__ scalars, const SortShape ss,
-                                                     const WinLayout lay, uint32_t* __restrict__ part_count) {
+// partition sizes: 1024 lanes x 4 scalars each (all four loads in flight before the first digit is extracted)
+__global__ void __launch_bounds__(1024) k_sort_count(const uint32_t* __restrict__ scalars, const SortShape ss,
+                                                      const WinLayout lay, uint32_t* __restrict__ part_count) {
     __shared__ uint32_t h[SORT_MAXPART];
     const uint32_t npart = 1u << ss.hbits;
-    for (uint32_t i = threadIdx.x; i < npart; i += 256) h[i] = 0;
+    for (uint32_t i = threadIdx.x; i < npart; i += 1024) h[i] = 0;
     __syncthreads();
-    for_each_entry(scalars, ss, lay, [&](uint32_t key, uint32_t) { lds_bump(h, key >> ss.lbits); });
+    uint32_t sc[4][8];
+    bool live[4], second[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint64_t g = (uint64_t)blockIdx.x * 4096 + r * 1024 + threadIdx.x;
+        live[r] = g < ss.total;
+        second[r] = live[r] && g >= ss.n;
+        const uint64_t j = second[r] ? g - ss.n : g;
+        if (live[r]) load_scalar(sc[r], second[r] ? ss.scalars2 : scalars, j, second[r] ? ss.mont2 : ss.mont);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (!live[r]) continue;
+        const uint32_t set_bit = second[r] ? 1u << ss.keybits : 0u;
+        uint32_t carry = 0, neg;
+        for (int w = 0; w < lay.nwin; w++) {
+            const uint32_t mag = signed_digit(sc[r], w, lay, carry, neg);
+            if (mag) lds_bump(h, ((mag - 1) | set_bit) >> ss.lbits);
+        }
+    }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < npart; i += 256)
+    for (uint32_t i = threadIdx.x; i < npart; i += 1024)
         if (h[i]) atomicAdd(&part_count[i], h[i]);
 }
 // part_base[0..npart] = exclusive scan of part_count (npart <= 4096); cursors zeroed
@@ -1194,7 +1214,7 @@ void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars,
     uint32_t* part_cursor = part_ws + 2 * SORT_MAXPART + 8;
     (void)hipMemsetAsync(part_count, 0, npart * 4, s);
     const uint32_t blocks = nblk(ss.total, ss.spb);
-    k_sort_count<<<blocks, 256, 0, s>>>(scalars, ss, sh.lay, part_count);
+    k_sort_count<<<nblk(ss.total, 4096), 1024, 0, s>>>(scalars, ss, sh.lay, part_count);
     k_sort_part_scan<<<1, 1024, 0, s>>>(part_count, npart, part_base, part_cursor);
     if (sh.nwin <= SORT1_MAXW) {
         uint32_t spb2 = (SORT1_STAGE / (uint32_t)sh.nwin) & ~63u;  // one scalar per lane, <= SORT1_STAGE entries
