@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) k_sort_partition(const uint32_t* __restri
 // entries are ordered by partition inside LDS and leave as runs of consecutive addresses instead of 8-byte singles
 // (the direct scatter wrote 3.5x the bytes it stored).  Used when nwin <= 16; otherwise k_sort_partition.
 #define SORT1_MAXW 16
-#define SORT1_STAGE 10240  // entries per workgroup: 80 KB of (key_low, value) + 20 KB of partition ids
+#define SORT1_STAGE 13312  // entries per workgroup: 104 KB of (key_low | partition << 16, value); 1024 scalars at 13 windows
 __global__ void __launch_bounds__(1024) k_sort_partition_staged(const uint32_t* __restrict__ scalars, const SortShape ss,
                                                                  const WinLayout lay, uint32_t spb,
                                                                  const uint32_t* __restrict__ part_base,
@@ -173,8 +173,7 @@ __global__ void __launch_bounds__(1024) k_sort_partition_staged(const uint32_t* 
     __shared__ uint32_t h[SORT_MAXPART];     // counts, then (global base - local offset) per partition
     __shared__ uint32_t loff[SORT_MAXPART];  // local exclusive offsets
     __shared__ uint32_t wsum[1024];
-    __shared__ uint2 stage[SORT1_STAGE];
-    __shared__ uint16_t stq[SORT1_STAGE];
+    __shared__ uint2 stage[SORT1_STAGE];  // .x = key_low (<= 12 bits) | partition << 16
     const uint32_t t = threadIdx.x;
     const uint32_t npart = 1u << ss.hbits;
     for (uint32_t i = t; i < npart; i += 1024) h[i] = 0;
@@ -237,15 +236,17 @@ __global__ void __launch_bounds__(1024) k_sort_partition_staged(const uint32_t* 
                 const uint32_t key = keyn[w] & 0x7fffffffu;
                 const uint32_t q = key >> ss.lbits;
                 const uint32_t i = loff[q] + rk[w];
-                stage[i] = make_uint2(key & lmask,
+                stage[i] = make_uint2((key & lmask) | (q << 16),
                                       (uint32_t)((uint64_t)w * ss.srs_stride + ss.srs_offset + j) | (keyn[w] & 0x80000000u));
-                stq[i] = (uint16_t)q;
             }
         }
     }
     __syncthreads();
     // 5. copy out: consecutive lanes -> consecutive addresses inside each partition's run
-    for (uint32_t i = t; i < count; i += 1024) parted[h[stq[i]] + i] = stage[i];
+    for (uint32_t i = t; i < count; i += 1024) {
+        const uint2 v = stage[i];
+        parted[h[v.x >> 16] + i] = make_uint2(v.x & 0xffffu, v.y);
+    }
 }
 
 #define SORT_STAGE 28672  // 112 KB: one 1024-thread workgroup per CU; fewer, larger partitions keep level 1's runs longer (A/B)
