@@ -37,7 +37,7 @@ def scalars(n, kind):
 
 while time.time() < t_end:
     # ---- one engine / SRS per round
-    lg = rnd.choice((3, 5, 8, 10, 11, 12, 13, 14, 15, 16))
+    lg = rnd.choice((3, 5, 8, 10, 11, 12, 13, 14, 15, 16, 16, 17, 18))
     ms = rnd.choice((0, 0, 1, 2)) if lg >= 4 else 0
     window = rnd.choice((0, 0, 0, 4, 5, 7, 8, 9, 11, 12, 13, 15, 16, 17, 18))
     tx, ty = rnd.randrange(2, o.R), rnd.randrange(2, o.R)
