@@ -160,10 +160,10 @@ __global__ void __launch_bounds__(256) k_sort_partition(const uint32_t* __restri
         parted[pos] = make_uint2(key & lmask, val);
     });
 }
-// ---- level 1, staged: one scalar per lane (its <= 16 digits stay in registers: no second decode), the workgroup's
+// ---- level 1, staged: one scalar per lane (its <= 32 digits stay in registers: no second decode), the workgroup's
 // entries are ordered by partition inside LDS and leave as runs of consecutive addresses instead of 8-byte singles
-// (the direct scatter wrote 3.5x the bytes it stored).  Used when nwin <= 16; otherwise k_sort_partition.
-#define SORT1_MAXW 16
+// (the direct scatter wrote 3.5x the bytes it stored).  Used when nwin <= 32 (c >= 8); otherwise k_sort_partition.
+#define SORT1_MAXW 32
 #define SORT1_STAGE 13312  // entries per workgroup: 104 KB of (key_low | partition << 16, value); 1024 scalars at 13 windows
 __global__ void __launch_bounds__(1024) k_sort_partition_staged(const uint32_t* __restrict__ scalars, const SortShape ss,
                                                                  const WinLayout lay, uint32_t spb,
