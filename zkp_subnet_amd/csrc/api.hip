@@ -56,7 +56,7 @@ struct StageSpan {
 // and latency-bound tail (carry fold, bucket tree, final combination) hide under the other's accumulate.
 struct MsmLane {
     hipStream_t stream = nullptr;
-    DevBuf rank, sorted, hist, offsets, bufA, bufB, carries, carry_key;
+    DevBuf rank, sorted, hist, offsets, bufA, bufB, bufC, carries, carry_key;
     DevBuf res, small;           // result point + its encoded form, for the ticketed (asynchronous) MSM
     hipEvent_t ev_sorted = nullptr, ev_done = nullptr;
     bool busy = false;           // a ticket is outstanding on this lane
@@ -238,7 +238,8 @@ int msm_core(kzg_ctx* ctx, int li, const uint32_t* scalars, int mont, uint64_t n
     HIPCHK(ctx, L.hist.ensure(16384 * 4));
     HIPCHK(ctx, L.offsets.ensure((B + 1) * 4));
     HIPCHK(ctx, L.bufA.ensure(B * sizeof(g1_xyzz_t)));
-    HIPCHK(ctx, L.bufB.ensure(B * sizeof(g1_xyzz_t)));
+    HIPCHK(ctx, L.bufB.ensure(B * sizeof(g1_xyzz_t) / 2 + 4096));   // level arrays: n/2^L nodes x L components <= B/2
+    HIPCHK(ctx, L.bufC.ensure(B * sizeof(g1_xyzz_t) / 2 + 4096));
     HIPCHK(ctx, L.carries.ensure((size_t)nchunks * sizeof(g1_xyzz_t)));
     HIPCHK(ctx, L.carry_key.ensure((size_t)nchunks * 4));
     uint32_t* max_len_d = ctx->flags + 2 + li;
@@ -269,19 +270,24 @@ int msm_core(kzg_ctx* ctx, int li, const uint32_t* scalars, int mont, uint64_t n
         launch_fold_heads(s, L.offsets.as<uint32_t>(), L.carry_key.as<uint32_t>(), (uint32_t)sh.chunk, nchunks,
                           L.carries.as<g1_xyzz_t>(), L.bufA.as<g1_xyzz_t>());
     }
+    // three buffers in rotation: a level reads its own array and the P array of the level below, writes the next
     g1_xyzz_t* in = L.bufA.as<g1_xyzz_t>();
+    g1_xyzz_t* prev = L.bufC.as<g1_xyzz_t>();
     g1_xyzz_t* out = L.bufB.as<g1_xyzz_t>();
     {
         Span sp(ctx, KZG_T_TREE, s, li);
         uint32_t n_in = sh.nbuckets;
         for (int level = 0; n_in > (uint32_t)nbatch; level++, n_in >>= 1) {
-            launch_msm_tree_level(s, in, out, n_in, level);
-            std::swap(in, out);
+            launch_msm_tree_level(s, in, prev, out, n_in, level);
+            g1_xyzz_t* recycled = prev;
+            prev = in;
+            in = out;
+            out = recycled;
         }
     }
     {
         Span sp(ctx, KZG_T_FINAL, s, li);
-        launch_msm_final(s, in, ctx->c - 1, nbatch, out_xyzz);
+        launch_msm_final(s, in, prev, ctx->c - 1, nbatch, out_xyzz);
     }
     HIPCHK(ctx, hipGetLastError());
     return KZG_OK;
@@ -600,7 +606,7 @@ void kzg_destroy(kzg_ctx* ctx) {
                           &ctx->coeffB, &ctx->qbuf, &ctx->hbuf, &ctx->hnext, &ctx->small, &ctx->out_be};
         for (DevBuf* b : bufs) b->release();
         for (MsmLane& L : ctx->lane) {
-            for (DevBuf* b : {&L.rank, &L.sorted, &L.hist, &L.offsets, &L.bufA, &L.bufB, &L.carries, &L.carry_key})
+            for (DevBuf* b : {&L.rank, &L.sorted, &L.hist, &L.offsets, &L.bufA, &L.bufB, &L.bufC, &L.carries, &L.carry_key})
                 b->release();
             L.res.release();
             L.small.release();

@@ -51,11 +51,16 @@ void launch_fold_step(hipStream_t s, const uint32_t* offsets, const uint32_t* ca
 void launch_fold_heads(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
                        uint32_t nchunks, const g1_xyzz_t* carries, g1_xyzz_t* buckets);
 // level i: in = nodes of (i+1) points, component-major; out = nodes of (i+2) points
-void launch_msm_tree_level(hipStream_t s, const g1_xyzz_t* in, g1_xyzz_t* out, uint32_t n_in_nodes, int level);
+// one merge level: `in` = the level-`level` array (n_in_nodes nodes; P, T_0 .. T_{level-2} stored component-major),
+// `prev` = the level below it (its P array holds the T_{level-1} of `in`'s nodes; unused at level 0), `out` = the
+// level + 1 array.  in, prev and out must be three different buffers.
+void launch_msm_tree_level(hipStream_t s, const g1_xyzz_t* in, const g1_xyzz_t* prev, g1_xyzz_t* out,
+                           uint32_t n_in_nodes, int level);
 // node = [P, T_0 .. T_{nbits-1}] ; out_xyzz = P + sum 2^i T_i
-// nodes: the bucket tree stopped at `nodes` roots (component-major: component k of root m at node[k * nodes + m]);
-// out_xyzz[m] = P_m + sum_i 2^i T_{i,m}
-void launch_msm_final(hipStream_t s, const g1_xyzz_t* node, int nbits, int nodes, g1_xyzz_t* out_xyzz);
+// nodes: the bucket tree stopped at `nodes` roots (component-major: component k of root m at node[k * nodes + m];
+// T_{nbits-1} of root m is P[2m + 1] of the level below, `prev`); out_xyzz[m] = P_m + sum_i 2^i T_{i,m}
+void launch_msm_final(hipStream_t s, const g1_xyzz_t* node, const g1_xyzz_t* prev, int nbits, int nodes,
+                      g1_xyzz_t* out_xyzz);
 // sum `count` XYZZ points (count <= 1024) into out_xyzz[0]
 void launch_g1_sum(hipStream_t s, const g1_xyzz_t* in, uint32_t count, g1_xyzz_t* out_xyzz);
 // affine + ZCash compression of one point

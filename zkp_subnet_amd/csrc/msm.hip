@@ -488,21 +488,35 @@ __global__ void __launch_bounds__(256) k_fold_heads(const uint32_t* __restrict__
 // Merging left (bit L = 0) and right (bit L = 1): P = P_l + P_r, T_k = T_k_l + T_k_r, T_L = P_r.
 // Every add of a level is independent, so the serial depth of the whole reduction is log2(B) point adds,
 // and sum_k (k+1) B_k = P + sum_i 2^i T_i at the root.
+// T_L of a merged node is just the P of its right child: it is never copied.  A level-L array stores P, T_0 .. T_{L-2}
+// (L components, one at levels 0 and 1); T_{L-1} of node m is read where it already lies, at P[2m + 1] of the
+// level-(L-1) array `prev` -- so the merge L -> L+1 does (L + 1) additions per output node and no copy:
+//   k = 0 .. L-1 : out[k][m] = in[k][2m] + in[k][2m+1]          (P and the stored T's)
+//   k = L (L>=1) : out[L][m] = prev[0][4m+1] + prev[0][4m+3]    (T_{L-1} of the two children)
+KZG_DEV void tree_operands(const g1_xyzz_t* in, const g1_xyzz_t* prev, uint32_t n_in, int level, uint32_t k, uint32_t m,
+                           const g1_xyzz_t*& pa, const g1_xyzz_t*& pb) {
+    if (level >= 1 && k == (uint32_t)level) {
+        pa = &prev[4 * (uint64_t)m + 1];
+        pb = &prev[4 * (uint64_t)m + 3];
+    } else {
+        pa = &in[(uint64_t)k * n_in + 2 * m];
+        pb = pa + 1;
+    }
+}
 __global__ void __launch_bounds__(256) k_msm_tree_level(const g1_xyzz_t* __restrict__ in,
+                                                         const g1_xyzz_t* __restrict__ prev,
                                                          g1_xyzz_t* __restrict__ out, uint32_t n_in, int level) {
     tail_priority();
     const uint32_t n_out = n_in >> 1;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n_out * (uint32_t)(level + 2)) return;
+    if (gid >= n_out * (uint32_t)(level + 1)) return;
     const uint32_t k = gid / n_out, m = gid - k * n_out;
+    const g1_xyzz_t *pa, *pb;
+    tree_operands(in, prev, n_in, level, k, m, pa, pb);
     g1_xyzz_t a, b, r;
-    if (k == (uint32_t)(level + 1)) {
-        load_xyzz(r, &in[2 * m + 1]);
-    } else {
-        load_xyzz(a, &in[(uint64_t)k * n_in + 2 * m]);
-        load_xyzz(b, &in[(uint64_t)k * n_in + 2 * m + 1]);
-        g1_add<true>(r, a, b);  // wide levels are throughput-bound: inlined products (-4 %, same-box A/B)
-    }
+    load_xyzz(a, pa);
+    load_xyzz(b, pb);
+    g1_add<true>(r, a, b);  // wide levels are throughput-bound: inlined products (-4 %, same-box A/B)
     store_xyzz(&out[(uint64_t)k * n_out + m], r);
 }
 
@@ -728,22 +742,17 @@ __global__ void __launch_bounds__(256) k_fold_heads_coop(const uint32_t* __restr
 
 // same merge as k_msm_tree_level, 64 operations per 256-thread workgroup, for the narrow (latency-bound) levels
 __global__ void __launch_bounds__(256) k_msm_tree_level_coop(const g1_xyzz_t* __restrict__ in,
+                                                              const g1_xyzz_t* __restrict__ prev,
                                                               g1_xyzz_t* __restrict__ out, uint32_t n_in, int level) {
     tail_priority();
     __shared__ CoopLds sm;
     const uint32_t n_out = n_in >> 1;
     const uint32_t gid = blockIdx.x * 64 + (threadIdx.x & 63);
-    const bool active = gid < n_out * (uint32_t)(level + 2);
+    const bool active = gid < n_out * (uint32_t)(level + 1);
     const uint32_t k = active ? gid / n_out : 0, m = active ? gid - k * n_out : 0;
-    const bool is_copy = k == (uint32_t)(level + 1);
-    g1_xyzz_t* dst = &out[(uint64_t)k * n_out + m];
-    if (active && is_copy && threadIdx.x < 64) {
-        g1_xyzz_t a;
-        load_xyzz(a, &in[2 * m + 1]);
-        store_xyzz(dst, a);
-    }
-    const g1_xyzz_t* pa = &in[(uint64_t)k * n_in + 2 * m];
-    coop_add(sm, dst, pa, pa + 1, active && !is_copy);
+    const g1_xyzz_t *pa, *pb;
+    tree_operands(in, prev, n_in, level, k, m, pa, pb);
+    coop_add(sm, &out[(uint64_t)k * n_out + m], pa, pb, active);
 }
 
 // sum of the values held by lanes [0, nthreads) (power of two <= blockDim), result in every lane's `mine`
@@ -765,7 +774,9 @@ KZG_DEV void lds_tree_sum(g1_xyzz_t* sm, g1_xyzz_t& mine, uint32_t tid, uint32_t
 
 // node = [P, T_0..T_{nbits-1}]; operation i doubles T_i i times, then a 32- or 64-wide tree sum; every doubling and
 // addition is cooperative (one 256-thread workgroup = 64 operations).
-__global__ void __launch_bounds__(256) k_msm_final(const g1_xyzz_t* __restrict__ node, int nbits, int nodes,
+// node: the roots (level nbits: P, T_0 .. T_{nbits-2} stored); prev: the level below, whose P[2m+1] is T_{nbits-1}
+__global__ void __launch_bounds__(256) k_msm_final(const g1_xyzz_t* __restrict__ node,
+                                                    const g1_xyzz_t* __restrict__ prev, int nbits, int nodes,
                                                     g1_xyzz_t* __restrict__ out) {
     tail_priority();
     __shared__ CoopLds sm;
@@ -775,7 +786,8 @@ __global__ void __launch_bounds__(256) k_msm_final(const g1_xyzz_t* __restrict__
     if (threadIdx.x < 64) {
         g1_xyzz_t v;
         g1_set_inf(v);
-        if ((int)l < nbits) load_xyzz(v, &node[(uint64_t)(1 + l) * nodes + m]);
+        if ((int)l < nbits - 1) load_xyzz(v, &node[(uint64_t)(1 + l) * nodes + m]);
+        else if ((int)l == nbits - 1) load_xyzz(v, &prev[2 * m + 1]);
         else if ((int)l == nbits) load_xyzz(v, &node[m]);
         store_xyzz(&pts[l], v);
     }
@@ -1251,14 +1263,16 @@ void launch_fold_heads(hipStream_t s, const uint32_t* offsets, const uint32_t* c
     else
         k_fold_heads_coop<<<nblk(nchunks, 64), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, carries, buckets);
 }
-void launch_msm_tree_level(hipStream_t s, const g1_xyzz_t* in, g1_xyzz_t* out, uint32_t n_in_nodes, int level) {
-    uint32_t ops = (n_in_nodes >> 1) * (uint32_t)(level + 2);
+void launch_msm_tree_level(hipStream_t s, const g1_xyzz_t* in, const g1_xyzz_t* prev, g1_xyzz_t* out,
+                           uint32_t n_in_nodes, int level) {
+    uint32_t ops = (n_in_nodes >> 1) * (uint32_t)(level + 1);
     // wide levels are throughput-bound (one lane per addition); narrow ones are latency-bound (4 waves per addition)
-    if (ops > 32768) k_msm_tree_level<<<nblk(ops, 256), 256, 0, s>>>(in, out, n_in_nodes, level);
-    else k_msm_tree_level_coop<<<nblk(ops, 64), 256, 0, s>>>(in, out, n_in_nodes, level);
+    if (ops > 32768) k_msm_tree_level<<<nblk(ops, 256), 256, 0, s>>>(in, prev, out, n_in_nodes, level);
+    else k_msm_tree_level_coop<<<nblk(ops, 64), 256, 0, s>>>(in, prev, out, n_in_nodes, level);
 }
-void launch_msm_final(hipStream_t s, const g1_xyzz_t* node, int nbits, int nodes, g1_xyzz_t* out_xyzz) {
-    k_msm_final<<<nodes, 256, 0, s>>>(node, nbits, nodes, out_xyzz);
+void launch_msm_final(hipStream_t s, const g1_xyzz_t* node, const g1_xyzz_t* prev, int nbits, int nodes,
+                      g1_xyzz_t* out_xyzz) {
+    k_msm_final<<<nodes, 256, 0, s>>>(node, prev, nbits, nodes, out_xyzz);
 }
 void launch_g1_sum(hipStream_t s, const g1_xyzz_t* in, uint32_t count, g1_xyzz_t* out_xyzz) {
     k_g1_sum<<<1, 64, 0, s>>>(in, count, out_xyzz);
