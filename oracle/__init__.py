@@ -13,7 +13,7 @@ session, reference ``tests/conftest.py:50-65``).  What *is* pinned:
 
 * the Fr wire encoding and ``eval`` -- by the one known-answer vector the
   reference holds (``tests/test_miner.py:33-55``: TEST_POLY / TEST_POINT /
-  TEST_EVAL), checked in ``tests/test_oracle_kat.py``;
+  TEST_EVAL), checked in ``tests/test_oracle.py``;
 * public constants of BLS12-381 (generator, ZCash 48-byte compression, 2-adic
   root of unity derived from 7).
 

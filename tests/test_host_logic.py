@@ -1,7 +1,7 @@
 """CPU-only tests of the host side above the C-ABI: the Client method surface / status mapping, the miner and
 validator mirrors, and the config-1 plumbing loop (degree-2^12 commit through the CPU prover under a mock
 miner/validator loop, BASELINE.json configs[0]).  The engine is the oracle-backed stand-in (tests/oracle_engine.py);
-the same tests run against the HIP engine in tests/test_gpu_kzg.py."""
+the same tests run against the HIP engine in tests/test_gpu_parity.py."""
 import base64
 import random
 
@@ -176,3 +176,32 @@ def test_commitment_api_shape(fr_kat):
     syn = api.prepare_synapse(fr_kat["poly"], 1)
     assert syn.poly == fr_kat["poly"] and syn.alpha is None and syn.index == 1
     assert api.select_commitment([None, 3, "", "abc", "def"]) == "abc" and api.select_commitment([]) is None
+
+
+def test_missing_setup_file_is_an_error_unless_synthetic_requested(tmp_path, caplog):
+    """The reference prover fails when its setup file is absent (base/miner.py:75-84 hands the path to the binary).  A
+    synthetic SRS has a public trapdoor, so it must be asked for explicitly (synthetic=True or an explicit seed)."""
+    missing = str(tmp_path / "no_such_setup")
+    c = Client(engine=OracleEngine(), setup_path=missing)
+    with pytest.raises(FileNotFoundError):
+        c.start(scale=6, machines_scale=2)
+    with pytest.raises(FileNotFoundError):      # the miner's defaults (setup_path="./setup", no seed) do not fall back
+        Miner(default_config(scale=6, machines_scale=2, setup_path=missing), client=None if False else Client(
+            engine=OracleEngine(), setup_path=missing))
+    import logging
+    with caplog.at_level(logging.WARNING, logger="zkp_subnet_amd.client"):
+        ok = Client(engine=OracleEngine(), setup_path=missing, synthetic=True)
+        ok.start(scale=6, machines_scale=2)
+    assert any("SYNTHETIC SRS" in r.message for r in caplog.records)
+    assert ok.worker_commit(0, [o.fr_to_b64(5)] * 16).status_code == 200
+    # seeds beyond 64 bits derive a trapdoor instead of overflowing
+    from zkp_subnet_amd.client import derive_taus
+    assert derive_taus(1 << 70) != derive_taus(1 << 71)
+
+
+def test_challenge_synapse_carries_eval():
+    """reference neurons/validator.py:41-42: the synapse sent to the miner carries the expected eval."""
+    from zkp_subnet_amd.validator import Challenge
+    ch = Challenge(polys=[["a"], ["b"]], alpha="x", evals=["e0", "e1"])
+    s = ch.to_synapse(1)
+    assert (s.index, s.poly, s.alpha, s.eval) == (1, ["b"], "x", "e1")

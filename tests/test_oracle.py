@@ -27,21 +27,53 @@ def test_reference_fr_kat_c(fr_kat, oracle_cpu):
     assert oracle_cpu.fr_eval(coeffs, x) == o.fr_from_b64(fr_kat["eval"]).to_bytes(32, "big")
 
 
+# Public literals, hard-coded here (NOT read from tests/golden/constants.json, which gen_golden.py writes from this same
+# oracle): the ZCash-compressed BLS12-381 G1 generator and the points 2G / -G (2G is the widely published BLS public key
+# of secret key 2), the identity encoding, and the roots of unity SURVEY.md Appendix A derived independently of oracle/.
+G1_C48 = "97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"
+TWO_G1_C48 = "a572cbea904d67468808c8eb50a9450c9721db309128012543902d0ac358a62ae28f75bb8f1c7c42c39a8c5529bf0f4e"
+NEG_G1_C48 = "b7f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"
+G1_Y = 0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1
+ROOTS = {
+    12: 0x564C0A11A0F704F4FC3E8ACFE0F8245F0AD1347B378FBF96E206DA11A5D36306,
+    20: 0x03E1C54BCB947035A57A6E07CB98DE4A2F69E02D265E09D9FECE7E0E39898D4B,
+    22: 0x0ABE6A5E5ABCAA32F2D38F10FBB8D1BBE08FEC7C86389BEEC6E7A6FFB08E3363,
+    32: 0x16A2A19EDFE81F20D09B681922C813B4B63683508C2280B93829971F439F0D2B,
+}
+
+
 def test_constants(golden_constants):
     x = o.BLS_X
     assert o.R == x**4 - x**2 + 1
     assert o.P == (x - 1) ** 2 * o.R // 3 + x
-    assert o.is_on_curve(o.G1)
+    assert o.P == 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+    assert o.R == 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    assert o.is_on_curve(o.G1) and o.G1[1] == G1_Y
     assert o.g1_mul(o.G1, o.R - 1) == o.g1_neg(o.G1)  # group order
-    assert o.g1_compress(o.G1).hex() == golden_constants["g1_compressed"]
-    assert golden_constants["g1_compressed"].startswith("97f1d3a73197d794") and golden_constants[
-        "g1_compressed"
-    ].endswith("db22c6bb")
+    assert o.g1_compress(o.G1).hex() == G1_C48
+    assert o.g1_compress(o.g1_mul(o.G1, 2)).hex() == TWO_G1_C48
+    assert o.g1_compress(o.g1_neg(o.G1)).hex() == NEG_G1_C48
+    assert o.g1_decompress(H(TWO_G1_C48)) == o.g1_add(o.G1, o.G1)
+    assert o.g1_decompress(H(NEG_G1_C48)) == o.g1_neg(o.G1)
+    assert o.g1_compress(o.g1_mul(o.G1, o.R)).hex() == "c0" + "00" * 47      # identity
+    for k, w in ROOTS.items():
+        assert o.root_of_unity(1 << k) == w
+        assert pow(w, 1 << k, o.R) == 1 and pow(w, 1 << (k - 1), o.R) == o.R - 1
+    # the committed fixture file agrees with the literals above (it is generated from the oracle: no extra evidence)
+    assert golden_constants["g1_compressed"] == G1_C48
+    assert golden_constants["two_g1_compressed"] == TWO_G1_C48
+    assert golden_constants["neg_g1_compressed"] == NEG_G1_C48
     assert golden_constants["identity_compressed"] == "c0" + "00" * 47
-    assert o.root_of_unity(1 << 32) == 0x16A2A19EDFE81F20D09B681922C813B4B63683508C2280B93829971F439F0D2B
     for k, v in golden_constants["roots_of_unity"].items():
         w = int(v, 16)
         assert pow(w, 1 << int(k), o.R) == 1 and pow(w, 1 << (int(k) - 1), o.R) == o.R - 1
+
+
+def test_constants_c_oracle(oracle_cpu):
+    """The same public literals through the C restatement (oracle/kzg_cpu.c): [1]G, [2]G, [r-1]G as one-point MSMs."""
+    g = o.g1_to_be96(o.G1)
+    for k, want in ((1, G1_C48), (2, TWO_G1_C48), (o.R - 1, NEG_G1_C48), (0, "c0" + "00" * 47)):
+        assert oracle_cpu.msm(g, k.to_bytes(32, "big")).hex() == want
 
 
 def test_non_canonical_fr_rejected():

@@ -12,6 +12,7 @@ prover failure -> 500, not implemented -> 501.
 """
 from __future__ import annotations
 
+import logging
 import os
 import secrets
 from typing import Any, Dict, List, Optional, Sequence
@@ -20,6 +21,7 @@ from . import codec
 from ._native import KZG_E_ARG, KZG_E_POINT, KZG_E_SCALAR, KzgError
 
 R_MODULUS = codec.R_MODULUS
+log = logging.getLogger("zkp_subnet_amd.client")
 
 
 class Response:
@@ -66,18 +68,22 @@ def _guard(fn):
 class Client:
     """Drop-in for fourier.Client.  `port` and `bin` are accepted and ignored (there is no child process);
     `setup_path` names a file holding the 2^scale-point SRS as uncompressed affine G1 points (x||y, 96 B each,
-    big-endian) or, with `uncompressed=False`, as 48-byte ZCash-compressed points (decompressed on the GPU); when it does not exist a synthetic tau-derived SRS is generated on the GPU from `seed`
-    (tests / benches -- mirrors `fourier setup --generate-setup`, reference tests/conftest.py:50-65)."""
+    big-endian) or, with `uncompressed=False`, as 48-byte ZCash-compressed points (decompressed on the GPU).
+    A missing setup file is an error, as it is for the reference prover.  A synthetic tau-derived SRS (generated on
+    the GPU; its trapdoor is a public function of `seed`, so openings against it can be forged by anyone) is only
+    built on explicit request -- `synthetic=True` or an explicit `seed` -- for tests and benches (mirrors
+    `fourier setup --generate-setup`, reference tests/conftest.py:50-65), and is logged loudly."""
 
     def __init__(self, port: int = 1337, bin: str = "", uncompressed: bool = True, setup_path: str = "",
                  precompute_path: str = "", engine: Any = None, device: int = 0, seed: Optional[int] = None,
-                 workers: Optional[Sequence[int]] = None):
+                 workers: Optional[Sequence[int]] = None, synthetic: Optional[bool] = None):
         self.port, self.bin, self.uncompressed = port, bin, uncompressed
         self.setup_path, self.precompute_path = setup_path, precompute_path
         self.engine = engine
         self._own_engine = engine is None
         self.device = device
         self.seed = seed
+        self.synthetic = (seed is not None) if synthetic is None else bool(synthetic)
         self.workers = list(workers) if workers is not None else None
         self.scale = self.machines_scale = 0
 
@@ -105,7 +111,17 @@ class Client:
                     vk = f.read()
                 self.engine.set_verifier_key(vk[:192], vk[192:])
         else:
+            if not self.synthetic:
+                if self._own_engine:
+                    self.engine.close()
+                    self.engine = None
+                raise FileNotFoundError(
+                    f"setup file {self.setup_path!r} not found: generate one with `python -m zkp_subnet_amd.setup_cli "
+                    "setup --generate-setup ...`.  A synthetic SRS (public trapdoor: forgeable openings) is only built "
+                    "when asked for with Client(synthetic=True) or an explicit seed (tests / benches).")
             seed = self.seed if self.seed is not None else 0
+            log.warning("SYNTHETIC SRS from public seed %d: its trapdoor is computable by anyone -- openings can be "
+                        "forged.  Tests and benches only; production needs a setup file (setup_path).", seed)
             tau_x, tau_y = derive_taus(seed)
             self.tau_x, self.tau_y = tau_x, tau_y
             self.engine.gen_srs(tau_x, tau_y, scale, machines_scale, self.workers)
@@ -194,7 +210,8 @@ def derive_taus(seed: int):
     import hashlib
 
     def h(tag: bytes) -> int:
-        v = int.from_bytes(hashlib.sha256(b"kzg-mi355x-srs" + tag + seed.to_bytes(8, "big")).digest(), "big")
+        sb = seed.to_bytes(max(8, (seed.bit_length() + 7) // 8), "big")   # 8 bytes for seeds < 2^64 (fixture-stable)
+        v = int.from_bytes(hashlib.sha256(b"kzg-mi355x-srs" + tag + sb).digest(), "big")
         return v % (R_MODULUS - 2) + 2
 
     return h(b"x"), h(b"y")

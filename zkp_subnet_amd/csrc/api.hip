@@ -12,8 +12,8 @@
 #include <vector>
 
 #include "../../include/kzg_mi355x.h"
-#include "fr_kernels.cuh"
-#include "msm.cuh"
+#include "fr_kernels.hip.h"
+#include "msm.hip.h"
 
 #define KZG_VERSION "kzg_mi355x 0.1 (gfx950)"
 #define N_SLOTS 4
@@ -481,8 +481,8 @@ int precompute_tables(kzg_ctx* ctx) {
 }
 
 // ---- unit-op test kernels
-// Fr: saturated 32-bit Montgomery (field.cuh).  Fp: op 0 mul / 1 add / 2 sub / 4 sqr on the 28-bit-limb working
-// representation (fp28.cuh); op 3 = the plain-C++ 12 x 32-bit CIOS reference product.
+// Fr: saturated 32-bit Montgomery (field.hip.h).  Fp: op 0 mul / 1 add / 2 sub / 4 sqr on the 28-bit-limb working
+// representation (fp28.hip.h); op 3 = the plain-C++ 12 x 32-bit CIOS reference product.
 __global__ void __launch_bounds__(256) k_test_fr(int op, const uint8_t* a_be, const uint8_t* b_be, uint8_t* out_be,
                                                   uint64_t n) {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,9 +1,9 @@
 // Montgomery prime fields over SATURATED 32-bit limbs, values fully reduced in [0, m): Fr (scalar field, 8 limbs,
 // R = 2^256) for the NTT / opening kernels, and Fp (12 limbs, R = 2^384) as the reference implementation for the
-// unit tests and the packed HBM format.  The MSM's working Fp is the unsaturated 14 x 28-bit form of fp28.cuh.
+// unit tests and the packed HBM format.  The MSM's working Fp is the unsaturated 14 x 28-bit form of fp28.hip.h.
 // Constants were re-derived in oracle/bls12_381.py.
 #pragma once
-#include "bigint.cuh"
+#include "bigint.hip.h"
 
 struct FpParams {
     static constexpr int N = 12;

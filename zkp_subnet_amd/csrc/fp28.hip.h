@@ -1,6 +1,6 @@
 // Fp (BLS12-381 base field) on 14 unsaturated 28-bit limbs -- the MSM's working representation.
 //
-// Why not 12 saturated 32-bit limbs (field.cuh): on gfx950 a v_mad_u64_u32 costs about the same issue time as
+// Why not 12 saturated 32-bit limbs (field.hip.h): on gfx950 a v_mad_u64_u32 costs about the same issue time as
 // any other VOP3 instruction (scripts/ubench/valu_rates.hip: 2.3 ns vs 2.0 ns per wave-instruction per SIMD), so
 // the cost of a field product is its INSTRUCTION COUNT.  Saturated limbs need a carry instruction per limb product
 // (857 instructions / product); with 28-bit limbs a 64-bit column accumulator absorbs 14 products of up to 60
@@ -15,7 +15,7 @@
 // limbs without changing the value.  Subtraction adds a multiple of p whose limbs dominate the subtrahend's:
 // M4 for subtrahends < 2p, M8 for < 6p, M16 for < 14p (all with normalised limbs).
 #pragma once
-#include "bigint.cuh"
+#include "bigint.hip.h"
 
 struct alignas(8) fp_t {
     uint32_t l[14];
@@ -255,7 +255,7 @@ KZG_DEV fp_ret fp_vec(const fp_t& r) {
 }
 #ifndef KZG_FP_MUL_INLINE
 // Real function calls (s_swappc) for everything except the hot mixed addition (which inlines fp_mul_inline, see
-// g1.cuh fpm<>): one copy of the product / square per translation unit keeps the many point formulas of the tail
+// g1.hip.h fpm<>): one copy of the product / square per translation unit keeps the many point formulas of the tail
 // kernels small; vector-typed arguments stay in VGPRs across the call.
 static __device__ __noinline__ fp_ret fp_mul_raw(u32x4 a0, u32x4 a1, u32x4 a2, u32x2 a3, u32x4 b0, u32x4 b1, u32x4 b2,
                                                   u32x2 b3) {

@@ -3,7 +3,7 @@
 // Replaces what the external prover does behind fft(poly,left,inverse) / eval / the implicit IFFT + synthetic
 // division of worker_commit / worker_open (reference neurons/validator.py:59-65,98-104; neurons/miner.py:39,48).
 // Domain convention: w_n = 7^((r-1)/n), natural order in and out, inverse carries 1/n.
-#include "fr_kernels.cuh"
+#include "fr_kernels.hip.h"
 
 static inline uint32_t nblk(uint64_t n, uint32_t b) { return (uint32_t)((n + b - 1) / b); }
 

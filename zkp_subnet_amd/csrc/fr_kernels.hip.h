@@ -1,6 +1,6 @@
 // Fr-side kernel launchers (fr_kernels.hip): wire codec, NTT, opening evaluation + quotient.
 #pragma once
-#include "g1.cuh"
+#include "g1.hip.h"
 
 void launch_fr_from_be(hipStream_t s, const uint8_t* be, uint32_t* out, uint64_t n, int to_mont, uint32_t* bad);
 void launch_fr_to_be(hipStream_t s, const uint32_t* in, uint8_t* be, uint64_t n, int from_mont);

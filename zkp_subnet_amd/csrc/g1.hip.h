@@ -1,14 +1,14 @@
-// BLS12-381 G1 (y^2 = x^3 + 4 over Fp) for the MSM kernels, on the 28-bit-limb Fp of fp28.cuh.
+// BLS12-381 G1 (y^2 = x^3 + 4 over Fp) for the MSM kernels, on the 28-bit-limb Fp of fp28.hip.h.
 //   affine point (HBM)  : x, y canonical Montgomery residues packed as 12 x u32 each, 96 B; all-zero = infinity
 //   bucket / sum (XYZZ) : X, Y, ZZ, ZZZ as 14-limb fp_t, 224 B, x = X/ZZ, y = Y/ZZZ; ZZ all-zero limbs = infinity
-// Stored-coordinate classes (fp28.cuh): X normalised limbs, value < 14p; Y normalised, < 6p; ZZ, ZZZ product outputs
+// Stored-coordinate classes (fp28.hip.h): X normalised limbs, value < 14p; Y normalised, < 6p; ZZ, ZZZ product outputs
 // (< 2p).  Every formula below ends inside these classes, so they hold inductively; subtrahends use the multiple
 // of p that dominates their class (X: M16, Y: M8, product outputs: M4).
 // XYZZ because the bucket update is a *mixed* add (affine table point into a running bucket): 8M + 2S, no inversion
 // (EFD madd-2008-s); bucket + bucket is add-2008-s (12M + 2S).
 #pragma once
-#include "field.cuh"
-#include "fp28.cuh"
+#include "field.hip.h"
+#include "fp28.hip.h"
 
 // HBM form of a table point: one 128-byte line = x, y as 14 canonical 28-bit limbs each (the working representation:
 // no unpacking in the hot loop) + 16 bytes of padding.  A 96-byte packed row straddled two 128-B lines for 3 rows in 4.

@@ -1,7 +1,7 @@
-// Pippenger G1 MSM kernels for gfx950 (see msm.cuh for the pipeline).  No reference source exists for this
+// Pippenger G1 MSM kernels for gfx950 (see msm.hip.h for the pipeline).  No reference source exists for this
 // path (reference neurons/miner.py:39,48 only calls the external prover); the algorithm is restated from the
 // published bucket method and checked bit-for-bit against oracle/ in tests/test_gpu_*.py.
-#include "msm.cuh"
+#include "msm.hip.h"
 
 #define NONE_KEY 0xffffffffu
 

@@ -13,7 +13,7 @@
 //   6. msm_tree_level    log2(B) pairwise-merge levels producing P = sum B_k and T_i = sum_{bit i of k} B_k
 //   7. msm_final         sum = P + sum_i 2^i T_i  (-> XYZZ, optionally affine + 48-byte compression)
 #pragma once
-#include "g1.cuh"
+#include "g1.hip.h"
 
 // Window w covers scalar bits [off[w], off[w+1]); off[nwin] = 256.  Widths differ by at most one bit
 // (256 = nwin*base + extra), so no window is a short "top" window that would pile its digits on a few buckets.

@@ -16,10 +16,11 @@ log = logging.getLogger("zkp_subnet_amd.miner")
 
 
 def default_config(**over) -> SimpleNamespace:
-    """The six prover flags of the reference (utils/config.py:124-164), same names and defaults."""
+    """The six prover flags of the reference (utils/config.py:124-164), same names and defaults.  `seed` / `synthetic`
+    are test-only: without them a missing setup file makes the miner fail at start, like the reference prover."""
     cfg = SimpleNamespace(prover_path="./prover", uncompressed=False, setup_path="./setup",
-                          precompute_path="./precompute", scale=18, machines_scale=8, device=0, seed=0,
-                          fused=False, workers=None)
+                          precompute_path="./precompute", scale=18, machines_scale=8, device=0, seed=None,
+                          synthetic=None, fused=False, workers=None)
     for k, v in over.items():
         setattr(cfg, k, v)
     return cfg
@@ -37,8 +38,9 @@ class Miner:
             setup_path=self.config.setup_path,
             precompute_path=self.config.precompute_path,
             device=getattr(self.config, "device", 0),
-            seed=getattr(self.config, "seed", 0),
+            seed=getattr(self.config, "seed", None),
             workers=getattr(self.config, "workers", None),
+            synthetic=getattr(self.config, "synthetic", None),
         )
         self.client.start(scale=self.config.scale, machines_scale=self.config.machines_scale)
 

@@ -8,15 +8,19 @@ Generates a tau-derived SRS **on the GPU** and writes
   <setup-path>.vk   192 B [tau_x]_2 (uncompressed G2, x.c1||x.c0||y.c1||y.c0) + 96 B [L_i(tau_y)]_1 per worker
 which is what `Client(setup_path=...)` loads.  The window tables the reference keeps in --precompute-path are rebuilt on
 the GPU at Client.start(); --precompute-path is accepted for command-line compatibility and only receives a small
-note.  The trapdoor comes from --seed (tests / staging) or from os.urandom, and is discarded after use.
+note.  Without --seed, tau_x and tau_y are drawn independently and uniformly from [2, r) with `secrets` (full 255-bit
+entropy each) and discarded after use; --seed derives them from a public hash and is for tests only.  Either way this
+is a SINGLE-PARTY trapdoor: whoever ran the command could have kept it.  Fine for staging; a production SRS must come
+from a multi-party ceremony and be loaded through --setup-path like any other file.
 """
 from __future__ import annotations
 
 import argparse
 import os
+import secrets
 import sys
 
-from .client import derive_taus
+from .client import R_MODULUS, derive_taus
 from .engine import HipEngine, lagrange_factor
 from .verifier import Verifier
 
@@ -43,8 +47,11 @@ def main(argv=None) -> int:
     if os.path.exists(a.setup_path) and not a.overwrite:
         print(f"{a.setup_path} exists (use --overwrite)", file=sys.stderr)
         return 1
-    seed = a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "big")
-    tau_x, tau_y = derive_taus(seed)
+    if a.seed is not None:
+        print(f"WARNING: --seed {a.seed}: the trapdoor is a public function of the seed (tests only)", file=sys.stderr)
+        tau_x, tau_y = derive_taus(a.seed)
+    else:
+        tau_x, tau_y = secrets.randbelow(R_MODULUS - 2) + 2, secrets.randbelow(R_MODULUS - 2) + 2
     m = 1 << a.machines_scale
     T = 1 << (a.scale - a.machines_scale)
     eng = HipEngine(a.device)

@@ -16,7 +16,7 @@ class Challenge:  # reference neurons/validator.py:35-42
     evals: List[str]
 
     def to_synapse(self, i: int) -> Prove:
-        return Prove(index=i, poly=self.polys[i], alpha=self.alpha)
+        return Prove(index=i, poly=self.polys[i], alpha=self.alpha, eval=self.evals[i])
 
 
 def _ok(resp, key, what):
