@@ -1,18 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- the driver's measurement contract for the KZG segment-prover hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload msm20|kzg22]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload msm20|msm26|kzg22]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Default workload (BASELINE.json configs[1], the one the metric is quoted on): one step = one 2^20-point BLS12-381 G1
-Pippenger MSM per GPU over a cached (device-resident) SRS segment with device-resident random scalars.  With N > 1
-the MSM is SRS-sharded: rank g owns segment [g*2^20, (g+1)*2^20) of a 2^20*N-point SRS, reduces it to one 192-byte
-partial on its GPU, the partials are all_gathered over RCCL/xGMI and summed on every rank (weak scaling: per-GPU work
-fixed).  `value` = points of all ranks / wall time of the K timed steps (max over ranks).
+Default workload `msm20` (BASELINE.json configs[1], the one the metric is quoted on): one step = one 2^20-point
+BLS12-381 G1 Pippenger MSM per GPU over a cached (device-resident) SRS segment with device-resident random scalars.
+With N > 1 the MSM is SRS-sharded: rank g owns segment [g*2^20, (g+1)*2^20) of a 2^20*N-point SRS, reduces it to one
+192-byte partial on its GPU, the partials are all_gathered over RCCL/xGMI and summed on every rank (weak scaling:
+per-GPU work fixed).  `value` = points of all ranks / wall time of the K timed steps (max over ranks).
 
-Extra objects on the JSON line: `roofline` for the dominant kernel (k_msm_accumulate, duration from HIP events on the
-library's own stream, denominators from SURVEY.md 8d: 128 B per point) and `cpu_baseline` (oracle/kzg_cpu.c, a C port
-timed on this box's host cores on a bounded sample of the same inputs; also used here as a parity check).
+`--workload msm26` is BASELINE.json configs[3]: ONE 2^26-point MSM whose SRS is split into N contiguous segments,
+one per rank (N = 1: all 2^26 points and 103 GB of window tables on one GPU); strong scaling, same collective.
+`--workload kzg22` is configs[2] / [4]: one degree-2^22 commit+open per GPU (N > 1: Pianist rows, no exchange).
+
+Extra objects on the JSON line:
+  roofline         dominant kernel (k_msm_accumulate): duration from HIP events on the library's own stream inside the
+                   timed region, denominators from SURVEY.md 8d (128 B per point)
+  mad_issue        what actually bounds that kernel: v_mad_u64_u32 wave-instructions per second against the chip's
+                   measured mad rate (profiles/ubench_valu_rates.txt) -- see DESIGN.md 3.3
+  kzg_commit_open  N = 1 default run only: commit+open latency of device-resident rows of 2^22 (configs[2]), 2^16
+                   (mainnet row) and 2^12 (testnet row) coefficients, each with p10/p90, stage times, a roofline entry at
+                   384 B per coefficient and its own CPU baseline
+  cpu_baseline     oracle/kzg_cpu.c (a C port; the real prover is an absent Rust binary) timed on this box's host
+                   cores on a bounded sample of the same inputs: 1 thread, 16 threads (the box's share per GPU) and all
+                   visible cores; also a parity check of the GPU result
 """
 import argparse
 import json
@@ -26,7 +38,14 @@ sys.path.insert(0, ROOT)
 R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy peak
 HBM_COPY_GBS = 6290.0
-VALU_PEAK_GINST_S = 256 * 4 * 2.4 / 4   # wave64 VALU instructions per ns, chip-wide: one per 4 cycles per SIMD at 2.4 GHz
+# v_mad_u64_u32 (the only wide integer multiply): 5.0 cycles per wave-instruction per SIMD measured with 1, 2 and 4
+# waves per SIMD (scripts/ubench/valu_rates.hip -> profiles/ubench_valu_rates.txt) => 1024 SIMDs x clock / 5.
+# For scale: the guide's full-rate figure for simple VALU (wave64 v_fma_f32 in 2 cycles on a SIMD-32 once >= 2 waves
+# share the SIMD) is 1024 x 2.4 GHz / 2 = 1228.8 G wave-instructions/s; integer multiplies do not issue at that rate.
+MAD_CYCLES = 5.0
+SIMDS = 1024
+CLOCK_GHZ_HELD = 2.15          # GRBM_GUI_ACTIVE / 8 / kernel time under this load (profiles/*_pmc.csv)
+VALU_FULL_RATE_GINST_S = SIMDS * 2.4 / 2
 TAU = 0x2F6C7A1D3B5E9F80412D6A7C93E1B5F7086A4D2C1E9B3F5A7D6C8E0F1A2B3C4D % R_MOD
 
 
@@ -91,26 +110,116 @@ def host_cores():
         return os.cpu_count() or 1
 
 
+def thread_counts(user):
+    """CPU-baseline thread counts: 1, the box's share for one GPU (16) and every visible core."""
+    if user:
+        return sorted({1, user})
+    return sorted({1, min(16, host_cores()), host_cores()})
+
+
+def pctl(xs, q):
+    s = sorted(xs)
+    return s[min(len(s) - 1, int(q * len(s)))]
+
+
+def kzg_rows_report(HipEngine, lagrange_factor, device, logs, cpu_threads, with_cpu):
+    """commit+open latency of device-resident evaluation-form rows (N = 1): BASELINE.json configs[2] (2^22) and the row
+    lengths the reference actually runs (mainnet 2^16, testnet 2^12: reference Makefile:63-116).  One engine per row
+    length (the window tables are built for the slice length).  Never part of `value`."""
+    rows = {}
+    for lg in logs:
+        T = 1 << lg
+        eng = HipEngine(device)
+        t0 = time.time()
+        eng.gen_srs(TAU, (TAU * 7 + 1) % R_MOD, lg, 0)
+        setup_s = time.time() - t0
+        row = uniform_fr(T, seed=0)
+        alpha = uniform_fr(1, seed=1)
+        eng.upload_fr(0, row, True)
+        warm, steps = (2, 8) if lg >= 20 else (5, 40)
+        for _ in range(warm):
+            ref = eng.commit_open_resident(0, 0, T, alpha, True)
+        lat = []
+        for _ in range(steps):
+            t1 = time.perf_counter()
+            got = eng.commit_open_resident(0, 0, T, alpha, True)
+            lat.append((time.perf_counter() - t1) * 1e3)
+            assert got == ref, "non-deterministic commit+open"
+        eng.set_profiling(True)          # stage times: serialised on one lane so that they stay attributable
+        stages = {}
+        nprof = 3
+        for _ in range(nprof):
+            assert eng.commit_open_resident(0, 0, T, alpha, True) == ref
+            for k, v in eng.timings().items():
+                stages[k] = stages.get(k, 0.0) + v / nprof
+        eng.set_profiling(False)
+        med = pctl(lat, 0.5)
+        alg = 384.0 * T                  # 64 INTT + 128 MSM + 64 quotient + 128 MSM bytes per coefficient (SURVEY 8d)
+        ach = alg / (med * 1e-3) / 1e9
+        rec = {"log2_T": lg, "window_bits": eng.window, "ms": round(med, 4), "p10": round(pctl(lat, 0.1), 4),
+               "p90": round(pctl(lat, 0.9), 4), "steps": steps, "coefficients_per_s": T / (med * 1e-3),
+               "stages_ms_profiled_serial": {k: round(v, 4) for k, v in stages.items()},
+               "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes": alg, "per": "whole commit+open call"},
+               "result_hex": b"".join(ref).hex(), "setup_s": round(setup_s, 2)}
+        if with_cpu:
+            from oracle import cpu as oc
+
+            oc.build()
+            m = min(T, 1 << 17)          # bounded CPU sample: a row of 2^17 coefficients at most
+            srs = eng.srs_read(0, m)
+            sample = row[: 32 * m]
+            per = {}
+            cpu_res = None
+            for th in cpu_threads:
+                if th == 1 and m > (1 << 14):
+                    continue             # one thread on a long row would take minutes
+                tc = time.perf_counter()
+                c = oc.commit(srs, sample, True, threads=th)
+                ev, pf = oc.open_(srs, sample, alpha, True, threads=th)
+                per[th] = time.perf_counter() - tc
+                cpu_res = (c, ev, pf)
+            best = min(per, key=per.get)
+            gpu_same = ref if m == T else eng.commit_open(0, sample, alpha, True)   # a shorter row on the same points
+            rec["cpu_baseline"] = {
+                "value": m / per[best], "unit": "coefficients/s", "cores": best, "kind": "port",
+                "sample": f"commit+open of the first 2^{m.bit_length() - 1} coefficients of the same row "
+                          f"(oracle/kzg_cpu.c); seconds by thread count: "
+                          + ", ".join(f"{th}: {s:.3f}" for th, s in sorted(per.items())),
+                "ms_scaled_to_full_row": per[best] * (T / m) * 1e3,
+                "matches_gpu_bit_exact": cpu_res == tuple(gpu_same)}
+            assert cpu_res == tuple(gpu_same), "GPU commit+open differs from the CPU oracle on the baseline sample"
+        rows[f"2^{lg}"] = rec
+        eng.close()
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="msm20", choices=["msm20", "kzg22"])
-    ap.add_argument("--log-n", type=int, default=0, help="override log2(points per GPU) (debug)")
+    ap.add_argument("--workload", default="msm20", choices=["msm20", "msm26", "kzg22"])
+    ap.add_argument("--log-n", type=int, default=0,
+                    help="override log2(points per GPU) (msm20, kzg22) or log2(total points) (msm26)")
     ap.add_argument("--window", type=int, default=0)
-    ap.add_argument("--cpu-sample-log", type=int, default=19)
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 16): the box's CPU share for one GPU")
+    ap.add_argument("--cpu-sample-log", type=int, default=20)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = 1, 16 and all visible cores")
     ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
-                    help="msm20: MSM requests in flight per GPU in the timed region (1 = one request at a time, the "
-                         "default; 2 = the library's two lanes)")
-    ap.add_argument("--pipelined", action="store_true",
-                    help="msm20: after the timed region, time the same K steps again with two requests in flight and "
-                         "report them as `pipelined` (off by default so that every k_msm_accumulate launch of the "
-                         "default run is an uncontended one and rocprofv3's average matches `roofline.kernel_ms`)")
+                    help="MSM requests in flight per GPU in the timed region (1 = one request at a time, the default; "
+                         "2 = two of the library's lanes)")
+    ap.add_argument("--no-pipelined", action="store_true",
+                    help="skip the second timing of the same K steps with two requests in flight (`pipelined`)")
+    ap.add_argument("--no-kzg-rows", action="store_true", help="skip the commit+open latency rows (`kzg_commit_open`)")
+    ap.add_argument("--kzg-rows", default="22,16,12", help="log2 row lengths of `kzg_commit_open`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adversarial", action="store_true", help="skip the separately reported adversarial inputs")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="timed region only (profiling runs: every k_msm_accumulate launch is then an uncontended launch "
+                         "of the headline size, so rocprofv3's average matches `roofline.kernel_ms`)")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_pipelined = args.no_kzg_rows = args.no_cpu_baseline = args.no_adversarial = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -134,51 +243,69 @@ def main():
 
     from zkp_subnet_amd import HipEngine
     from zkp_subnet_amd.distributed import all_gather_partials
+    from zkp_subnet_amd.engine import lagrange_factor
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
+    is_msm = args.workload in ("msm20", "msm26")
     eng = HipEngine(local_rank, window=args.window)
     t_setup = time.time()
     if args.workload == "msm20":
         lg = args.log_n or 20
         n = 1 << lg
+        n_total = n * world
         # this rank's SRS segment: points [rank*n, (rank+1)*n) of the 2^lg * world point SRS [tau^j] G
         eng.gen_srs(TAU, 1, lg, 0, factors=[pow(TAU, rank * n, R_MOD)])
         scal = uniform_fr(n, seed=rank)                       # seed 0 on rank 0
         eng.upload_fr(0, scal, False)
         alpha = None
+        scaling = "weak"
+    elif args.workload == "msm26":
+        lg_total = args.log_n or 26
+        if world & (world - 1) or (1 << lg_total) % world:
+            raise SystemExit("msm26 needs a power-of-two number of ranks")
+        n_total = 1 << lg_total
+        n = n_total // world
+        lg = n.bit_length() - 1
+        # contiguous SRS segment [rank*n, (rank+1)*n) of the 2^26-point SRS; scalars of the same index range
+        eng.gen_srs(TAU, 1, lg, 0, factors=[pow(TAU, rank * n, R_MOD)])
+        scal = uniform_fr(n, seed=1000 + rank)
+        eng.upload_fr(0, scal, False)
+        alpha = None
+        scaling = "strong"
     else:
         lg = args.log_n or 22
         n = 1 << lg
+        n_total = n * world
         # Pianist segments: worker row `rank`, one per GPU, no exchange (BASELINE.json configs[2] / [4])
-        from zkp_subnet_amd.engine import lagrange_factor
         ms = max(0, (world - 1).bit_length())
         eng.gen_srs(TAU, 0, lg + ms, ms, factors=[lagrange_factor(rank, ms, (TAU * 7 + 1) % R_MOD)])
         scal = uniform_fr(n, seed=rank)
         eng.upload_fr(0, scal, True)
         alpha = uniform_fr(1, seed=1)
+        scaling = "weak"
     setup_s = time.time() - t_setup
     plan = eng.msm_plan(n)
 
     results = []
     stage_sum = {}
     step_ms = []
-    depth = args.in_flight if args.workload == "msm20" else 1
+    depth = args.in_flight if is_msm else 1
     state = {"depth": depth}
 
     # N > 1, one request at a time: partial -> RCCL all_gather -> sum entirely through device buffers
     gather = None
-    if use_dist and args.workload == "msm20" and depth == 1:
+    if use_dist and is_msm and depth == 1:
         from zkp_subnet_amd.distributed import DeviceGather
 
         gather = DeviceGather(eng)
     state["gather"] = gather
 
     def submit():
-        if args.workload == "msm20" and state["gather"] is None:
+        if is_msm and state["gather"] is None:
             return eng.msm_submit(0, n, 0, partial=use_dist)
         return None
 
@@ -188,7 +315,7 @@ def main():
             if collect:
                 for k, v in eng.timings().items():
                     stage_sum[k] = stage_sum.get(k, 0.0) + v
-        elif args.workload == "msm20":
+        elif is_msm:
             r = eng.msm_wait(ticket)
             if collect:
                 for k, v in eng.timings().items():
@@ -222,10 +349,10 @@ def main():
     run_steps(args.warmup, False)
     results.clear()
     step_ms.clear()
-    # msm20 and short rows (one batched pass): stage spans (HIP events on the library's stream) are recorded inside the
-    # timed region.  Rows above 2^18: the library runs the two MSMs of a commit+open on two streams unless profiling is
+    # MSM workloads and short rows (one batched pass): stage spans (HIP events on the library's stream) are recorded inside
+    # the timed region.  Rows above 2^18: the library runs the two MSMs of a commit+open on two lanes unless profiling is
     # on, so the timed region runs unprofiled and the stage times come from extra profiled (serialised) steps afterwards.
-    profile_in_timed = args.workload == "msm20" or n <= (1 << 18)
+    profile_in_timed = (is_msm and depth == 1) or (not is_msm and n <= (1 << 18))
     eng.set_profiling(profile_in_timed)
     barrier()
     t0 = time.perf_counter()
@@ -235,14 +362,16 @@ def main():
     n_prof = args.steps
     timed_step_ms = list(step_ms)
     if not profile_in_timed:
+        state["depth"] = 1
         eng.set_profiling(True)
         n_prof = min(args.steps, 5)
         run_steps(n_prof, True)
+        state["depth"] = depth
     eng.set_profiling(False)
-    # the same K steps with two requests in flight on the library's two lanes (MSM i+1's sort/accumulate overlaps the
+    # the same K steps with two requests in flight on two of the library's lanes (MSM i+1's sort/accumulate overlaps the
     # latency-bound tail of MSM i): reported beside the headline, never mixed into it
     pipelined = None
-    if args.workload == "msm20" and depth == 1 and args.pipelined:
+    if is_msm and depth == 1 and not args.no_pipelined:
         state["depth"], state["gather"] = 2, None
         run_steps(args.warmup, False)
         barrier()
@@ -255,13 +384,13 @@ def main():
             t = torch.tensor([pipe_s], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             pipe_s = float(t.item())
-        pipelined = {"requests_in_flight": 2, "value": n * world * args.steps / pipe_s, "unit": "points/s",
+        pipelined = {"requests_in_flight": 2, "value": n_total * args.steps / pipe_s, "unit": "points/s",
                      "ms_per_step": pipe_s / args.steps * 1e3}
     # single-request latency (one request at a time, result on the host before the next starts)
     lat = []
     for _ in range(min(args.steps, 10)):
         tl = time.perf_counter()
-        if args.workload == "msm20":
+        if is_msm:
             if not use_dist:
                 results.append(eng.msm_resident(0, n, 0))
             elif gather is not None:
@@ -280,16 +409,20 @@ def main():
 
     if rank == 0:
         stages = {k: v / n_prof for k, v in stage_sum.items()}
-        sm = sorted(timed_step_ms)
-        pct = lambda q: sm[min(len(sm) - 1, int(q * len(sm)))]
-        units = n * world * args.steps
         acc_ms = stages.get("accumulate", 0.0)
-        if args.workload == "msm20":
+        if is_msm:
+            units = n_total * args.steps
             alg_bytes = 128.0 * n                 # 96 B affine point + 32 B scalar, each read once
             launches = 1
             metric, unit, value = "BLS12-381 G1 MSM points/sec at 2^20", "points/s", units / elapsed
-            wl = f"2^{lg}-point BLS12-381 G1 Pippenger MSM per GPU (uniform scalars in [0,r), cached SRS)"
+            if args.workload == "msm20":
+                wl = f"2^{lg}-point BLS12-381 G1 Pippenger MSM per GPU (uniform scalars in [0,r), cached SRS)"
+            else:
+                metric = "BLS12-381 G1 MSM points/sec at 2^26 (SRS-sharded)"
+                wl = (f"2^{n_total.bit_length() - 1}-point BLS12-381 G1 Pippenger MSM, SRS split into {world} contiguous "
+                      f"segment(s) of 2^{lg} points, one per GPU (uniform scalars in [0,r), cached SRS)")
         else:
+            units = n_total * args.steps
             batched = n <= (1 << 18)              # short rows: ONE accumulate launch carries both MSMs
             alg_bytes = (2 if batched else 1) * 128.0 * n   # per k_msm_accumulate launch (commit: n, open: n-1 scalars)
             launches = 1 if batched else 2
@@ -298,28 +431,29 @@ def main():
         copy_gbs = measured_copy_peak_gbs(torch) if world == 1 else None
         per_launch_s = acc_ms / 1e3 / launches if acc_ms else float("nan")
         achieved = alg_bytes / per_launch_s / 1e9 if acc_ms else None
-        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the value is
-        # the one measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 FETCH correction)
-        # on this exact configuration and committed under profiles/; null for any other configuration.
-        traffic = None
-        valu_insts = None
+        # HBM traffic and instruction counts of the dominant kernel: PMC counters cannot be read from inside this process,
+        # so the values are the ones measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE / SQ passes, gfx950
+        # x2 FETCH correction) on this exact configuration and committed under profiles/; null for any other configuration.
+        traffic = valu_insts = mads = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pmc = json.load(f)
-            if (pmc["workload"], pmc["points_per_gpu"], pmc["window_bits"]) == (args.workload, n, eng.window):
+            if (pmc["workload"], pmc["points_per_gpu"], pmc["window_bits"]) == ("msm20" if is_msm else args.workload, n, eng.window):
                 traffic = pmc["traffic_bytes_per_launch"]
                 valu_insts = pmc.get("sq_insts_valu_per_launch")
+                mads = pmc.get("wave_mads_per_launch")
         except (OSError, KeyError, ValueError):
             pass
+        mad_peak = SIMDS * CLOCK_GHZ_HELD / MAD_CYCLES
         out = {
             "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "scaling": scaling, "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": wl, "points_per_gpu": n, "window_bits": eng.window, "windows": plan["windows"],
                        "buckets": plan["buckets"], "entries_per_lane": plan["chunk"], "lanes": plan["lanes"],
                        "requests_in_flight": depth,
                        "parallelism": "single GPU" if world == 1 else
-                       (f"SRS-sharded x{world}, all_gather of 192 B partials over RCCL" if args.workload == "msm20"
+                       (f"SRS-sharded x{world}, all_gather of 192 B partials over RCCL" if is_msm
                         else f"Pianist segments x{world}, no exchange")},
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
@@ -327,21 +461,24 @@ def main():
                          "measured_copy_peak_gbs": round(copy_gbs, 1) if copy_gbs else None,
                          "frac_of_measured_copy_peak": (achieved / (copy_gbs or HBM_COPY_GBS)) if achieved else None,
                          "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc, 2 x FETCH_SIZE + WRITE_SIZE)" if traffic else None,
-                         "note": "integer-VALU-bound (14 x 28-bit-limb Montgomery products on v_mad_u64_u32: ~3.7k mads "
-                                 "per mixed point addition), not HBM-bound; see DESIGN.md 3.3"},
-            # what actually bounds the kernel: VALU wave-instructions issued per second against one
-            # wave64 instruction per 4 cycles per SIMD (256 CUs x 4 SIMDs x 2.4 GHz / 4); SQ_INSTS_VALU from the same
-            # rocprofv3 --pmc passes as `traffic`
-            "valu_issue": ({"wave_insts_per_launch": valu_insts,
-                            "achieved_ginst_s": valu_insts / per_launch_s / 1e9,
-                            "peak_ginst_s": VALU_PEAK_GINST_S,
-                            "frac": valu_insts / per_launch_s / 1e9 / VALU_PEAK_GINST_S}
-                           if valu_insts and acc_ms else None),
+                         "note": "integer-multiply-bound (14 x 28-bit-limb Montgomery products on v_mad_u64_u32), not "
+                                 "HBM-bound: see mad_issue and DESIGN.md 3.3"},
+            # what actually bounds the kernel: v_mad_u64_u32 wave-instructions per second against the
+            # measured rate of that instruction (5.0 cycles per wave-instruction per SIMD, 1024 SIMDs, clock held under
+            # this load); counts from the code object / SQ_INSTS_VALU passes under profiles/
+            "mad_issue": ({"wave_mads_per_launch": mads, "wave_valu_insts_per_launch": valu_insts,
+                           "achieved_gmad_s": mads / per_launch_s / 1e9, "peak_gmad_s": mad_peak,
+                           "frac": mads / per_launch_s / 1e9 / mad_peak,
+                           "peak_basis": f"{SIMDS} SIMDs x {CLOCK_GHZ_HELD} GHz held / {MAD_CYCLES} cycles per v_mad_u64_u32 "
+                                         "(profiles/ubench_valu_rates.txt)",
+                           "simd32_full_rate_ginst_s": VALU_FULL_RATE_GINST_S}
+                          if mads and acc_ms else None),
             "result_hex": results[0].hex() if isinstance(results[0], (bytes, bytearray)) else b"".join(results[0]).hex(),
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "single_request_latency_ms": round(latency_ms, 4),
             "pipelined": pipelined,
-            "step_ms": {"median": round(pct(0.5), 4), "p10": round(pct(0.1), 4), "p90": round(pct(0.9), 4)},
+            "step_ms": {"median": round(pctl(timed_step_ms, 0.5), 4), "p10": round(pctl(timed_step_ms, 0.1), 4),
+                        "p90": round(pctl(timed_step_ms, 0.9), 4)},
             "setup_s": round(setup_s, 2),
         }
         if args.workload == "kzg22":
@@ -367,32 +504,48 @@ def main():
                     eng.msm_resident(1, n, 0)
                 adv[name] = {"ms_per_msm": round((time.perf_counter() - ta) / 5 * 1e3, 4)}
             out["adversarial"] = adv
-        # ---- CPU baseline: the oracle's C port on a bounded sample of the same inputs, all host cores
-        if world == 1 and not args.no_cpu_baseline and args.workload == "msm20":
+        # ---- CPU baseline: the oracle's C port on a bounded sample of the same inputs
+        threads = thread_counts(args.cpu_threads)
+        if world == 1 and not args.no_cpu_baseline and is_msm:
             from oracle import cpu as oc
 
             oc.build()
             m = 1 << min(args.cpu_sample_log, lg)
-            cores = args.cpu_threads or min(host_cores(), 16)
             srs = eng.srs_read(0, m)
-            prep = oc.PreparedMsm(srs, scal[: 32 * m])
-            tc = time.perf_counter()
-            cpu_res = prep.run(cores)
-            cpu_s = time.perf_counter() - tc
-            tc1 = time.perf_counter()
-            prep1 = oc.PreparedMsm(srs[: 96 * (m >> 3)], scal[: 32 * (m >> 3)])
-            prep1.run(1)
-            cpu1_s = time.perf_counter() - tc1
+            per = {}
+            cpu_res = None
+            for th in threads:
+                mm = m if th > 1 else min(m, 1 << 16)          # one thread: 2^16 points (~1 s)
+                prep = oc.PreparedMsm(srs[: 96 * mm], scal[: 32 * mm])
+                tc = time.perf_counter()
+                r = prep.run(th)
+                per[th] = (mm, time.perf_counter() - tc)
+                prep.close()
+                if mm == m:
+                    cpu_res = r
+            if cpu_res is None:
+                cpu_res = oc.msm(srs, scal[: 32 * m], threads=max(threads))
             gpu_same = eng.msm(scal[: 32 * m], 0)
+            rates = {th: mm / s for th, (mm, s) in per.items()}
+            best = max(rates, key=rates.get)
             out["cpu_baseline"] = {
-                "value": m / cpu_s, "unit": "points/s", "cores": cores, "kind": "port",
+                "value": rates[best], "unit": "points/s", "cores": best, "kind": "port",
                 "sample": f"first 2^{m.bit_length() - 1} points/scalars of the same workload, one Pippenger MSM split over "
-                          f"{cores} threads ({cpu_s:.2f} s wall, {host_cores()} host cores visible, {cpu_model()}); 1 thread on "
-                          f"2^{(m >> 3).bit_length() - 1}: {(m >> 3) / cpu1_s:.0f} points/s",
-                "single_thread_points_per_s": (m >> 3) / cpu1_s,
+                          f"the threads ({host_cores()} host cores visible, {cpu_model()}); points/s by thread count: "
+                          + ", ".join(f"{th}: {r:.0f} (2^{per[th][0].bit_length() - 1} pts, {per[th][1]:.2f} s)"
+                                      for th, r in sorted(rates.items())),
+                "points_per_s_by_threads": {str(th): r for th, r in sorted(rates.items())},
+                "single_thread_points_per_s": rates.get(1),
                 "matches_gpu_bit_exact": cpu_res == gpu_same,
             }
             assert cpu_res == gpu_same, "GPU MSM differs from the CPU oracle on the baseline sample"
+        eng.close()
+        eng = None
+        # ---- KZG commit+open latency: the other half of BASELINE.json's metric (configs[2] + the production row sizes)
+        if world == 1 and args.workload == "msm20" and not args.no_kzg_rows:
+            logs = [int(x) for x in args.kzg_rows.split(",") if x]
+            out["kzg_commit_open"] = kzg_rows_report(HipEngine, lagrange_factor, local_rank, logs, threads,
+                                                     not args.no_cpu_baseline)
         # RCCL writes its version banner through C stdio, which is flushed at exit: push it out now so that the JSON
         # line is the LAST line of stdout
         try:
@@ -401,7 +554,8 @@ def main():
         except OSError:
             pass
         print(json.dumps(out), flush=True)
-    eng.close()
+    if eng is not None:
+        eng.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

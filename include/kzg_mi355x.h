@@ -13,8 +13,12 @@
  *           compressed encoding for results.  Partial sums cross the ABI as 192 opaque bytes (XYZZ).
  *   - return 0 on success, negative kzg_status otherwise; kzg_last_error(ctx) gives the message.
  *     No exception or abort crosses the boundary.
- *   - one ctx = one GPU; calls on one ctx are serialised by an internal mutex (re-entrant per ctx,
- *     ctypes releases the GIL during a call).
+ *   - one ctx = one GPU, and it is thread-safe: the reference's axon runs Miner.forward on worker threads
+ *     (neurons/miner.py:106-135), so concurrent calls on one ctx each take one of four internal lanes (own HIP stream
+ *     + workspace) and run concurrently on the GPU -- one request's sort and latency-bound tail hide under another's
+ *     accumulate.  A fifth concurrent call waits for a lane.  (Re)loading the SRS and writing a resident slot are
+ *     exclusive: they wait until the lanes are idle.  kzg_last_error reports the calling THREAD's last failure
+ *     (ctypes releases the GIL during a call).
  *   - there is NO CPU fallback: every compute entry point fails with KZG_E_HIP when no gfx950 device works.
  */
 #ifndef KZG_MI355X_H
@@ -39,7 +43,7 @@ typedef enum {
 /* ---- lifecycle: replaces Client(port, bin, ...) + Client.start()/stop()  (reference base/miner.py:73-84,155,181) */
 int kzg_create(int device_id, kzg_ctx** out);
 void kzg_destroy(kzg_ctx* ctx);
-const char* kzg_last_error(kzg_ctx* ctx);
+const char* kzg_last_error(kzg_ctx* ctx); /* last failure of the calling thread; valid until its next failing call */
 const char* kzg_version(void);
 /* window bits c for the signed-digit Pippenger tables; 0 = choose from the slice length.  Call before the SRS. */
 int kzg_set_window(kzg_ctx* ctx, int c);
@@ -110,6 +114,10 @@ int kzg_vk_pairing(const uint8_t p_be96[96], const uint8_t q_be192[192], uint8_t
 int kzg_msm_partial(kzg_ctx* ctx, const uint8_t* scalars_be32, uint64_t n, uint64_t srs_offset,
                     uint8_t out_xyzz192[192]);
 int kzg_g1_sum(kzg_ctx* ctx, const uint8_t* partials_xyzz192, uint32_t count, uint8_t out48[48]);
+/* Pianist master aggregation: sum of `count` 48-byte compressed G1 points (the worker rows' commitments,
+ * sum_i commit_i = commitment of the bivariate polynomial; reference neurons/validator.py:196-198, README.md:38).
+ * Inputs are decompressed on the GPU (one Fp square root each); malformed / off-curve input -> KZG_E_POINT. */
+int kzg_g1_sum_compressed(kzg_ctx* ctx, const uint8_t* points_c48, uint32_t count, uint8_t out48[48]);
 /* Device-pointer forms for the collective path: the partial is written into / the gathered partials are read from the
  * CALLER's device memory (the tensors of an RCCL all_gather), so a step makes no host round trip for them.
  * kzg_msm_partial_resident_dev returns after its stream has drained (dev_out is complete); the caller must have
@@ -122,12 +130,12 @@ int kzg_g1_sum_dev(kzg_ctx* ctx, const void* dev_partials_xyzz192, uint32_t coun
 int kzg_upload_fr(kzg_ctx* ctx, int slot, const uint8_t* be32, uint64_t n, int to_mont);
 int kzg_msm_resident(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint8_t out48[48]);
 int kzg_msm_partial_resident(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint8_t out_xyzz192[192]);
-/* Ticketed form of the two calls above, for a serving loop with several requests in flight (the reference miner's
- * axon hands forward() to worker threads, neurons/miner.py:106-135): submit queues the MSM on one of two internal
- * lanes (own stream + workspace) and returns; wait blocks for that ticket and writes 48 (partial=0) or 192 bytes.
- * MSM i+1's sort/accumulate then overlaps the latency-bound tail of MSM i.  Results are identical to the blocking
- * calls.  With both lanes taken submit fails with KZG_E_BUSY; while any ticket is outstanding only kzg_msm_submit,
- * kzg_msm_wait and kzg_g1_sum[_dev] are accepted on the context (everything else returns KZG_E_BUSY). */
+/* Ticketed form of the two calls above: several requests in flight from ONE host thread.  submit queues the MSM on a
+ * free lane and returns; wait blocks for that ticket and writes 48 (partial=0) or 192 bytes (exactly one waiter per
+ * ticket).  MSM i+1's sort/accumulate then overlaps the latency-bound tail of MSM i.  Results are identical to the
+ * blocking calls.  With every lane taken submit fails with KZG_E_BUSY; a blocking call made while tickets are
+ * outstanding uses a free lane, or fails with KZG_E_BUSY when every lane is parked under a ticket; operations that
+ * need the whole context (SRS load, kzg_upload_fr, kzg_ntt_resident) fail with KZG_E_BUSY while any ticket is out. */
 int kzg_msm_submit(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, int partial, int* out_ticket);
 int kzg_msm_wait(kzg_ctx* ctx, int ticket, uint8_t* out);
 int kzg_commit_open_resident(kzg_ctx* ctx, uint32_t i, int slot, uint64_t T, int evaluation_form,
@@ -135,11 +143,23 @@ int kzg_commit_open_resident(kzg_ctx* ctx, uint32_t i, int slot, uint64_t T, int
                              uint8_t out_proof48[48]);
 int kzg_ntt_resident(kzg_ctx* ctx, int slot, uint64_t n, int inverse); /* in place on the slot */
 
-/* ---- pinned host staging.  Returns a page-locked buffer of at least `bytes` bytes owned by the ctx (valid until the
- *      next call asking for more, or kzg_destroy).  A host that decodes the synapse's base64 text itself
+/* ---- pinned host staging.  acquire hands out one of four page-locked buffers of at least `bytes` bytes (it waits
+ *      when all are held); release returns it.  A host that decodes the synapse's base64 text itself
  *      (zkp_subnet_amd/csrc/wire_py.c) writes the 32-byte scalars straight into it and passes the pointer as
- *      row_be32 / scalars_be32: the upload then runs at PCIe speed with no pageable bounce and no page faults. */
-int kzg_staging_buffer(kzg_ctx* ctx, uint64_t bytes, void** out_ptr);
+ *      row_be32 / scalars_be32: the upload then runs at PCIe speed with no pageable bounce and no page faults, and
+ *      concurrent requests each decode into their own buffer. */
+int kzg_staging_acquire(kzg_ctx* ctx, uint64_t bytes, void** out_ptr, int* out_token);
+int kzg_staging_release(kzg_ctx* ctx, int token);
+
+/* ---- where the result point is encoded.  1 (default): the XYZZ working form of the ONE point a request produces
+ *      comes back in the request's single device-to-host copy and the host does the affine conversion (one Fp
+ *      inversion) + ZCash compression -- a few microseconds instead of a ~140 us single-lane GPU kernel.
+ *      0: encode on the GPU (k_g1_compress).  Results are identical; the *_dev entry points always stay on the GPU. */
+int kzg_set_host_finish(kzg_ctx* ctx, int enable);
+/* the host encoder itself (no GPU): 4 x 14 limbs of 28 bits (X, Y, ZZ, ZZZ; lazy limbs < 2^32; residues with
+ * R = 2^392) -> 48-byte compressed point / 192-byte partial record.  Test hooks. */
+int kzg_host_xyzz_to_c48(const uint32_t xyzz_limbs28[56], uint8_t out48[48]);
+int kzg_host_xyzz_to_partial192(const uint32_t xyzz_limbs28[56], uint8_t out192[192]);
 
 /* ---- per-stage HIP-event timings of the last hot-path call (events recorded on the ctx's own stream) */
 enum {

@@ -67,6 +67,10 @@ class OracleEngine:
     def g1_sum(self, partials):
         return oc.g1_sum(b"".join(partials[i:i + 96] for i in range(0, len(partials), 192)))
 
+    def g1_sum_compressed(self, points_c48):
+        pts = [o.g1_decompress(points_c48[k:k + 48]) for k in range(0, len(points_c48), 48)]
+        return oc.g1_sum(b"".join(o.g1_to_be96(p) for p in pts))
+
     def ntt(self, vals, inverse):
         return oc.fr_ntt(vals, inverse)
 

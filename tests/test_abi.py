@@ -113,3 +113,51 @@ def test_wire_extension_matches_python_base64():
             codec.fr_list_to_be32(bad)
     with pytest.raises(ValueError):
         codec._wire.encode_fr_list(b"\x00" * 33)
+
+
+def _limbs28(v, slack_rng=None):
+    """14 limbs of 28 bits of v (< 2^392); with slack_rng: a lazy, non-normalised representation of the same value."""
+    l = [(v >> (28 * i)) & 0xFFFFFFF for i in range(14)]
+    l[13] = v >> (28 * 13)
+    if slack_rng is not None:        # move one unit of limb i+1 down into limb i (limb i gains 2^28): still < 2^32
+        for i in range(13):
+            if l[i + 1] > 0 and slack_rng.random() < 0.5:
+                l[i + 1] -= 1
+                l[i] += 1 << 28
+    assert sum(x << (28 * i) for i, x in enumerate(l)) == v and all(0 <= x < (1 << 32) for x in l)
+    return l
+
+
+def test_host_encoder_matches_oracle(lib):
+    """finish_host.cpp (the encoder that turns the GPU's XYZZ working form into wire bytes) against the Python oracle:
+    random points in random projective representatives with lazy limbs, both y signs, infinity."""
+    import random
+
+    from oracle import bls12_381 as o
+
+    rnd = random.Random(31)
+    R392 = pow(2, 392, o.P)
+    for case in range(40):
+        pt = o.g1_mul(o.G1, rnd.randrange(1, o.R))
+        if case & 1:
+            pt = o.g1_neg(pt)
+        z = rnd.randrange(1, o.P)
+        zz, zzz = z * z % o.P, z * z * z % o.P
+        vals = [pt[0] * zz % o.P, pt[1] * zzz % o.P, zz, zzz]
+        limbs = []
+        for k, v in enumerate(vals):
+            m = v * R392 % o.P + rnd.randrange(0, 14 if k == 0 else 2) * o.P      # loose: X < 14p, others < 2p
+            limbs += _limbs28(m, rnd if case % 3 else None)
+        arr = (ctypes.c_uint32 * 56)(*limbs)
+        out = ctypes.create_string_buffer(48)
+        assert lib.kzg_host_xyzz_to_c48(arr, out) == 0
+        assert out.raw == o.g1_compress(pt), case
+        part = ctypes.create_string_buffer(192)
+        assert lib.kzg_host_xyzz_to_partial192(arr, part) == 0
+        for k, v in enumerate(vals):
+            assert int.from_bytes(part.raw[48 * k:48 * k + 48], "little") == v * R392 % o.P
+    inf = (ctypes.c_uint32 * 56)(*([5] * 28 + [0] * 28))
+    out = ctypes.create_string_buffer(48)
+    assert lib.kzg_host_xyzz_to_c48(inf, out) == 0 and out.raw == b"\xc0" + bytes(47)
+    part = ctypes.create_string_buffer(192)
+    assert lib.kzg_host_xyzz_to_partial192(inf, part) == 0 and part.raw == bytes(192)

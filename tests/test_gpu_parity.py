@@ -259,26 +259,37 @@ def test_msm_tickets_pipeline_matches_blocking_calls(hip):
     want_half = eng.msm(data[0][:32 * half], 0)
     ta = eng.msm_submit(0, half, 0, partial=True)
     tb = eng.msm_submit(0, half, 0, partial=True)          # same range twice: 2 * MSM(first half)
+    # a blocking call made while tickets are outstanding runs on a free lane
+    assert eng.msm_resident(1, n, 0) == want[1]
+    tc, td = eng.msm_submit(1, n, 0), eng.msm_submit(2, n, 0)       # all four lanes now parked under tickets
     with pytest.raises(KzgError) as ei:
         eng.msm_submit(1, n, 0)
     assert ei.value.code == KZG_E_BUSY
     with pytest.raises(KzgError) as ei:
-        eng.msm_resident(1, n, 0)
+        eng.msm_resident(1, n, 0)                           # would wait forever on a single thread: refused instead
+    assert ei.value.code == KZG_E_BUSY
+    with pytest.raises(KzgError) as ei:
+        eng.upload_fr(3, data[0], False)                    # whole-context operations need every lane idle
     assert ei.value.code == KZG_E_BUSY
     pa = eng.msm_wait(ta)
     assert eng.g1_sum(pa) == want_half                                                  # tb still outstanding
+    with pytest.raises(KzgError) as ei:
+        eng.upload_fr(3, data[0], False)
+    assert ei.value.code == KZG_E_BUSY
     pb = eng.msm_wait(tb)
     assert eng.g1_sum(pb) == want_half          # (the 192-byte partial is a projective form: only its sum is canonical)
     assert eng.g1_sum(pa + pb) == eng.g1_sum(eng.msm_partial(data[0][:32 * half], 0) * 2)
     with pytest.raises(KzgError):
         eng.msm_wait(tb)                                                                # already collected
-    assert eng.msm_resident(1, n, 0) == want[1]                                        # idle again
+    assert (eng.msm_wait(td), eng.msm_wait(tc)) == (want[2], want[1])                  # any order
+    eng.upload_fr(3, data[0], False)                                                   # idle again
+    assert eng.msm_resident(3, n, 0) == want[0]
     eng.close()
 
 
 def test_msm_2_24_large_size_trapdoor(hip):
-    """2^24 points on one GPU (12 window tables = 19 GB resident; the same kernels were checked up to 2^26 = 77 GB
-    with tests/bringup_big.py): bit-exact against [f(tau)]G."""
+    """2^24 points on one GPU (12 window tables = 26 GB resident; 2^26: test_cfg4_msm_2_26_in_eight_srs_segments):
+    bit-exact against [f(tau)]G."""
     lg, n = 24, 1 << 24
     eng = hip()
     tx = 0x24242424242424242424
@@ -403,6 +414,166 @@ def test_kzg_2_22_commit_open_bit_exact(hip):
     assert eng.commit_open(0, row, alpha_b, True) == (c, ev, pf)        # host-buffer entry point agrees
 
 
+def test_cfg4_msm_2_26_in_eight_srs_segments(hip):
+    """BASELINE.json configs[3] on ONE GPU: a 2^26-point MSM (103 GB of window tables resident) as eight contiguous
+    SRS segments of 2^23 points, one partial each, summed -- what eight ranks do with one all_gather between the partials
+    and the sum -- equals the single 2^26 MSM equals [f(tau)]G from the oracle (no MSM on the CPU side)."""
+    lg, n = 26, 1 << 26
+    eng = hip()
+    tx = 0x26262626262626262626262626
+    eng.gen_srs(tx, 1, lg, 0)
+    assert eng.window == 22
+    seg = n // 8
+    y = 0
+    txs = tx.to_bytes(32, "big")
+    partials = []
+    tau_seg = pow(tx, seg, o.R)
+    for g in range(8):
+        s_b = rand_scalars_bytes(seg, 2600 + g)
+        eng.upload_fr(0, s_b, False)
+        partials.append(eng.msm_partial_resident(0, seg, g * seg))
+        # f(tau) = sum_g tau^(g * seg) * f_g(tau)
+        y = (y + pow(tau_seg, g, o.R) * int.from_bytes(oc.fr_eval(s_b, txs), "big")) % o.R
+        if g == 7:
+            eng.upload_fr(1, s_b, False)        # keep the last segment for the range check below
+        del s_b
+    want = oc.g1_mul_gen(y.to_bytes(32, "big"))
+    assert eng.g1_sum(b"".join(partials)) == want
+    # the same segment through the blocking compressed form == its own trapdoor value
+    assert eng.msm_resident(1, seg, 7 * seg) == eng.g1_sum(partials[7])
+    # one 2^26 MSM over all the scalars at once (2 GB of scalars in one slot)
+    whole = b"".join(rand_scalars_bytes(seg, 2600 + g) for g in range(8))
+    eng.upload_fr(2, whole, False)
+    del whole
+    assert eng.msm_resident(2, n, 0) == want
+    eng.close()
+
+
+def test_cfg5_eight_pianist_rows_2_22_on_one_engine(hip):
+    """BASELINE.json configs[4] on ONE GPU: eight Pianist worker rows i = 0..7 of 2^22 coefficients, each a full
+    commit+open on its own SRS slice U_i = [tau_x^j L_i(tau_y)]G (one row per GPU on an 8-GPU node; no exchange), each
+    bit-exact against the trapdoor identities; the eight commitments then aggregate to the bivariate commitment."""
+    lg, ms = 22, 3
+    T = 1 << lg
+    eng = hip()
+    tx, ty = 0x5E6D5E6D5E6D5E6D, 0xA11CEA11CE
+    eng.gen_srs(tx, ty, lg + ms, ms)                       # 2^25 points, 13 windows: 55 GB resident
+    alpha_b = rand_scalars_bytes(1, 501)
+    alpha = int.from_bytes(alpha_b, "big")
+    commits, total = [], 0
+    for i in range(1 << ms):
+        row = rand_scalars_bytes(T, 510 + i)
+        eng.upload_fr(0, row, True)
+        c, ev, pf = eng.commit_open_resident(i, 0, T, alpha_b, True)
+        coeffs_b = oc.fr_ntt(row, True)
+        y = oc.fr_eval(coeffs_b, alpha_b)
+        ft = int.from_bytes(oc.fr_eval(coeffs_b, tx.to_bytes(32, "big")), "big")
+        li = o.lagrange_at(i, 1 << ms, ty)
+        assert ev == y
+        assert c == oc.g1_mul_gen((li * ft % o.R).to_bytes(32, "big")), i
+        qt = (ft - int.from_bytes(y, "big")) * o.fr_inv(tx - alpha) % o.R
+        assert pf == oc.g1_mul_gen((li * qt % o.R).to_bytes(32, "big")), i
+        commits.append(c)
+        total = (total + li * ft) % o.R
+    assert eng.g1_sum_compressed(b"".join(commits)) == oc.g1_mul_gen(total.to_bytes(32, "big"))
+    eng.close()
+
+
+def test_two_processes_sharded_msm_on_one_gpu(hip):
+    """Two REAL processes (fresh interpreters, torch.distributed gloo group), each with its own HipEngine on this GPU
+    holding its own SRS segment, run zkp_subnet_amd.distributed.sharded_msm: the result of every rank equals the
+    single-process MSM over the whole SRS and the trapdoor value."""
+    import subprocess
+    import sys
+
+    lg = 17
+    n = 1 << lg
+    tx = 0xD157D157D157
+    procs = []
+    port = 29500 + (os.getpid() % 400)
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_hip_worker.py"), str(lg), hex(tx)],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT))
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=900)
+        assert p.returncode == 0, se[-3000:]
+        outs.append(so.strip().splitlines()[-1])
+    assert outs[0] == outs[1]
+    eng = hip()
+    eng.gen_srs(tx, 1, lg + 1, 0)
+    whole = rand_scalars_bytes(n, 7000) + rand_scalars_bytes(n, 7001)
+    assert eng.msm(whole, 0).hex() == outs[0]
+    assert outs[0] == oc.g1_mul_gen(oc.fr_eval(whole, tx.to_bytes(32, "big"))).hex()
+    eng.close()
+
+
+def test_host_and_gpu_result_encoding_agree(hip):
+    """The result point's affine conversion + compression runs on the host by default (finish_host.cpp); the GPU encoder
+    (k_g1_compress[_pair], k_xyzz_pack) must give the same bytes on every entry point."""
+    lg = 12
+    T = 1 << lg
+    eng = hip()
+    eng.gen_srs(0xE2C0DE, 0x77, lg + 1, 1)
+    row, alpha = rand_scalars_bytes(T, 61), rand_scalars_bytes(1, 62)
+    eng.upload_fr(0, row, False)
+    eng.upload_fr(1, row, True)
+    got = {}
+    for mode in (True, False):
+        eng.set_host_finish(mode)
+        t1 = eng.msm_submit(0, T, T)
+        t2 = eng.msm_submit(0, T // 2, 0, partial=True)
+        got[mode] = (eng.commit_open(1, row, alpha, True), eng.commit(0, row, True), eng.open(1, row, alpha, False),
+                     eng.msm(row, 0), eng.msm_resident(0, T, T), eng.g1_sum(eng.msm_partial(row, 0)),
+                     eng.commit_open_resident(1, 1, T, alpha, True), eng.msm_wait(t1), eng.g1_sum(eng.msm_wait(t2)),
+                     eng.msm(bytes(32) * 8, 0), eng.g1_sum_compressed(eng.commit(0, row, True) * 3))
+    assert got[True] == got[False]
+    srs = oc.srs_gen((0xE2C0DE).to_bytes(32, "big"), (0x77).to_bytes(32, "big"), lg + 1, 1, 1)
+    assert got[True][0][0] == oc.commit(srs, row, True)
+    assert got[True][9] == b"\xc0" + bytes(47)
+    eng.close()
+
+
+def test_aggregate_commitments_and_api_commit_on_hip_engine(hip):
+    """SURVEY 8a7 + 8f-4 on the HIP engine: `commit()` (reference api/commit.py:75-100) over CommitOnlyAxon(Miner) returns
+    the oracle's commitment of the row, and Client.aggregate_commitments over ALL worker rows returns the commitment
+    [f(tau_x, tau_y)]G of the bivariate polynomial (GPU decompression + sum; reference README.md:38)."""
+    from zkp_subnet_amd import codec
+    from zkp_subnet_amd.api import CommitOnlyAxon, commit
+    from zkp_subnet_amd.client import Client, derive_taus
+    from zkp_subnet_amd.miner import Miner, default_config
+
+    scale, ms, seed = 9, 2, 77
+    T, m = 1 << (scale - ms), 1 << ms
+    miner = Miner(default_config(scale=scale, machines_scale=ms, seed=seed, setup_path=""))
+    tx, ty = derive_taus(seed)
+    rnd = random.Random(5)
+    rows = [[rnd.randrange(o.R) for _ in range(T)] for _ in range(m)]
+    axons = [CommitOnlyAxon(miner)] * 3
+    comms, acc = [], 0
+    for i in range(m):
+        poly = [o.fr_to_b64(v) for v in rows[i]]
+        got = commit(poly, axons, index=i, rng=random.Random(i))
+        srs = oc.srs_gen(tx.to_bytes(32, "big"), ty.to_bytes(32, "big"), scale, ms, i)
+        assert base64.b64decode(got) == oc.commit(srs, o.fr_to_be32(rows[i]), True)
+        comms.append(got)
+        acc = (acc + o.lagrange_at(i, m, ty) * o.poly_eval(o.ntt(rows[i], inverse=True), tx)) % o.R
+    with miner.client.aggregate_commitments(comms) as r:
+        assert r.status_code == 200
+        assert base64.b64decode(r.json()["commitment"]) == oc.g1_mul_gen(acc.to_bytes(32, "big"))
+    # -P + P = infinity; malformed / off-curve inputs are refused, not summed
+    neg = bytearray(base64.b64decode(comms[0]))
+    neg[0] ^= 0x20
+    with miner.client.aggregate_commitments([comms[0], base64.b64encode(bytes(neg)).decode()]) as r:
+        assert base64.b64decode(r.json()["commitment"]) == b"\xc0" + bytes(47)
+    bad_x = bytes([0x9F]) + b"\xff" * 47                  # x >= p
+    assert miner.client.aggregate_commitments([base64.b64encode(bad_x).decode()]).status_code == 400
+    assert commit([o.fr_to_b64(1)] * T, [], index=0) == ""
+    assert commit(["@@"], axons, index=0) == ""            # the miner's commit handler failed: request echoed, no string
+    miner.stop()
+
+
 def test_client_and_miner_on_hip_engine(hip, fr_kat):
     """The reference miner test (tests/test_miner.py:62-121) on the HIP engine: 16-coefficient TEST_POLY at
     scale 6 / machines_scale 2; forward() returns the client's commitment and proof; oracle agrees bit for bit."""
@@ -456,9 +627,9 @@ def test_client_and_miner_on_hip_engine(hip, fr_kat):
 
 
 def test_concurrent_host_threads_and_contexts(hip):
-    """The axon calls forward() from worker threads (SURVEY 8b threading): four threads hammer ONE context (serialised by
-    its mutex, staging buffer guarded by the engine lock) while a fifth drives a second context on the same GPU; every
-    answer equals the oracle's."""
+    """The axon calls forward() from worker threads (SURVEY 8b threading): four threads hammer ONE context (each call on
+    its own lane and pinned staging buffer, running concurrently on the GPU) while a fifth drives a second context on the
+    same GPU; every answer equals the oracle's."""
     import threading
 
     from zkp_subnet_amd import codec
@@ -589,7 +760,7 @@ def test_bench_contract_line(hip):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--log-n", "14", "--steps", "3", "--warmup", "1",
-                          "--cpu-sample-log", "12"], capture_output=True, text=True, timeout=600, cwd=root)
+                          "--cpu-sample-log", "12", "--kzg-rows", "10,8"], capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     rec = json.loads(lines[-1])
@@ -603,10 +774,16 @@ def test_bench_contract_line(hip):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["matches_gpu_bit_exact"] is True
+    assert "1" in cb["points_per_s_by_threads"] and len(cb["points_per_s_by_threads"]) >= 2      # 1 thread AND more
+    assert rec["pipelined"]["value"] > 0
+    for key in ("2^10", "2^8"):                     # commit+open latency rows, each with roofline + cpu_baseline
+        row = rec["kzg_commit_open"][key]
+        assert row["ms"] > 0 and row["p10"] <= row["ms"] <= row["p90"] and row["roofline"]["algorithmic_bytes"] == 384.0 * (1 << row["log2_T"])
+        assert row["cpu_baseline"]["matches_gpu_bit_exact"] is True and len(row["result_hex"]) == 2 * (48 + 32 + 48)
     # the collective path (1-rank RCCL group: partial -> all_gather -> sum through device buffers) gives the same point
     env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
     out2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--log-n", "14", "--steps", "3", "--warmup", "1",
-                           "--no-cpu-baseline", "--no-adversarial", "--pipelined"], capture_output=True, text=True,
+                           "--no-cpu-baseline", "--no-adversarial", "--no-kzg-rows"], capture_output=True, text=True,
                           timeout=600, cwd=root, env=env)
     assert out2.returncode == 0, out2.stderr[-2000:]
     rec2 = json.loads([ln for ln in out2.stdout.splitlines() if ln.strip()][-1])

@@ -205,3 +205,30 @@ def test_challenge_synapse_carries_eval():
     ch = Challenge(polys=[["a"], ["b"]], alpha="x", evals=["e0", "e1"])
     s = ch.to_synapse(1)
     assert (s.index, s.poly, s.alpha, s.eval) == (1, ["b"], "x", "e1")
+
+
+def test_aggregate_commitments_is_the_bivariate_commitment():
+    """SURVEY 8f-4 / reference README.md:38: sum_i commit_i over ALL worker rows equals [f(tau_x, tau_y)] G for the
+    bivariate polynomial whose row i (evaluation form in X) is worker i's polynomial, f = sum_i L_i(Y) f_i(X)."""
+    scale, ms, seed = 5, 2, 13
+    c = make_client(scale, ms, seed=seed)
+    T, m = 1 << (scale - ms), 1 << ms
+    rnd = random.Random(8)
+    rows = [[rnd.randrange(o.R) for _ in range(T)] for _ in range(m)]
+    comms = []
+    for i in range(m):
+        with c.worker_commit(i, [o.fr_to_b64(v) for v in rows[i]]) as r:
+            assert r.status_code == 200
+            comms.append(r.json()["commitment"])
+    with c.aggregate_commitments(comms) as r:
+        assert r.status_code == 200
+        total = r.json()["commitment"]
+    from zkp_subnet_amd.client import derive_taus
+    tx, ty = derive_taus(seed)
+    acc = 0
+    for i in range(m):
+        acc = (acc + o.lagrange_at(i, m, ty) * o.poly_eval(o.ntt(rows[i], inverse=True), tx)) % o.R
+    assert base64.b64decode(total) == o.g1_compress(o.g1_mul(o.G1, acc))
+    assert c.aggregate_commitments(["AAAA"]).status_code == 400
+    with c.aggregate_commitments([]) as r:
+        assert base64.b64decode(r.json()["commitment"]) == b"\xc0" + bytes(47)

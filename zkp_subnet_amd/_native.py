@@ -53,7 +53,12 @@ SYMBOLS = {
     "kzg_msm_wait": (_I, [_P, _I, _B]),
     "kzg_commit_open_resident": (_I, [_P, _U32, _I, _U64, _I, _B, _B, _B, _B]),
     "kzg_ntt_resident": (_I, [_P, _I, _U64, _I]),
-    "kzg_staging_buffer": (_I, [_P, _U64, ctypes.POINTER(_P)]),
+    "kzg_staging_acquire": (_I, [_P, _U64, ctypes.POINTER(_P), ctypes.POINTER(_I)]),
+    "kzg_staging_release": (_I, [_P, _I]),
+    "kzg_set_host_finish": (_I, [_P, _I]),
+    "kzg_host_xyzz_to_c48": (_I, [_P, _B]),
+    "kzg_host_xyzz_to_partial192": (_I, [_P, _B]),
+    "kzg_g1_sum_compressed": (_I, [_P, _B, _U32, _B]),
     "kzg_set_profiling": (_I, [_P, _I]),
     "kzg_get_timings": (_I, [_P, ctypes.POINTER(ctypes.c_float), _I]),
     "kzg_msm_plan": (_I, [_P, _U64, ctypes.POINTER(ctypes.c_int32)]),

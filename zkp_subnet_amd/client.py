@@ -166,6 +166,14 @@ class Client:
             self.engine.commit_open(self._slice(i), codec.fr_list_to_be32(poly), codec.fr_to_be32(x), True)
         return {"commitment": codec.g1_to_b64(c), "eval": codec.be32_to_fr(ev), "proof": codec.g1_to_b64(pf)}
 
+    @_guard
+    def aggregate_commitments(self, commitments: Sequence[str]):
+        """Pianist master aggregation: sum_i commit_i of the worker rows' commitments = the commitment of the whole
+        bivariate polynomial (reference neurons/validator.py:196-198 distributes the rows; README.md:38 names the
+        aggregation as the next milestone).  Points are decompressed and summed on the GPU."""
+        raw = b"".join(codec.g1_from_b64(c) for c in commitments)
+        return {"commitment": codec.g1_to_b64(self.engine.g1_sum_compressed(raw))}
+
     # ------------------------------------------------------------------ validator side (neurons/validator.py:58-104)
     @_guard
     def worker_verify(self, i: int, proof: str, alpha: str, eval: str, commitment: str):

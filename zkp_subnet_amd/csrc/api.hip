@@ -4,37 +4,60 @@
 // No CPU arithmetic fallback exists here: if HIP fails, the call fails.
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/kzg_mi355x.h"
 #include "fr_kernels.hip.h"
 #include "msm.hip.h"
 
-#define KZG_VERSION "kzg_mi355x 0.1 (gfx950)"
+#define KZG_VERSION "kzg_mi355x 0.2 (gfx950)"
 #define N_SLOTS 4
+#define N_LANES 4
+#define N_STAGE 4
+
+namespace kzg_host {  // finish_host.cpp
+void xyzz_to_c48(const uint32_t* xyzz, uint8_t out48[48]);
+void xyzz_to_partial192(const uint32_t* xyzz, uint8_t out192[192]);
+}  // namespace kzg_host
 
 namespace {
 
+// device allocation that frees itself: an early error return can no longer leak it (move-only)
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) {
+            release();
+            p = o.p; cap = o.cap;
+            o.p = nullptr; o.cap = 0;
+        }
+        return *this;
+    }
+    ~DevBuf() { release(); }
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
+        release();
         size_t want = bytes + (bytes >> 3) + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
+            (void)hipGetLastError();
             e = hipMalloc(&p, bytes);
             want = bytes;
         }
         if (e == hipSuccess) cap = want;
+        else p = nullptr;
         return e;
     }
     void release() {
@@ -51,60 +74,81 @@ struct StageSpan {
     hipEvent_t a, b;
 };
 
-// One MSM in flight: its own stream and sort / bucket workspace.  Lane 0 runs on the context's main stream; lane 1
-// takes the opening MSM of a long row's commit+open and every second ticket of kzg_msm_submit, so that one MSM's sort
-// and latency-bound tail (carry fold, bucket tree, final combination) hide under the other's accumulate.
-struct MsmLane {
+// A lane = everything ONE request needs: its own HIP stream, MSM workspace (sort / bucket / carry buffers), request
+// buffers (uploaded row, coefficients, quotient, scan scratch) and a 1-KB "tail" record whose first half comes back to
+// the host in a single copy.  A call owns its lane from acquire to release, so host threads calling into one ctx (the
+// reference's axon runs Miner.forward on worker threads, neurons/miner.py:106-135) run concurrently on different lanes:
+// one request's sort and latency-bound tail hide under another's accumulate.  The SRS tables are shared, read-only.
+enum { LANE_FREE = 0, LANE_CALL, LANE_TICKET, LANE_WAITING };
+// tail record (device, 1024 B).  [0, TB_COPY) is copied to the lane's pinned buffer when a request finishes.
+enum {
+    TB_RES0 = 0, TB_RES1 = 224,   // result points, XYZZ working form (2 x 224 B)
+    TB_EVAL = 448,                // y = f(alpha), 32 B big-endian
+    TB_FLAGS = 480,               // u32 x 4: [0] bad scalar, [1] bad point, [2] longest carry run, [3] spare
+    TB_C48 = 512, TB_P48 = 576,   // GPU-side encodings (host_finish off)
+    TB_PART = 640,                // 192-byte partial (GPU-side packing)
+    TB_COPY = 832,
+    TB_ALPHA_M = 832, TB_Y_M = 864, TB_ALPHA_BE = 896, TB_SIZE = 1024
+};
+#define PIN_MAXLEN 1024           // offset of the fold-depth read-back inside the lane's pinned page
+struct Lane {
+    int index = 0;
     hipStream_t stream = nullptr;
-    DevBuf rank, sorted, hist, offsets, bufA, bufB, bufC, carries, carry_key;
-    DevBuf res, small;           // result point + its encoded form, for the ticketed (asynchronous) MSM
-    hipEvent_t ev_sorted = nullptr, ev_done = nullptr;
-    bool busy = false;           // a ticket is outstanding on this lane
-    bool partial = false;
+    DevBuf rank, sorted, hist, offsets, bufA, bufB, bufC, carries, carry_key;      // MSM workspace
+    DevBuf in_be, scal, coeffA, coeffB, qbuf, hbuf, hnext, out_be;                 // request buffers
+    uint8_t* tail = nullptr;      // device, TB_SIZE
+    uint8_t* pin = nullptr;       // host pinned, 4096
+    hipEvent_t ev_sorted = nullptr, ev_done = nullptr, ev_coeffs = nullptr;
+    int state = LANE_FREE;
+    bool partial = false;         // outstanding ticket wants the 192-byte partial
     // profiling spans of the call running on this lane
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     std::vector<StageSpan> spans;
+    g1_xyzz_t* res() const { return reinterpret_cast<g1_xyzz_t*>(tail + TB_RES0); }
+    uint32_t* flags() const { return reinterpret_cast<uint32_t*>(tail + TB_FLAGS); }
 };
-#define N_LANES 2
+struct Stage {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool used = false;
+};
 
 }  // namespace
 
 struct kzg_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
-    std::mutex mu;
-    std::string err;
+    std::mutex mu;                 // guards lane states, the staging pool, the twiddle caches, config and timings
+    std::condition_variable cv;    // a lane or a staging buffer was released
     int c_user = 0, c = 0, nwin = 0;
     WinLayout lay;
     uint32_t nbuckets = 0;
-    // resident SRS + window tables: table[w*stride + j] = 2^(c*w) P_j
+    // resident SRS + window tables: table[w*stride + j] = 2^off[w] P_j   (read-only while any lane is busy)
     DevBuf table;
     uint64_t stride = 0, T = 0;
     int scale = 0, mscale = 0;
-    // workspace
-    DevBuf in_be, scal, res, coeffA, coeffB, qbuf, hbuf, hnext, small, out_be;
-    MsmLane lane[N_LANES];
-    hipEvent_t ev_coeffs = nullptr;
+    Lane lane[N_LANES];
     DevBuf slot[N_SLOTS];
     uint64_t slot_n[N_SLOTS] = {0, 0, 0, 0};
     int slot_mont[N_SLOTS] = {0, 0, 0, 0};
     std::map<int, DevBuf> tw_fwd, tw_inv, inv_n;
-    uint32_t* flags = nullptr;   // device: [0] bad scalar, [1] bad point
-    uint8_t* host_pin = nullptr; // pinned staging for small results
-    void* stage_host = nullptr;  // pinned staging for a caller-decoded polynomial (kzg_staging_buffer)
-    size_t stage_cap = 0;
-    int next_lane = 0;
-    hipStream_t aux = nullptr;   // kzg_g1_sum: independent of the MSM lanes
+    Stage stage[N_STAGE];
+    // kzg_g1_sum*: own stream and buffers, independent of the lanes
+    std::mutex aux_mu;
+    hipStream_t aux = nullptr;
     DevBuf aux_in, aux_pts, aux_out;
+    uint8_t* aux_pin = nullptr;
     bool profiling = false;
+    bool host_finish = true;
     float tms[KZG_T_COUNT] = {0};  // stage times of the last completed hot-path call
 };
 
 namespace {
 
-int fail(kzg_ctx* ctx, int code, const std::string& msg) {
-    if (ctx) ctx->err = msg;
+// the message of the last failing call ON THIS THREAD (calls run concurrently: a per-ctx string would be torn)
+thread_local std::string tl_err;
+int fail(kzg_ctx*, int code, const std::string& msg) {
+    tl_err = msg;
     return code;
 }
 #define HIPCHK(ctx, expr)                                                                                   \
@@ -115,7 +159,104 @@ int fail(kzg_ctx* ctx, int code, const std::string& msg) {
                         std::string(#expr) + ": " + hipGetErrorString(_e));                                 \
     } while (0)
 
-hipEvent_t prof_event(MsmLane& L) {
+// ---- lane ownership
+// blocking call: take the lowest free lane (keeps a single-threaded caller on lane 0 and its warm workspace); wait while
+// lanes are merely busy with other calls; fail with KZG_E_BUSY when every lane is parked under an MSM ticket (only
+// kzg_msm_wait can free those: waiting here could deadlock a single-threaded caller).  Profiling pins everything to
+// lane 0 so that stage times stay attributable.
+int lane_acquire(kzg_ctx* ctx, int state, int* out_li) {
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    for (;;) {
+        const int limit = ctx->profiling ? 1 : N_LANES;
+        bool any_call = false;
+        for (int i = 0; i < limit; i++) {
+            if (ctx->lane[i].state == LANE_FREE) {
+                ctx->lane[i].state = state;
+                *out_li = i;
+                return KZG_OK;
+            }
+            any_call |= ctx->lane[i].state == LANE_CALL;
+        }
+        if (!any_call || state == LANE_TICKET)
+            return fail(ctx, KZG_E_BUSY, state == LANE_TICKET ? "every MSM lane is taken: call kzg_msm_wait first"
+                                                               : "every lane holds an outstanding MSM ticket: call kzg_msm_wait first");
+        ctx->cv.wait(lk);
+    }
+}
+int lane_try_second(kzg_ctx* ctx, int first) {  // a second free lane for the two-lane form of a long commit+open, or -1
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->profiling) return -1;
+    for (int i = 0; i < N_LANES; i++) {
+        if (i != first && ctx->lane[i].state == LANE_FREE) {
+            ctx->lane[i].state = LANE_CALL;
+            return i;
+        }
+    }
+    return -1;
+}
+void lane_release(kzg_ctx* ctx, int li) {
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        ctx->lane[li].state = LANE_FREE;
+    }
+    ctx->cv.notify_all();
+}
+// exclusive operations ((re)loading the SRS, uploading a resident slot, reading the SRS back): all lanes, on lane 0
+int lanes_acquire_all(kzg_ctx* ctx) {
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    for (;;) {
+        bool all_free = true, ticket = false;
+        for (const Lane& L : ctx->lane) {
+            all_free &= L.state == LANE_FREE;
+            ticket |= L.state == LANE_TICKET || L.state == LANE_WAITING;
+        }
+        if (ticket) return fail(ctx, KZG_E_BUSY, "an MSM ticket is outstanding: call kzg_msm_wait first");
+        if (all_free) break;
+        ctx->cv.wait(lk);
+    }
+    for (Lane& L : ctx->lane) L.state = LANE_CALL;
+    return KZG_OK;
+}
+void lanes_release_all(kzg_ctx* ctx) {
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        for (Lane& L : ctx->lane) L.state = LANE_FREE;
+    }
+    ctx->cv.notify_all();
+}
+// Owns one lane (optionally a second) for the duration of a call.  Unless the call reached its normal end (`clean`),
+// the streams are drained before the lanes become reusable: a HIP failure midway leaves kernels queued that still read
+// and write the lane's buffers.
+struct LaneHold {
+    kzg_ctx* ctx;
+    int li = -1, li2 = -1;
+    bool all = false, clean = false;
+    explicit LaneHold(kzg_ctx* c) : ctx(c) {}
+    int take() { return lane_acquire(ctx, LANE_CALL, &li); }
+    int take_all() {
+        int rc = lanes_acquire_all(ctx);
+        if (rc == KZG_OK) { all = true; li = 0; }
+        return rc;
+    }
+    Lane& L() { return ctx->lane[li]; }
+    Lane* second() {
+        if (li2 < 0) li2 = lane_try_second(ctx, li);
+        return li2 >= 0 ? &ctx->lane[li2] : nullptr;
+    }
+    ~LaneHold() {
+        if (li < 0) return;
+        if (!clean) {
+            (void)hipStreamSynchronize(ctx->lane[li].stream);
+            if (li2 >= 0) (void)hipStreamSynchronize(ctx->lane[li2].stream);
+            (void)hipGetLastError();
+        }
+        if (all) { lanes_release_all(ctx); return; }
+        if (li2 >= 0) lane_release(ctx, li2);
+        lane_release(ctx, li);
+    }
+};
+
+hipEvent_t prof_event(Lane& L) {
     if (L.ev_used == L.ev_pool.size()) {
         hipEvent_t e;
         (void)hipEventCreate(&e);
@@ -124,24 +265,23 @@ hipEvent_t prof_event(MsmLane& L) {
     return L.ev_pool[L.ev_used++];
 }
 struct Span {
-    MsmLane* lane = nullptr;
+    Lane* lane = nullptr;
     int idx = -1;
     hipStream_t stream;
-    Span(kzg_ctx* c, int stage, hipStream_t st = nullptr, int li = 0) : stream(st ? st : c->stream) {
+    Span(kzg_ctx* c, Lane& L, int stage, hipStream_t st = nullptr) : stream(st ? st : L.stream) {
         if (!c->profiling) return;
-        lane = &c->lane[li];
-        StageSpan s{stage, prof_event(*lane), prof_event(*lane)};
+        lane = &L;
+        StageSpan s{stage, prof_event(L), prof_event(L)};
         (void)hipEventRecord(s.a, stream);
-        lane->spans.push_back(s);
-        idx = (int)lane->spans.size() - 1;
+        L.spans.push_back(s);
+        idx = (int)L.spans.size() - 1;
     }
     ~Span() {
         if (idx >= 0) (void)hipEventRecord(lane->spans[idx].b, stream);
     }
 };
-// opens the KZG_T_TOTAL span of the call on lane li; prof_close() ends it just before the last copy-back
-void prof_begin(kzg_ctx* ctx, int li = 0) {
-    MsmLane& L = ctx->lane[li];
+// opens the KZG_T_TOTAL span of the call on lane L; prof_close() ends it just before the last copy-back
+void prof_begin(kzg_ctx* ctx, Lane& L) {
     L.spans.clear();
     L.ev_used = 0;
     if (!ctx->profiling) return;
@@ -149,19 +289,19 @@ void prof_begin(kzg_ctx* ctx, int li = 0) {
     (void)hipEventRecord(s.a, L.stream);
     L.spans.push_back(s);
 }
-void prof_close(kzg_ctx* ctx, int li = 0) {
-    MsmLane& L = ctx->lane[li];
+void prof_close(kzg_ctx* ctx, Lane& L) {
     if (ctx->profiling && !L.spans.empty() && L.spans[0].stage == KZG_T_TOTAL) (void)hipEventRecord(L.spans[0].b, L.stream);
 }
-void prof_end(kzg_ctx* ctx, int li = 0) {  // lane stream already synchronised
-    MsmLane& L = ctx->lane[li];
+void prof_end(kzg_ctx* ctx, Lane& L) {  // lane stream already synchronised
     if (L.spans.empty()) return;
-    for (float& t : ctx->tms) t = 0.f;
+    float t[KZG_T_COUNT] = {0};
     for (auto& s : L.spans) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) ctx->tms[s.stage] += ms;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) t[s.stage] += ms;
     }
     L.spans.clear();
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    memcpy(ctx->tms, t, sizeof(t));
 }
 
 int choose_window(uint64_t T) {
@@ -211,13 +351,13 @@ int ilog2_exact(uint64_t n) {
     return l;
 }
 
-// ---- the MSM pipeline on device-resident scalars -> one XYZZ point at out_xyzz (device), on lane `li`.
+// ---- the MSM pipeline on device-resident scalars -> one XYZZ point at out_xyzz (device), on lane L.
 // With scalars2 != null: TWO MSMs over the same n points in one pass (the commitment and the opening of one row):
 // set b is sorted into bucket set b, the sort / accumulate / fold / tree kernels simply see twice the buckets, the
 // tree stops at two roots and out_xyzz[0..1] receive the two sums.  One kernel sequence, one latency-bound tail.
-int msm_core(kzg_ctx* ctx, int li, const uint32_t* scalars, int mont, uint64_t n, uint64_t srs_offset,
+// The only host wait inside is on the 4-byte fold-depth read-back; the calling thread holds no lock meanwhile.
+int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t n, uint64_t srs_offset,
              g1_xyzz_t* out_xyzz, const uint32_t* scalars2 = nullptr, int mont2 = 0) {
-    MsmLane& L = ctx->lane[li];
     hipStream_t s = L.stream;
     const int nbatch = scalars2 ? 2 : 1;
     if (n == 0) {
@@ -242,10 +382,10 @@ int msm_core(kzg_ctx* ctx, int li, const uint32_t* scalars, int mont, uint64_t n
     HIPCHK(ctx, L.bufC.ensure(B * sizeof(g1_xyzz_t) / 2 + 4096));
     HIPCHK(ctx, L.carries.ensure((size_t)nchunks * sizeof(g1_xyzz_t)));
     HIPCHK(ctx, L.carry_key.ensure((size_t)nchunks * 4));
-    uint32_t* max_len_d = ctx->flags + 2 + li;
-    uint32_t* max_len_h = reinterpret_cast<uint32_t*>(ctx->host_pin + 32) + li;
+    uint32_t* max_len_d = L.flags() + 2;
+    uint32_t* max_len_h = reinterpret_cast<uint32_t*>(L.pin + PIN_MAXLEN);
     {
-        Span sp(ctx, KZG_T_DIGITS, s, li);
+        Span sp(ctx, L, KZG_T_DIGITS);
         HIPCHK(ctx, hipMemsetAsync(L.bufA.p, 0, B * sizeof(g1_xyzz_t), s));
         launch_msm_sort(s, sh, scalars, mont, scalars2, mont2, L.hist.as<uint32_t>(), L.rank.as<uint2>(),
                         L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>());
@@ -257,13 +397,13 @@ int msm_core(kzg_ctx* ctx, int li, const uint32_t* scalars, int mont, uint64_t n
         HIPCHK(ctx, hipEventRecord(L.ev_sorted, s));
     }
     {
-        Span sp(ctx, KZG_T_ACCUMULATE, s, li);
+        Span sp(ctx, L, KZG_T_ACCUMULATE);
         launch_msm_accumulate(s, sh, ctx->table.as<g1_affine_t>(), L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(),
                               L.bufA.as<g1_xyzz_t>(), L.carries.as<g1_xyzz_t>(), L.carry_key.as<uint32_t>(), nchunks);
     }
     HIPCHK(ctx, hipEventSynchronize(L.ev_sorted));
     {
-        Span sp(ctx, KZG_T_FIXUP, s, li);
+        Span sp(ctx, L, KZG_T_FIXUP);
         for (uint32_t d = 1; d < *max_len_h; d <<= 1)
             launch_fold_step(s, L.offsets.as<uint32_t>(), L.carry_key.as<uint32_t>(), (uint32_t)sh.chunk, nchunks, d,
                              L.carries.as<g1_xyzz_t>());
@@ -275,7 +415,7 @@ int msm_core(kzg_ctx* ctx, int li, const uint32_t* scalars, int mont, uint64_t n
     g1_xyzz_t* prev = L.bufC.as<g1_xyzz_t>();
     g1_xyzz_t* out = L.bufB.as<g1_xyzz_t>();
     {
-        Span sp(ctx, KZG_T_TREE, s, li);
+        Span sp(ctx, L, KZG_T_TREE);
         uint32_t n_in = sh.nbuckets;
         for (int level = 0; n_in > (uint32_t)nbatch; level++, n_in >>= 1) {
             launch_msm_tree_level(s, in, prev, out, n_in, level);
@@ -286,60 +426,81 @@ int msm_core(kzg_ctx* ctx, int li, const uint32_t* scalars, int mont, uint64_t n
         }
     }
     {
-        Span sp(ctx, KZG_T_FINAL, s, li);
+        Span sp(ctx, L, KZG_T_FINAL);
         launch_msm_final(s, in, prev, ctx->c - 1, nbatch, out_xyzz);
     }
     HIPCHK(ctx, hipGetLastError());
     return KZG_OK;
 }
 
-// every entry point except kzg_msm_submit / kzg_msm_wait / kzg_g1_sum shares lane 0 and the context buffers
-int need_idle(kzg_ctx* ctx) {
-    for (const MsmLane& L : ctx->lane)
-        if (L.busy) return fail(ctx, KZG_E_BUSY, "an MSM ticket is outstanding: call kzg_msm_wait first");
-    return KZG_OK;
-}
 int need_srs(kzg_ctx* ctx) {
     if (!ctx->table.p || !ctx->stride) return fail(ctx, KZG_E_ARG, "no SRS resident: call kzg_load_srs / kzg_gen_srs");
     return KZG_OK;
 }
-int clear_flags(kzg_ctx* ctx) {
-    HIPCHK(ctx, hipMemsetAsync(ctx->flags, 0, 16, ctx->stream));
+int clear_flags(kzg_ctx* ctx, Lane& L) {
+    HIPCHK(ctx, hipMemsetAsync(L.flags(), 0, 16, L.stream));
     return KZG_OK;
 }
-// results staged in host_pin: [0..16) flags, then payload
-int finish(kzg_ctx* ctx) {
-    prof_close(ctx);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin, ctx->flags, 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    prof_end(ctx);
-    const uint32_t* f = reinterpret_cast<const uint32_t*>(ctx->host_pin);
+// ends a request: the lane's tail record comes back in ONE copy (result points, eval, flags, GPU-side encodings)
+int finish(kzg_ctx* ctx, Lane& L) {
+    prof_close(ctx, L);
+    HIPCHK(ctx, hipMemcpyAsync(L.pin, L.tail, TB_COPY, hipMemcpyDeviceToHost, L.stream));
+    HIPCHK(ctx, hipStreamSynchronize(L.stream));
+    prof_end(ctx, L);
+    const uint32_t* f = reinterpret_cast<const uint32_t*>(L.pin + TB_FLAGS);
     if (f[0]) return fail(ctx, KZG_E_SCALAR, "non-canonical Fr scalar (>= r)");
     if (f[1]) return fail(ctx, KZG_E_POINT, "G1 input not reduced or not on the curve");
     return KZG_OK;
 }
-int ensure_twiddles(kzg_ctx* ctx, int log_n, int inverse, uint32_t** tw, uint32_t** invn) {
+// encodes result point `which` (0 / 1) of a finished request: on the host from the XYZZ working form (default), or
+// the bytes the GPU encoder left in the tail record
+void result_c48(kzg_ctx* ctx, Lane& L, int which, uint8_t out48[48]) {
+    if (ctx->host_finish) kzg_host::xyzz_to_c48(reinterpret_cast<const uint32_t*>(L.pin + (which ? TB_RES1 : TB_RES0)), out48);
+    else memcpy(out48, L.pin + (which ? TB_P48 : TB_C48), 48);
+}
+void result_partial(kzg_ctx* ctx, Lane& L, uint8_t out192[192]) {
+    if (ctx->host_finish) kzg_host::xyzz_to_partial192(reinterpret_cast<const uint32_t*>(L.pin + TB_RES0), out192);
+    else memcpy(out192, L.pin + TB_PART, 192);
+}
+// queue the GPU-side encoders when the host does not finish (no-ops otherwise)
+void queue_encode(kzg_ctx* ctx, Lane& L, bool first, bool second) {
+    if (ctx->host_finish) return;
+    Span sp(ctx, L, KZG_T_FINAL);
+    if (first && second) launch_g1_compress_pair(L.stream, L.res(), L.res() + 1, L.tail + TB_C48, L.tail + TB_P48);
+    else if (first) launch_g1_compress(L.stream, L.res(), L.tail + TB_C48);
+    else if (second) launch_g1_compress(L.stream, L.res() + 1, L.tail + TB_P48);
+}
+void queue_pack(kzg_ctx* ctx, Lane& L) {
+    if (!ctx->host_finish) launch_xyzz_pack(L.stream, L.res(), reinterpret_cast<uint32_t*>(L.tail + TB_PART), 1);
+}
+// twiddle / 1/n tables are shared by all lanes: built once under the ctx mutex, complete before the mutex is dropped
+int ensure_twiddles(kzg_ctx* ctx, Lane& L, int log_n, int inverse, uint32_t** tw, uint32_t** invn) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
     auto& m = inverse ? ctx->tw_inv : ctx->tw_fwd;
+    bool built = false;
     if (log_n >= 1 && !m.count(log_n)) {
         DevBuf b;
         HIPCHK(ctx, b.ensure(((size_t)1 << (log_n - 1)) * 32));
-        launch_fr_twiddles(ctx->stream, b.as<uint32_t>(), log_n, inverse);
-        m[log_n] = b;
+        launch_fr_twiddles(L.stream, b.as<uint32_t>(), log_n, inverse);
+        m[log_n] = std::move(b);
+        built = true;
     }
     *tw = log_n >= 1 ? m[log_n].as<uint32_t>() : nullptr;
     if (invn) {
         if (!ctx->inv_n.count(log_n)) {
             DevBuf b;
             HIPCHK(ctx, b.ensure(32));
-            launch_fr_inv_pow2(ctx->stream, b.as<uint32_t>(), log_n);
-            ctx->inv_n[log_n] = b;
+            launch_fr_inv_pow2(L.stream, b.as<uint32_t>(), log_n);
+            ctx->inv_n[log_n] = std::move(b);
+            built = true;
         }
         *invn = ctx->inv_n[log_n].as<uint32_t>();
     }
+    if (built) HIPCHK(ctx, hipStreamSynchronize(L.stream));
     return KZG_OK;
 }
 // coefficients (Montgomery) of the row; returns pointer in *coeffs.  row_dev: Montgomery-form row.
-int row_to_coeffs(kzg_ctx* ctx, const uint32_t* row_dev, uint64_t T, int evaluation_form, const uint32_t** coeffs) {
+int row_to_coeffs(kzg_ctx* ctx, Lane& L, const uint32_t* row_dev, uint64_t T, int evaluation_form, const uint32_t** coeffs) {
     if (!evaluation_form || T == 1) {
         *coeffs = row_dev;
         return KZG_OK;
@@ -347,12 +508,12 @@ int row_to_coeffs(kzg_ctx* ctx, const uint32_t* row_dev, uint64_t T, int evaluat
     int lg = ilog2_exact(T);
     if (lg < 0) return fail(ctx, KZG_E_ARG, "evaluation-form row length must be a power of two");
     uint32_t *tw, *invn;
-    int rc = ensure_twiddles(ctx, lg, 1, &tw, &invn);
+    int rc = ensure_twiddles(ctx, L, lg, 1, &tw, &invn);
     if (rc) return rc;
-    HIPCHK(ctx, ctx->coeffB.ensure(T * 32));
-    Span sp(ctx, KZG_T_NTT);
-    launch_fr_ntt(ctx->stream, row_dev, ctx->coeffB.as<uint32_t>(), lg, tw, invn);
-    *coeffs = ctx->coeffB.as<uint32_t>();
+    HIPCHK(ctx, L.coeffB.ensure(T * 32));
+    Span sp(ctx, L, KZG_T_NTT);
+    launch_fr_ntt(L.stream, row_dev, L.coeffB.as<uint32_t>(), lg, tw, invn);
+    *coeffs = L.coeffB.as<uint32_t>();
     return KZG_OK;
 }
 int check_worker(kzg_ctx* ctx, uint32_t i, uint64_t T) {
@@ -364,94 +525,100 @@ int check_worker(kzg_ctx* ctx, uint32_t i, uint64_t T) {
     return KZG_OK;
 }
 // upload BE scalars to `dst` (device limbs); dst must hold n*32 bytes
-int upload_fr(kzg_ctx* ctx, const uint8_t* be32, uint64_t n, uint32_t* dst, int to_mont) {
+int upload_fr(kzg_ctx* ctx, Lane& L, const uint8_t* be32, uint64_t n, uint32_t* dst, int to_mont) {
     if (!n) return KZG_OK;
-    HIPCHK(ctx, ctx->in_be.ensure(n * 32));
-    Span sp(ctx, KZG_T_DECODE);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->in_be.p, be32, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    launch_fr_from_be(ctx->stream, ctx->in_be.as<uint8_t>(), dst, n, to_mont, ctx->flags);
+    HIPCHK(ctx, L.in_be.ensure(n * 32));
+    Span sp(ctx, L, KZG_T_DECODE);
+    HIPCHK(ctx, hipMemcpyAsync(L.in_be.p, be32, n * 32, hipMemcpyHostToDevice, L.stream));
+    launch_fr_from_be(L.stream, L.in_be.as<uint8_t>(), dst, n, to_mont, L.flags());
     return KZG_OK;
 }
 
-// commit and/or open on a device-resident Montgomery row.  With both requested:
+// commit and/or open on a device-resident Montgomery row, on the lane(s) the call holds.  With both requested:
 //  * rows up to 2^18 (latency-bound: dozens of small dependent kernels): the commitment MSM(U_i, f) and the opening
 //    MSM(U_i, q) run as ONE batched pass over the slice's window tables (msm_core with two scalar sets) -- one sort,
-//    one accumulate launch, one bucket tree with two roots, one shared inversion: a single tail instead of two;
-//  * longer rows (throughput-bound): the opening (evaluation, quotient, MSM) runs on lane 1 concurrently with the
-//    commitment MSM on lane 0 -- they share only the read-only coefficients -- so that each one's sort and tail hide
-//    under the other's accumulate.  Profiling keeps everything on lane 0 so that stage times stay attributable.
+//    one accumulate launch, one bucket tree with two roots: a single tail instead of two;
+//  * longer rows (throughput-bound): when a second lane is free the opening (evaluation, quotient, MSM) runs there,
+//    concurrently with the commitment MSM -- they share only the read-only coefficients -- so that each one's sort and
+//    tail hide under the other's accumulate; otherwise (another host thread's request holds the other lanes, or
+//    profiling is on) the two MSMs run back to back on this lane and the overlap comes from the other requests.
 #ifndef KZG_BATCHED_ROW_MAX
 #define KZG_BATCHED_ROW_MAX ((uint64_t)1 << 18)
 #endif
-int commit_open_dev(kzg_ctx* ctx, uint32_t i, const uint32_t* row_dev, uint64_t T, int evaluation_form,
+int commit_open_dev(kzg_ctx* ctx, LaneHold& H, uint32_t i, const uint32_t* row_dev, uint64_t T, int evaluation_form,
                     const uint8_t* alpha_be32, uint8_t* out_c48, uint8_t* out_eval32, uint8_t* out_p48) {
-    hipStream_t s = ctx->stream;
+    Lane& A = H.L();
+    hipStream_t s = A.stream;
     const uint32_t* coeffs = nullptr;
-    int rc = row_to_coeffs(ctx, row_dev, T, evaluation_form, &coeffs);
+    int rc = row_to_coeffs(ctx, A, row_dev, T, evaluation_form, &coeffs);
     if (rc) return rc;
-    HIPCHK(ctx, ctx->res.ensure(4 * sizeof(g1_xyzz_t)));
-    HIPCHK(ctx, ctx->small.ensure(1024));
-    uint8_t* small = ctx->small.as<uint8_t>();  // [0,48) commitment [64,112) proof [128,160) eval be [192..) alpha/y limbs
     const uint64_t offset = (uint64_t)i * ctx->T;
-    g1_xyzz_t* res = ctx->res.as<g1_xyzz_t>();
+    g1_xyzz_t* res = A.res();
     const bool both = out_c48 && out_p48;
     const bool batched = both && T <= KZG_BATCHED_ROW_MAX;
-    const int lo = (both && !batched && !ctx->profiling) ? 1 : 0;  // lane of the opening
-    hipStream_t so = ctx->lane[lo].stream;
-    if (lo) {
-        HIPCHK(ctx, hipEventRecord(ctx->ev_coeffs, s));
-        HIPCHK(ctx, hipStreamWaitEvent(so, ctx->ev_coeffs, 0));
+    Lane* B = (both && !batched) ? H.second() : nullptr;   // lane of the opening, when one is free
+    Lane& O = B ? *B : A;
+    hipStream_t so = O.stream;
+    if (B) {
+        HIPCHK(ctx, hipEventRecord(A.ev_coeffs, s));
+        HIPCHK(ctx, hipStreamWaitEvent(so, A.ev_coeffs, 0));
     }
     if (out_c48 && !batched) {
-        rc = msm_core(ctx, 0, coeffs, 1, T, offset, res);
+        rc = msm_core(ctx, A, coeffs, 1, T, offset, res);
         if (rc) return rc;
-        if (!out_p48) {  // commit only; with an opening the two points share one inversion below
-            Span sp(ctx, KZG_T_FINAL);
-            launch_g1_compress(s, res, small);
-        }
     }
     if (out_p48) {
-        uint32_t* alpha_m = reinterpret_cast<uint32_t*>(small + 192);
-        uint32_t* y_m = reinterpret_cast<uint32_t*>(small + 256);
-        HIPCHK(ctx, hipMemcpyAsync(small + 320, alpha_be32, 32, hipMemcpyHostToDevice, so));
-        launch_fr_from_be(so, small + 320, alpha_m, 1, 1, ctx->flags);
+        uint32_t* alpha_m = reinterpret_cast<uint32_t*>(A.tail + TB_ALPHA_M);
+        uint32_t* y_m = reinterpret_cast<uint32_t*>(A.tail + TB_Y_M);
+        HIPCHK(ctx, hipMemcpyAsync(A.tail + TB_ALPHA_BE, alpha_be32, 32, hipMemcpyHostToDevice, so));
+        launch_fr_from_be(so, A.tail + TB_ALPHA_BE, alpha_m, 1, 1, A.flags());
         const uint64_t nchunks = (T + 3) / 4;
-        HIPCHK(ctx, ctx->hbuf.ensure((nchunks + (nchunks >> 3) + 64) * 32));
-        HIPCHK(ctx, ctx->hnext.ensure((nchunks + (nchunks >> 3) + 64) * 32));
-        HIPCHK(ctx, ctx->qbuf.ensure(T * 32));
+        HIPCHK(ctx, O.hbuf.ensure((nchunks + (nchunks >> 3) + 64) * 32));
+        HIPCHK(ctx, O.hnext.ensure((nchunks + (nchunks >> 3) + 64) * 32));
+        HIPCHK(ctx, O.qbuf.ensure(T * 32));
         {
-            Span sp(ctx, KZG_T_POLY, so);
-            launch_poly_open(so, coeffs, T, alpha_m, ctx->hbuf.as<uint32_t>(), ctx->hnext.as<uint32_t>(), y_m,
-                             ctx->qbuf.as<uint32_t>());
-            launch_fr_to_be(so, y_m, small + 128, 1, 1);
+            Span sp(ctx, A, KZG_T_POLY, so);
+            launch_poly_open(so, coeffs, T, alpha_m, O.hbuf.as<uint32_t>(), O.hnext.as<uint32_t>(), y_m,
+                             O.qbuf.as<uint32_t>());
+            launch_fr_to_be(so, y_m, A.tail + TB_EVAL, 1, 1);
         }
         if (batched) {
             // the quotient has T - 1 coefficients; a zero in slot T - 1 lets it ride as a second length-T scalar set
-            HIPCHK(ctx, hipMemsetAsync(ctx->qbuf.as<uint32_t>() + 8 * (T - 1), 0, 32, s));
-            rc = msm_core(ctx, 0, coeffs, 1, T, offset, res, ctx->qbuf.as<uint32_t>(), 0);
+            HIPCHK(ctx, hipMemsetAsync(O.qbuf.as<uint32_t>() + 8 * (T - 1), 0, 32, s));
+            rc = msm_core(ctx, A, coeffs, 1, T, offset, res, O.qbuf.as<uint32_t>(), 0);
         } else {
-            rc = msm_core(ctx, lo, ctx->qbuf.as<uint32_t>(), 0, T - 1, offset, res + 1);
+            rc = msm_core(ctx, O, O.qbuf.as<uint32_t>(), 0, T - 1, offset, res + 1);
         }
         if (rc) return rc;
-        if (lo) {
-            HIPCHK(ctx, hipEventRecord(ctx->lane[lo].ev_done, so));
-            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->lane[lo].ev_done, 0));
+        if (B) {
+            HIPCHK(ctx, hipEventRecord(B->ev_done, so));
+            HIPCHK(ctx, hipStreamWaitEvent(s, B->ev_done, 0));
         }
-        Span sp(ctx, KZG_T_FINAL);
-        if (out_c48) launch_g1_compress_pair(s, res, res + 1, small, small + 64);
-        else launch_g1_compress(s, res + 1, small + 64);
     }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, small, 192, hipMemcpyDeviceToHost, s));
-    rc = finish(ctx);
+    queue_encode(ctx, A, out_c48 != nullptr, out_p48 != nullptr);
+    rc = finish(ctx, A);
     if (rc) return rc;
-    if (out_c48) memcpy(out_c48, ctx->host_pin + 64, 48);
+    if (out_c48) result_c48(ctx, A, 0, out_c48);
     if (out_p48) {
-        memcpy(out_p48, ctx->host_pin + 64 + 64, 48);
-        memcpy(out_eval32, ctx->host_pin + 64 + 128, 32);
+        result_c48(ctx, A, 1, out_p48);
+        memcpy(out_eval32, A.pin + TB_EVAL, 32);
     }
+    H.clean = true;
     return KZG_OK;
 }
 
+// a failed (re)load must not leave a half-built table behind: need_srs() would pass and MSMs would return garbage
+struct TableRollback {
+    kzg_ctx* ctx;
+    bool armed = false;
+    ~TableRollback() {
+        if (!armed) return;
+        (void)hipStreamSynchronize(ctx->lane[0].stream);
+        ctx->table.release();
+        ctx->stride = 0;
+        ctx->T = 0;
+    }
+};
 int alloc_table(kzg_ctx* ctx, uint64_t n_points, int scale, int mscale) {
     if (mscale < 0 || scale < mscale || scale - mscale > 30) return fail(ctx, KZG_E_ARG, "bad scale / machines_scale");
     const uint64_t T = (uint64_t)1 << (scale - mscale);
@@ -460,22 +627,22 @@ int alloc_table(kzg_ctx* ctx, uint64_t n_points, int scale, int mscale) {
     if ((uint64_t)ctx->nwin * n_points >= ((uint64_t)1 << 31))
         return fail(ctx, KZG_E_ARG, "SRS x windows exceeds 2^31 table entries");
     ctx->table.release();
+    ctx->stride = 0;
+    ctx->T = 0;
     HIPCHK(ctx, ctx->table.ensure((size_t)ctx->nwin * n_points * sizeof(g1_affine_t)));
     ctx->stride = n_points; ctx->T = T; ctx->scale = scale; ctx->mscale = mscale;
     return KZG_OK;
 }
 int precompute_tables(kzg_ctx* ctx) {
+    hipStream_t s = ctx->lane[0].stream;
     const uint64_t tile = ctx->stride < ((uint64_t)1 << 20) ? ctx->stride : ((uint64_t)1 << 20);
     DevBuf tmp;
     HIPCHK(ctx, tmp.ensure((size_t)(ctx->nwin - 1) * tile * sizeof(g1_xyzz_t) + 256));
     for (uint64_t first = 0; first < ctx->stride; first += tile) {
         uint64_t cnt = ctx->stride - first < tile ? ctx->stride - first : tile;
-        launch_srs_precompute(ctx->stream, ctx->table.as<g1_affine_t>(), ctx->stride, first, cnt, ctx->lay,
-                              tmp.as<g1_xyzz_t>());
+        launch_srs_precompute(s, ctx->table.as<g1_affine_t>(), ctx->stride, first, cnt, ctx->lay, tmp.as<g1_xyzz_t>());
     }
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    tmp.release();
-    HIPCHK(ctx, e);
+    HIPCHK(ctx, hipStreamSynchronize(s));
     HIPCHK(ctx, hipGetLastError());
     return KZG_OK;
 }
@@ -568,28 +735,30 @@ int kzg_create(int device_id, kzg_ctx** out) {
     if (!out) return KZG_E_ARG;
     *out = nullptr;
     int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count) return KZG_E_HIP;
-    if (hipSetDevice(device_id) != hipSuccess) return KZG_E_HIP;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count)
+        return fail(nullptr, KZG_E_HIP, "no usable HIP device with that index");
+    if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, KZG_E_HIP, "hipSetDevice failed");
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return KZG_E_HIP;
-    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) return KZG_E_HIP;  // built for gfx950 only
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return fail(nullptr, KZG_E_HIP, "hipGetDeviceProperties failed");
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(nullptr, KZG_E_HIP, "this library is built for gfx950 (MI355X) only");
     kzg_ctx* ctx = new kzg_ctx();
     ctx->device = device_id;
-    bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipMalloc((void**)&ctx->flags, 16) == hipSuccess &&
-              hipHostMalloc((void**)&ctx->host_pin, 4096, hipHostMallocDefault) == hipSuccess &&
-              hipEventCreateWithFlags(&ctx->ev_coeffs, hipEventDisableTiming) == hipSuccess &&
-              hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) == hipSuccess &&
+              hipHostMalloc((void**)&ctx->aux_pin, 256, hipHostMallocDefault) == hipSuccess;
     for (int l = 0; ok && l < N_LANES; l++) {
-        MsmLane& L = ctx->lane[l];
-        if (l == 0) L.stream = ctx->stream;
-        else ok = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&L.ev_sorted, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) == hipSuccess;
+        Lane& L = ctx->lane[l];
+        L.index = l;
+        ok = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess &&
+             hipMalloc((void**)&L.tail, TB_SIZE) == hipSuccess && hipMemset(L.tail, 0, TB_SIZE) == hipSuccess &&
+             hipHostMalloc((void**)&L.pin, 4096, hipHostMallocDefault) == hipSuccess &&
+             hipEventCreateWithFlags(&L.ev_sorted, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&L.ev_coeffs, hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) {
         kzg_destroy(ctx);
-        return KZG_E_HIP;
+        return fail(nullptr, KZG_E_HIP, "stream / event / buffer creation failed");
     }
     *out = ctx;
     return KZG_OK;
@@ -597,42 +766,31 @@ int kzg_create(int device_id, kzg_ctx** out) {
 
 void kzg_destroy(kzg_ctx* ctx) {
     if (!ctx) return;
-    {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        (void)hipSetDevice(ctx->device);
-        for (MsmLane& L : ctx->lane)
-            if (L.stream) (void)hipStreamSynchronize(L.stream);
-        DevBuf* bufs[] = {&ctx->table, &ctx->in_be, &ctx->scal, &ctx->res, &ctx->coeffA,
-                          &ctx->coeffB, &ctx->qbuf, &ctx->hbuf, &ctx->hnext, &ctx->small, &ctx->out_be};
-        for (DevBuf* b : bufs) b->release();
-        for (MsmLane& L : ctx->lane) {
-            for (DevBuf* b : {&L.rank, &L.sorted, &L.hist, &L.offsets, &L.bufA, &L.bufB, &L.bufC, &L.carries, &L.carry_key})
-                b->release();
-            L.res.release();
-            L.small.release();
-            for (hipEvent_t e : L.ev_pool) (void)hipEventDestroy(e);
-            if (L.ev_sorted) (void)hipEventDestroy(L.ev_sorted);
-            if (L.ev_done) (void)hipEventDestroy(L.ev_done);
-            if (L.stream && L.stream != ctx->stream) (void)hipStreamDestroy(L.stream);
-        }
-        for (auto& b : ctx->slot) b.release();
-        for (auto* m : {&ctx->tw_fwd, &ctx->tw_inv, &ctx->inv_n})
-            for (auto& kv : *m) kv.second.release();
-        if (ctx->ev_coeffs) (void)hipEventDestroy(ctx->ev_coeffs);
-        for (DevBuf* b : {&ctx->aux_in, &ctx->aux_pts, &ctx->aux_out}) b->release();
-        if (ctx->aux) {
-            (void)hipStreamSynchronize(ctx->aux);
-            (void)hipStreamDestroy(ctx->aux);
-        }
-        if (ctx->flags) (void)hipFree(ctx->flags);
-        if (ctx->host_pin) (void)hipHostFree(ctx->host_pin);
-        if (ctx->stage_host) (void)hipHostFree(ctx->stage_host);
-        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    (void)hipSetDevice(ctx->device);
+    for (Lane& L : ctx->lane) {
+        if (L.stream) (void)hipStreamSynchronize(L.stream);
+        for (DevBuf* b : {&L.rank, &L.sorted, &L.hist, &L.offsets, &L.bufA, &L.bufB, &L.bufC, &L.carries, &L.carry_key,
+                          &L.in_be, &L.scal, &L.coeffA, &L.coeffB, &L.qbuf, &L.hbuf, &L.hnext, &L.out_be})
+            b->release();
+        for (hipEvent_t e : L.ev_pool) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {L.ev_sorted, L.ev_done, L.ev_coeffs})
+            if (e) (void)hipEventDestroy(e);
+        if (L.tail) (void)hipFree(L.tail);
+        if (L.pin) (void)hipHostFree(L.pin);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
     }
-    delete ctx;
+    if (ctx->aux) {
+        (void)hipStreamSynchronize(ctx->aux);
+        (void)hipStreamDestroy(ctx->aux);
+    }
+    if (ctx->aux_pin) (void)hipHostFree(ctx->aux_pin);
+    for (Stage& st : ctx->stage)
+        if (st.p) (void)hipHostFree(st.p);
+    delete ctx;  // the remaining DevBufs (table, slots, twiddles, aux) free themselves
 }
 
-const char* kzg_last_error(kzg_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+// message of the last failing call made by THIS thread (valid until its next failing call)
+const char* kzg_last_error(kzg_ctx*) { return tl_err.c_str(); }
 
 int kzg_set_window(kzg_ctx* ctx, int c) {
     if (!ctx) return KZG_E_ARG;
@@ -649,38 +807,45 @@ int kzg_get_window_layout(kzg_ctx* ctx, int32_t* out_offsets, int max) {
     return ctx->nwin;
 }
 uint64_t kzg_srs_points(kzg_ctx* ctx) { return ctx ? ctx->stride : 0; }
+int kzg_set_host_finish(kzg_ctx* ctx, int enable) {
+    if (!ctx) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->host_finish = enable != 0;
+    return KZG_OK;
+}
 
 static int load_srs_common(kzg_ctx* ctx, const uint8_t* data, uint64_t n_points, int scale, int machines_scale,
                            bool compressed) {
     if (!ctx || !data) return KZG_E_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (int busy = need_idle(ctx)) return busy;
+    LaneHold H(ctx);
+    if (int rc = H.take_all()) return rc;
+    Lane& L = H.L();
+    TableRollback rollback{ctx};
     int rc = alloc_table(ctx, n_points, scale, machines_scale);
     if (rc) return rc;
-    rc = clear_flags(ctx);
+    rollback.armed = true;
+    rc = clear_flags(ctx, L);
     if (rc) return rc;
     const uint64_t tile = (uint64_t)1 << 20;
     const size_t rec = compressed ? 48 : 96;
-    HIPCHK(ctx, ctx->in_be.ensure((n_points < tile ? n_points : tile) * rec));
+    HIPCHK(ctx, L.in_be.ensure((n_points < tile ? n_points : tile) * rec));
     for (uint64_t first = 0; first < n_points; first += tile) {
         uint64_t cnt = n_points - first < tile ? n_points - first : tile;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->in_be.p, data + rec * first, cnt * rec, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(L.in_be.p, data + rec * first, cnt * rec, hipMemcpyHostToDevice, L.stream));
         if (compressed)
-            launch_srs_from_c48(ctx->stream, ctx->in_be.as<uint8_t>(), ctx->table.as<g1_affine_t>() + first, cnt,
-                                ctx->flags + 1);
+            launch_srs_from_c48(L.stream, L.in_be.as<uint8_t>(), ctx->table.as<g1_affine_t>() + first, cnt, L.flags() + 1);
         else
-            launch_srs_from_be96(ctx->stream, ctx->in_be.as<uint8_t>(), ctx->table.as<g1_affine_t>() + first, cnt,
-                                 ctx->flags + 1);
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            launch_srs_from_be96(L.stream, L.in_be.as<uint8_t>(), ctx->table.as<g1_affine_t>() + first, cnt, L.flags() + 1);
+        HIPCHK(ctx, hipStreamSynchronize(L.stream));
     }
-    rc = finish(ctx);
-    if (rc) {
-        ctx->table.release();
-        ctx->stride = 0;
-        return rc;
-    }
-    return precompute_tables(ctx);
+    rc = finish(ctx, L);
+    if (rc) return rc;
+    rc = precompute_tables(ctx);
+    if (rc) return rc;
+    rollback.armed = false;
+    H.clean = true;
+    return KZG_OK;
 }
 int kzg_load_srs(kzg_ctx* ctx, const uint8_t* g1_affine_be96, uint64_t n_points, int scale, int machines_scale) {
     return load_srs_common(ctx, g1_affine_be96, n_points, scale, machines_scale, false);
@@ -692,15 +857,18 @@ int kzg_load_srs_compressed(kzg_ctx* ctx, const uint8_t* g1_c48, uint64_t n_poin
 int kzg_gen_srs(kzg_ctx* ctx, const uint8_t tau_be32[32], const uint8_t* s0_be32, uint32_t n_slices, int scale,
                 int machines_scale) {
     if (!ctx || !tau_be32 || !s0_be32 || !n_slices) return KZG_E_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (int busy = need_idle(ctx)) return busy;
     if (machines_scale < 0 || scale < machines_scale || scale - machines_scale > 30)
         return fail(ctx, KZG_E_ARG, "bad scale / machines_scale");
+    LaneHold H(ctx);
+    if (int rc = H.take_all()) return rc;
+    Lane& L = H.L();
     const uint64_t T = (uint64_t)1 << (scale - machines_scale);
+    TableRollback rollback{ctx};
     int rc = alloc_table(ctx, (uint64_t)n_slices * T, scale, machines_scale);
     if (rc) return rc;
-    rc = clear_flags(ctx);
+    rollback.armed = true;
+    rc = clear_flags(ctx, L);
     if (rc) return rc;
     DevBuf gtab, tmp, sc;
     HIPCHK(ctx, gtab.ensure(32 * 255 * sizeof(g1_affine_t)));
@@ -709,42 +877,46 @@ int kzg_gen_srs(kzg_ctx* ctx, const uint8_t tau_be32[32], const uint8_t* s0_be32
     HIPCHK(ctx, sc.ensure(((size_t)n_slices + 1) * 32 + 64));
     // tau and the per-slice factors, Montgomery form, on device
     uint32_t* tau_m = sc.as<uint32_t>();
-    HIPCHK(ctx, ctx->in_be.ensure(((size_t)n_slices + 1) * 32));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->in_be.p, tau_be32, 32, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->in_be.as<uint8_t>() + 32, s0_be32, (size_t)n_slices * 32, hipMemcpyHostToDevice,
-                               ctx->stream));
-    launch_fr_from_be(ctx->stream, ctx->in_be.as<uint8_t>(), tau_m, (uint64_t)n_slices + 1, 1, ctx->flags);
+    HIPCHK(ctx, L.in_be.ensure(((size_t)n_slices + 1) * 32));
+    HIPCHK(ctx, hipMemcpyAsync(L.in_be.p, tau_be32, 32, hipMemcpyHostToDevice, L.stream));
+    HIPCHK(ctx, hipMemcpyAsync(L.in_be.as<uint8_t>() + 32, s0_be32, (size_t)n_slices * 32, hipMemcpyHostToDevice, L.stream));
+    launch_fr_from_be(L.stream, L.in_be.as<uint8_t>(), tau_m, (uint64_t)n_slices + 1, 1, L.flags());
     for (uint32_t k = 0; k < n_slices; k++) {
         for (uint64_t first = 0; first < T; first += tile) {
             uint64_t cnt = T - first < tile ? T - first : tile;
-            launch_srs_generate(ctx->stream, ctx->table.as<g1_affine_t>() + (uint64_t)k * T + first, cnt, first, tau_m,
+            launch_srs_generate(L.stream, ctx->table.as<g1_affine_t>() + (uint64_t)k * T + first, cnt, first, tau_m,
                                 tau_m + 8 * (1 + (uint64_t)k), gtab.as<g1_affine_t>(), tmp.as<g1_xyzz_t>(),
                                 k == 0 && first == 0);
         }
     }
-    rc = finish(ctx);
-    gtab.release(); tmp.release(); sc.release();
+    rc = finish(ctx, L);  // synchronises: gtab / tmp / sc are idle when they go out of scope
     if (rc) return rc;
     HIPCHK(ctx, hipGetLastError());
-    return precompute_tables(ctx);
+    rc = precompute_tables(ctx);
+    if (rc) return rc;
+    rollback.armed = false;
+    H.clean = true;
+    return KZG_OK;
 }
 
 static int srs_read_common(kzg_ctx* ctx, int w, uint64_t first, uint64_t count, uint8_t* out, bool compressed) {
     if (!ctx || !out) return KZG_E_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (int busy = need_idle(ctx)) return busy;
+    LaneHold H(ctx);
+    if (int rc = H.take()) return rc;
+    Lane& L = H.L();
     int rc = need_srs(ctx);
     if (rc) return rc;
     if (w < 0 || w >= ctx->nwin || first + count > ctx->stride) return fail(ctx, KZG_E_ARG, "srs_read out of range");
     if (!count) return KZG_OK;
     const size_t rec = compressed ? 48 : 96;
-    HIPCHK(ctx, ctx->out_be.ensure(count * rec));
+    HIPCHK(ctx, L.out_be.ensure(count * rec));
     const g1_affine_t* src = ctx->table.as<g1_affine_t>() + (uint64_t)w * ctx->stride + first;
-    if (compressed) launch_srs_to_c48(ctx->stream, src, ctx->out_be.as<uint8_t>(), count);
-    else launch_srs_to_be96(ctx->stream, src, ctx->out_be.as<uint8_t>(), count);
-    HIPCHK(ctx, hipMemcpyAsync(out, ctx->out_be.p, count * rec, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (compressed) launch_srs_to_c48(L.stream, src, L.out_be.as<uint8_t>(), count);
+    else launch_srs_to_be96(L.stream, src, L.out_be.as<uint8_t>(), count);
+    HIPCHK(ctx, hipMemcpyAsync(out, L.out_be.p, count * rec, hipMemcpyDeviceToHost, L.stream));
+    HIPCHK(ctx, hipStreamSynchronize(L.stream));
+    H.clean = true;
     return KZG_OK;
 }
 int kzg_srs_read(kzg_ctx* ctx, int w, uint64_t first, uint64_t count, uint8_t* out_be96) {
@@ -757,31 +929,27 @@ int kzg_srs_read_compressed(kzg_ctx* ctx, int w, uint64_t first, uint64_t count,
 static int msm_host_common(kzg_ctx* ctx, const uint8_t* scalars_be32, uint64_t n, uint64_t srs_offset, uint8_t* out,
                            bool partial) {
     if (!ctx || !out || (n && !scalars_be32)) return KZG_E_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (int busy = need_idle(ctx)) return busy;
+    LaneHold H(ctx);
+    if (int rc = H.take()) return rc;
+    Lane& L = H.L();
     int rc = need_srs(ctx);
     if (rc) return rc;
-    prof_begin(ctx);
-    rc = clear_flags(ctx);
+    prof_begin(ctx, L);
+    rc = clear_flags(ctx, L);
     if (rc) return rc;
-    HIPCHK(ctx, ctx->scal.ensure(n * 32 + 32));
-    HIPCHK(ctx, ctx->res.ensure(4 * sizeof(g1_xyzz_t)));
-    HIPCHK(ctx, ctx->small.ensure(1024));
-    rc = upload_fr(ctx, scalars_be32, n, ctx->scal.as<uint32_t>(), 0);
+    HIPCHK(ctx, L.scal.ensure(n * 32 + 32));
+    rc = upload_fr(ctx, L, scalars_be32, n, L.scal.as<uint32_t>(), 0);
     if (rc) return rc;
-    rc = msm_core(ctx, 0, ctx->scal.as<uint32_t>(), 0, n, srs_offset, ctx->res.as<g1_xyzz_t>());
+    rc = msm_core(ctx, L, L.scal.as<uint32_t>(), 0, n, srs_offset, L.res());
     if (rc) return rc;
-    if (partial) {
-        launch_xyzz_pack(ctx->stream, ctx->res.as<g1_xyzz_t>(), ctx->small.as<uint32_t>(), 1);
-        HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, ctx->small.p, 192, hipMemcpyDeviceToHost, ctx->stream));
-    } else {
-        launch_g1_compress(ctx->stream, ctx->res.as<g1_xyzz_t>(), ctx->small.as<uint8_t>());
-        HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, ctx->small.p, 48, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    rc = finish(ctx);
+    if (partial) queue_pack(ctx, L);
+    else queue_encode(ctx, L, true, false);
+    rc = finish(ctx, L);
     if (rc) return rc;
-    memcpy(out, ctx->host_pin + 64, partial ? 192 : 48);
+    if (partial) result_partial(ctx, L, out);
+    else result_c48(ctx, L, 0, out);
+    H.clean = true;
     return KZG_OK;
 }
 int kzg_msm(kzg_ctx* ctx, const uint8_t* scalars_be32, uint64_t n, uint64_t srs_offset, uint8_t out48[48]) {
@@ -792,55 +960,80 @@ int kzg_msm_partial(kzg_ctx* ctx, const uint8_t* scalars_be32, uint64_t n, uint6
     return msm_host_common(ctx, scalars_be32, n, srs_offset, out_xyzz192, true);
 }
 
-// runs on its own stream and buffers: legal while MSM tickets are outstanding (a rank sums the gathered partials
-// of step i while its step i+1 is already on the GPU).  `on_device`: the partials already sit in device memory
-// (the output tensor of the all_gather) and every prior writer has completed.
-static int g1_sum_common(kzg_ctx* ctx, const uint8_t* partials, uint32_t count, uint8_t out48[48], bool on_device) {
-    if (!ctx || !out48 || (count && !partials)) return KZG_E_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+// Sums of a few points run on their own stream and buffers: legal while MSM tickets are outstanding (a rank sums the
+// gathered partials of step i while its step i+1 is already on the GPU).  Three input forms:
+//   host partials (192-byte XYZZ records), device partials (the output tensor of an all_gather; every prior writer has
+//   completed), and 48-byte compressed points (the commitments of the worker rows: Pianist's master aggregation
+//   sum_i commit_i, reference neurons/validator.py:196-198, README.md:38) which are decompressed on the GPU.
+static int g1_sum_common(kzg_ctx* ctx, const uint8_t* in, uint32_t count, uint8_t out48[48], int form) {
+    if (!ctx || !out48 || (count && !in)) return KZG_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, ctx->aux_in.ensure((size_t)count * 192 + 192));
+    std::lock_guard<std::mutex> lk(ctx->aux_mu);
+    const size_t rec = form == 2 ? 48 : 192;
+    HIPCHK(ctx, ctx->aux_in.ensure((size_t)count * rec + 192));
     HIPCHK(ctx, ctx->aux_pts.ensure(((size_t)count + 2) * sizeof(g1_xyzz_t)));
-    HIPCHK(ctx, ctx->aux_out.ensure(64));
+    HIPCHK(ctx, ctx->aux_out.ensure(256));
     hipStream_t s = ctx->aux;
     g1_xyzz_t* pts = ctx->aux_pts.as<g1_xyzz_t>();
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(partials);
-    if (!on_device) {
-        if (count) HIPCHK(ctx, hipMemcpyAsync(ctx->aux_in.p, partials, (size_t)count * 192, hipMemcpyHostToDevice, s));
-        src = ctx->aux_in.as<uint32_t>();
+    uint32_t* bad = ctx->aux_out.as<uint32_t>() + 32;
+    HIPCHK(ctx, hipMemsetAsync(bad, 0, 4, s));
+    if (form == 2) {
+        static_assert(sizeof(g1_affine_t) <= sizeof(g1_xyzz_t), "affine rows are staged in the XYZZ scratch");
+        if (count) HIPCHK(ctx, hipMemcpyAsync(ctx->aux_in.p, in, (size_t)count * 48, hipMemcpyHostToDevice, s));
+        g1_affine_t* aff = reinterpret_cast<g1_affine_t*>(pts + 1);
+        launch_srs_from_c48(s, ctx->aux_in.as<uint8_t>(), aff, count, bad);
+        launch_g1_sum_affine(s, aff, count, pts);
+    } else {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(in);
+        if (form == 0) {
+            if (count) HIPCHK(ctx, hipMemcpyAsync(ctx->aux_in.p, in, (size_t)count * 192, hipMemcpyHostToDevice, s));
+            src = ctx->aux_in.as<uint32_t>();
+        }
+        launch_xyzz_unpack(s, src, pts + 1, count);
+        launch_g1_sum(s, pts + 1, count, pts);
     }
-    launch_xyzz_unpack(s, src, pts + 1, count);
-    launch_g1_sum(s, pts + 1, count, pts);
-    launch_g1_compress(s, pts, ctx->aux_out.as<uint8_t>());
-    uint8_t* pin = ctx->host_pin + 1024;
-    HIPCHK(ctx, hipMemcpyAsync(pin, ctx->aux_out.p, 48, hipMemcpyDeviceToHost, s));
+    uint8_t* pin = ctx->aux_pin;
+    if (ctx->host_finish) {
+        HIPCHK(ctx, hipMemcpyAsync(pin, pts, sizeof(g1_xyzz_t), hipMemcpyDeviceToHost, s));
+    } else {
+        launch_g1_compress(s, pts, ctx->aux_out.as<uint8_t>());
+        HIPCHK(ctx, hipMemcpyAsync(pin, ctx->aux_out.p, 48, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(pin + 224, bad, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
     HIPCHK(ctx, hipGetLastError());
-    memcpy(out48, pin, 48);
+    if (*reinterpret_cast<const uint32_t*>(pin + 224))
+        return fail(ctx, KZG_E_POINT, "compressed G1 input malformed, not reduced or not on the curve");
+    if (ctx->host_finish) kzg_host::xyzz_to_c48(reinterpret_cast<const uint32_t*>(pin), out48);
+    else memcpy(out48, pin, 48);
     return KZG_OK;
 }
 int kzg_g1_sum(kzg_ctx* ctx, const uint8_t* partials_xyzz192, uint32_t count, uint8_t out48[48]) {
-    return g1_sum_common(ctx, partials_xyzz192, count, out48, false);
+    return g1_sum_common(ctx, partials_xyzz192, count, out48, 0);
 }
 int kzg_g1_sum_dev(kzg_ctx* ctx, const void* dev_partials_xyzz192, uint32_t count, uint8_t out48[48]) {
-    return g1_sum_common(ctx, reinterpret_cast<const uint8_t*>(dev_partials_xyzz192), count, out48, true);
+    return g1_sum_common(ctx, reinterpret_cast<const uint8_t*>(dev_partials_xyzz192), count, out48, 1);
+}
+int kzg_g1_sum_compressed(kzg_ctx* ctx, const uint8_t* points_c48, uint32_t count, uint8_t out48[48]) {
+    return g1_sum_common(ctx, points_c48, count, out48, 2);
 }
 
 static int commit_open_host(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
                             const uint8_t* alpha, uint8_t* c48, uint8_t* e32, uint8_t* p48) {
     if (!ctx || !row_be32 || (p48 && (!alpha || !e32))) return KZG_E_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (int busy = need_idle(ctx)) return busy;
+    LaneHold H(ctx);
+    if (int rc = H.take()) return rc;
+    Lane& L = H.L();
     int rc = check_worker(ctx, i, T);
     if (rc) return rc;
-    prof_begin(ctx);
-    rc = clear_flags(ctx);
+    prof_begin(ctx, L);
+    rc = clear_flags(ctx, L);
     if (rc) return rc;
-    HIPCHK(ctx, ctx->coeffA.ensure(T * 32));
-    rc = upload_fr(ctx, row_be32, T, ctx->coeffA.as<uint32_t>(), 1);
+    HIPCHK(ctx, L.coeffA.ensure(T * 32));
+    rc = upload_fr(ctx, L, row_be32, T, L.coeffA.as<uint32_t>(), 1);
     if (rc) return rc;
-    return commit_open_dev(ctx, i, ctx->coeffA.as<uint32_t>(), T, evaluation_form, alpha, c48, e32, p48);
+    return commit_open_dev(ctx, H, i, L.coeffA.as<uint32_t>(), T, evaluation_form, alpha, c48, e32, p48);
 }
 int kzg_commit(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
                uint8_t out_commitment48[48]) {
@@ -860,89 +1053,92 @@ int kzg_commit_open(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t 
                             out_proof48);
 }
 
-static int ntt_dev(kzg_ctx* ctx, uint32_t* data, uint64_t n, int inverse) {  // in place via coeffB
+static int ntt_dev(kzg_ctx* ctx, Lane& L, uint32_t* data, uint64_t n, int inverse) {  // in place via coeffB
     int lg = ilog2_exact(n);
     if (lg < 0) return fail(ctx, KZG_E_ARG, "NTT length must be a power of two");
     uint32_t *tw = nullptr, *invn = nullptr;
-    int rc = ensure_twiddles(ctx, lg, inverse, &tw, inverse ? &invn : nullptr);
+    int rc = ensure_twiddles(ctx, L, lg, inverse, &tw, inverse ? &invn : nullptr);
     if (rc) return rc;
-    HIPCHK(ctx, ctx->coeffB.ensure(n * 32));
+    HIPCHK(ctx, L.coeffB.ensure(n * 32));
     {
-        Span sp(ctx, KZG_T_NTT);
-        launch_fr_ntt(ctx->stream, data, ctx->coeffB.as<uint32_t>(), lg, tw, inverse ? invn : nullptr);
-        HIPCHK(ctx, hipMemcpyAsync(data, ctx->coeffB.p, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+        Span sp(ctx, L, KZG_T_NTT);
+        launch_fr_ntt(L.stream, data, L.coeffB.as<uint32_t>(), lg, tw, inverse ? invn : nullptr);
+        HIPCHK(ctx, hipMemcpyAsync(data, L.coeffB.p, n * 32, hipMemcpyDeviceToDevice, L.stream));
     }
     return KZG_OK;
 }
 int kzg_ntt(kzg_ctx* ctx, uint8_t* inout_be32, uint64_t n, int inverse) {
     if (!ctx || !inout_be32 || !n) return KZG_E_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (int busy = need_idle(ctx)) return busy;
-    prof_begin(ctx);
-    int rc = clear_flags(ctx);
+    LaneHold H(ctx);
+    if (int rc = H.take()) return rc;
+    Lane& L = H.L();
+    prof_begin(ctx, L);
+    int rc = clear_flags(ctx, L);
     if (rc) return rc;
-    HIPCHK(ctx, ctx->coeffA.ensure(n * 32));
-    HIPCHK(ctx, ctx->out_be.ensure(n * 32));
-    rc = upload_fr(ctx, inout_be32, n, ctx->coeffA.as<uint32_t>(), 1);
+    HIPCHK(ctx, L.coeffA.ensure(n * 32));
+    HIPCHK(ctx, L.out_be.ensure(n * 32));
+    rc = upload_fr(ctx, L, inout_be32, n, L.coeffA.as<uint32_t>(), 1);
     if (rc) return rc;
-    rc = ntt_dev(ctx, ctx->coeffA.as<uint32_t>(), n, inverse);
+    rc = ntt_dev(ctx, L, L.coeffA.as<uint32_t>(), n, inverse);
     if (rc) return rc;
-    launch_fr_to_be(ctx->stream, ctx->coeffA.as<uint32_t>(), ctx->out_be.as<uint8_t>(), n, 1);
-    rc = finish(ctx);
+    launch_fr_to_be(L.stream, L.coeffA.as<uint32_t>(), L.out_be.as<uint8_t>(), n, 1);
+    rc = finish(ctx, L);
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpy(inout_be32, ctx->out_be.p, n * 32, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(inout_be32, L.out_be.p, n * 32, hipMemcpyDeviceToHost));
+    H.clean = true;
     return KZG_OK;
 }
 int kzg_eval(kzg_ctx* ctx, const uint8_t* coeffs_be32, uint64_t n, const uint8_t x_be32[32], uint8_t out_be32[32]) {
     if (!ctx || !x_be32 || !out_be32 || (n && !coeffs_be32)) return KZG_E_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (int busy = need_idle(ctx)) return busy;
     if (n == 0) {
         memset(out_be32, 0, 32);
         return KZG_OK;
     }
-    prof_begin(ctx);
-    int rc = clear_flags(ctx);
+    LaneHold H(ctx);
+    if (int rc = H.take()) return rc;
+    Lane& L = H.L();
+    prof_begin(ctx, L);
+    int rc = clear_flags(ctx, L);
     if (rc) return rc;
-    HIPCHK(ctx, ctx->coeffA.ensure(n * 32));
-    HIPCHK(ctx, ctx->small.ensure(1024));
+    HIPCHK(ctx, L.coeffA.ensure(n * 32));
     const uint64_t nchunks = (n + 3) / 4;
-    HIPCHK(ctx, ctx->hbuf.ensure((nchunks + (nchunks >> 3) + 64) * 32));
-    HIPCHK(ctx, ctx->hnext.ensure((nchunks + (nchunks >> 3) + 64) * 32));
-    rc = upload_fr(ctx, coeffs_be32, n, ctx->coeffA.as<uint32_t>(), 1);
+    HIPCHK(ctx, L.hbuf.ensure((nchunks + (nchunks >> 3) + 64) * 32));
+    HIPCHK(ctx, L.hnext.ensure((nchunks + (nchunks >> 3) + 64) * 32));
+    rc = upload_fr(ctx, L, coeffs_be32, n, L.coeffA.as<uint32_t>(), 1);
     if (rc) return rc;
-    uint8_t* small = ctx->small.as<uint8_t>();
-    uint32_t* x_m = reinterpret_cast<uint32_t*>(small + 192);
-    uint32_t* y_m = reinterpret_cast<uint32_t*>(small + 256);
-    HIPCHK(ctx, hipMemcpyAsync(small + 320, x_be32, 32, hipMemcpyHostToDevice, ctx->stream));
-    launch_fr_from_be(ctx->stream, small + 320, x_m, 1, 1, ctx->flags);
-    launch_poly_open(ctx->stream, ctx->coeffA.as<uint32_t>(), n, x_m, ctx->hbuf.as<uint32_t>(),
-                     ctx->hnext.as<uint32_t>(), y_m, nullptr);
-    launch_fr_to_be(ctx->stream, y_m, small + 128, 1, 1);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, small + 128, 32, hipMemcpyDeviceToHost, ctx->stream));
-    rc = finish(ctx);
+    uint32_t* x_m = reinterpret_cast<uint32_t*>(L.tail + TB_ALPHA_M);
+    uint32_t* y_m = reinterpret_cast<uint32_t*>(L.tail + TB_Y_M);
+    HIPCHK(ctx, hipMemcpyAsync(L.tail + TB_ALPHA_BE, x_be32, 32, hipMemcpyHostToDevice, L.stream));
+    launch_fr_from_be(L.stream, L.tail + TB_ALPHA_BE, x_m, 1, 1, L.flags());
+    launch_poly_open(L.stream, L.coeffA.as<uint32_t>(), n, x_m, L.hbuf.as<uint32_t>(), L.hnext.as<uint32_t>(), y_m, nullptr);
+    launch_fr_to_be(L.stream, y_m, L.tail + TB_EVAL, 1, 1);
+    rc = finish(ctx, L);
     if (rc) return rc;
-    memcpy(out_be32, ctx->host_pin + 64, 32);
+    memcpy(out_be32, L.pin + TB_EVAL, 32);
+    H.clean = true;
     return KZG_OK;
 }
 
 int kzg_upload_fr(kzg_ctx* ctx, int slot, const uint8_t* be32, uint64_t n, int to_mont) {
     if (!ctx || slot < 0 || slot >= N_SLOTS || (n && !be32)) return KZG_E_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (int busy = need_idle(ctx)) return busy;
-    prof_begin(ctx);
-    int rc = clear_flags(ctx);
+    LaneHold H(ctx);
+    if (int rc = H.take_all()) return rc;   // no request may be reading the slot
+    Lane& L = H.L();
+    prof_begin(ctx, L);
+    int rc = clear_flags(ctx, L);
     if (rc) return rc;
+    ctx->slot_n[slot] = 0;
     HIPCHK(ctx, ctx->slot[slot].ensure(n * 32 + 32));
-    rc = upload_fr(ctx, be32, n, ctx->slot[slot].as<uint32_t>(), to_mont);
+    rc = upload_fr(ctx, L, be32, n, ctx->slot[slot].as<uint32_t>(), to_mont);
     if (rc) return rc;
-    rc = finish(ctx);
+    rc = finish(ctx, L);
     if (rc) return rc;
     ctx->slot_n[slot] = n;
     ctx->slot_mont[slot] = to_mont ? 1 : 0;
+    H.clean = true;
     return KZG_OK;
 }
 // dev_out != null: the 192-byte partial is left in the CALLER's device buffer (e.g. a torch tensor about to enter an
@@ -950,32 +1146,28 @@ int kzg_upload_fr(kzg_ctx* ctx, int slot, const uint8_t* be32, uint64_t n, int t
 static int msm_resident_common(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint8_t* out, bool partial,
                                void* dev_out = nullptr) {
     if (!ctx || (!out && !dev_out) || slot < 0 || slot >= N_SLOTS) return KZG_E_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (int busy = need_idle(ctx)) return busy;
+    LaneHold H(ctx);
+    if (int rc = H.take()) return rc;
+    Lane& L = H.L();
     int rc = need_srs(ctx);
     if (rc) return rc;
     if (n > ctx->slot_n[slot]) return fail(ctx, KZG_E_ARG, "slot holds fewer scalars than requested");
-    prof_begin(ctx);
-    rc = clear_flags(ctx);
+    prof_begin(ctx, L);
+    rc = clear_flags(ctx, L);
     if (rc) return rc;
-    HIPCHK(ctx, ctx->res.ensure(4 * sizeof(g1_xyzz_t)));
-    HIPCHK(ctx, ctx->small.ensure(1024));
-    rc = msm_core(ctx, 0, ctx->slot[slot].as<uint32_t>(), ctx->slot_mont[slot], n, srs_offset, ctx->res.as<g1_xyzz_t>());
+    rc = msm_core(ctx, L, ctx->slot[slot].as<uint32_t>(), ctx->slot_mont[slot], n, srs_offset, L.res());
     if (rc) return rc;
-    if (dev_out) {
-        launch_xyzz_pack(ctx->stream, ctx->res.as<g1_xyzz_t>(), reinterpret_cast<uint32_t*>(dev_out), 1);
-    } else if (partial) {
-        launch_xyzz_pack(ctx->stream, ctx->res.as<g1_xyzz_t>(), ctx->small.as<uint32_t>(), 1);
-        HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, ctx->small.p, 192, hipMemcpyDeviceToHost, ctx->stream));
-    } else {
-        Span sp(ctx, KZG_T_FINAL);
-        launch_g1_compress(ctx->stream, ctx->res.as<g1_xyzz_t>(), ctx->small.as<uint8_t>());
-        HIPCHK(ctx, hipMemcpyAsync(ctx->host_pin + 64, ctx->small.p, 48, hipMemcpyDeviceToHost, ctx->stream));
+    if (dev_out) launch_xyzz_pack(L.stream, L.res(), reinterpret_cast<uint32_t*>(dev_out), 1);
+    else if (partial) queue_pack(ctx, L);
+    else queue_encode(ctx, L, true, false);
+    rc = finish(ctx, L);  // synchronises the stream: dev_out is complete when the call returns
+    if (rc) return rc;
+    if (out) {
+        if (partial) result_partial(ctx, L, out);
+        else result_c48(ctx, L, 0, out);
     }
-    rc = finish(ctx);  // synchronises the stream: dev_out is complete when the call returns
-    if (rc) return rc;
-    if (out) memcpy(out, ctx->host_pin + 64, partial ? 192 : 48);
+    H.clean = true;
     return KZG_OK;
 }
 int kzg_msm_partial_resident_dev(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, void* dev_out_xyzz192) {
@@ -988,58 +1180,63 @@ int kzg_msm_resident(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, ui
 int kzg_msm_partial_resident(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint8_t out_xyzz192[192]) {
     return msm_resident_common(ctx, slot, n, srs_offset, out_xyzz192, true);
 }
-// ---- ticketed MSM: submit returns once the work is queued on a free lane, wait returns the result.  Two lanes, so
-// MSM i+1 (sort, accumulate) overlaps the latency-bound tail (fold, bucket tree, final combination, inversion) of
-// MSM i.  While a ticket is outstanding only kzg_msm_submit / kzg_msm_wait / kzg_g1_sum may be called on the ctx.
+// ---- ticketed MSM: submit returns once the work is queued on a free lane, wait returns the result, so MSM i+1 (sort,
+// accumulate) overlaps the latency-bound tail (fold, bucket tree, final combination) of MSM i from ONE host thread.
+// (Several host threads get the same overlap from the blocking calls: each call runs on its own lane.)
 int kzg_msm_submit(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, int partial, int* out_ticket) {
     if (!ctx || !out_ticket || slot < 0 || slot >= N_SLOTS) return KZG_E_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc = need_srs(ctx);
     if (rc) return rc;
     if (n > ctx->slot_n[slot]) return fail(ctx, KZG_E_ARG, "slot holds fewer scalars than requested");
     int li = -1;
-    for (int k = 0; k < N_LANES && li < 0; k++)
-        if (!ctx->lane[(ctx->next_lane + k) % N_LANES].busy) li = (ctx->next_lane + k) % N_LANES;
-    if (li < 0) return fail(ctx, KZG_E_BUSY, "both MSM lanes hold an outstanding ticket: call kzg_msm_wait first");
-    MsmLane& L = ctx->lane[li];
-    HIPCHK(ctx, L.res.ensure(sizeof(g1_xyzz_t)));
-    HIPCHK(ctx, L.small.ensure(256));
-    prof_begin(ctx, li);
-    rc = msm_core(ctx, li, ctx->slot[slot].as<uint32_t>(), ctx->slot_mont[slot], n, srs_offset, L.res.as<g1_xyzz_t>());
+    rc = lane_acquire(ctx, LANE_TICKET, &li);
     if (rc) return rc;
-    uint8_t* pin = ctx->host_pin + 256 + 256 * li;
-    if (partial) {
-        launch_xyzz_pack(L.stream, L.res.as<g1_xyzz_t>(), L.small.as<uint32_t>(), 1);
-    } else {
-        Span sp(ctx, KZG_T_FINAL, L.stream, li);
-        launch_g1_compress(L.stream, L.res.as<g1_xyzz_t>(), L.small.as<uint8_t>());
+    Lane& L = ctx->lane[li];
+    prof_begin(ctx, L);
+    rc = clear_flags(ctx, L);
+    if (!rc) rc = msm_core(ctx, L, ctx->slot[slot].as<uint32_t>(), ctx->slot_mont[slot], n, srs_offset, L.res());
+    if (!rc) {
+        L.partial = partial != 0;
+        if (partial) queue_pack(ctx, L);
+        else queue_encode(ctx, L, true, false);
+        prof_close(ctx, L);
+        hipError_t e = hipMemcpyAsync(L.pin, L.tail, TB_COPY, hipMemcpyDeviceToHost, L.stream);
+        if (e == hipSuccess) e = hipEventRecord(L.ev_done, L.stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) rc = fail(ctx, KZG_E_HIP, std::string("kzg_msm_submit: ") + hipGetErrorString(e));
     }
-    prof_close(ctx, li);
-    HIPCHK(ctx, hipMemcpyAsync(pin, L.small.p, partial ? 192 : 48, hipMemcpyDeviceToHost, L.stream));
-    HIPCHK(ctx, hipEventRecord(L.ev_done, L.stream));
-    HIPCHK(ctx, hipGetLastError());
-    L.busy = true;
-    L.partial = partial != 0;
-    ctx->next_lane = (li + 1) % N_LANES;
+    if (rc) {  // nothing may still be running on the lane's buffers when it becomes reusable
+        (void)hipStreamSynchronize(L.stream);
+        (void)hipGetLastError();
+        lane_release(ctx, li);
+        return rc;
+    }
     *out_ticket = li;
     return KZG_OK;
 }
 int kzg_msm_wait(kzg_ctx* ctx, int ticket, uint8_t* out) {
     if (!ctx || !out || ticket < 0 || ticket >= N_LANES) return KZG_E_ARG;
-    MsmLane& L = ctx->lane[ticket];
+    Lane& L = ctx->lane[ticket];
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
-        if (!L.busy) return fail(ctx, KZG_E_ARG, "no outstanding MSM on this ticket");
-        HIPCHK(ctx, hipSetDevice(ctx->device));
+        // exactly one waiter per ticket: a second one would read the pinned result after the lane has been reused
+        if (L.state != LANE_TICKET) return fail(ctx, KZG_E_ARG, "no outstanding MSM on this ticket (or it is already being waited for)");
+        L.state = LANE_WAITING;
     }
-    hipError_t e = hipEventSynchronize(L.ev_done);  // not under the lock: another thread may submit meanwhile
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    L.busy = false;
-    HIPCHK(ctx, e);
-    prof_end(ctx, ticket);
-    memcpy(out, ctx->host_pin + 256 + 256 * ticket, L.partial ? 192 : 48);
-    return KZG_OK;
+    (void)hipSetDevice(ctx->device);
+    hipError_t e = hipEventSynchronize(L.ev_done);  // not under the lock: other threads submit / run meanwhile
+    int rc = KZG_OK;
+    if (e != hipSuccess) {
+        rc = fail(ctx, KZG_E_HIP, std::string("hipEventSynchronize(ticket): ") + hipGetErrorString(e));
+        (void)hipStreamSynchronize(L.stream);
+    } else {
+        prof_end(ctx, L);
+        if (L.partial) result_partial(ctx, L, out);
+        else result_c48(ctx, L, 0, out);
+    }
+    lane_release(ctx, ticket);
+    return rc;
 }
 
 int kzg_commit_open_resident(kzg_ctx* ctx, uint32_t i, int slot, uint64_t T, int evaluation_form,
@@ -1047,50 +1244,86 @@ int kzg_commit_open_resident(kzg_ctx* ctx, uint32_t i, int slot, uint64_t T, int
                              uint8_t out_proof48[48]) {
     if (!ctx || slot < 0 || slot >= N_SLOTS || !alpha_be32 || !out_commitment48 || !out_eval32 || !out_proof48)
         return KZG_E_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (int busy = need_idle(ctx)) return busy;
+    LaneHold H(ctx);
+    if (int rc = H.take()) return rc;
+    Lane& L = H.L();
     int rc = check_worker(ctx, i, T);
     if (rc) return rc;
     if (T > ctx->slot_n[slot] || !ctx->slot_mont[slot])
         return fail(ctx, KZG_E_ARG, "slot must hold >= T Montgomery-form elements (kzg_upload_fr(.., to_mont=1))");
-    prof_begin(ctx);
-    rc = clear_flags(ctx);
+    prof_begin(ctx, L);
+    rc = clear_flags(ctx, L);
     if (rc) return rc;
-    return commit_open_dev(ctx, i, ctx->slot[slot].as<uint32_t>(), T, evaluation_form, alpha_be32, out_commitment48,
+    return commit_open_dev(ctx, H, i, ctx->slot[slot].as<uint32_t>(), T, evaluation_form, alpha_be32, out_commitment48,
                            out_eval32, out_proof48);
 }
 int kzg_ntt_resident(kzg_ctx* ctx, int slot, uint64_t n, int inverse) {
     if (!ctx || slot < 0 || slot >= N_SLOTS || !n) return KZG_E_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (int busy = need_idle(ctx)) return busy;
+    LaneHold H(ctx);
+    if (int rc = H.take_all()) return rc;   // rewrites the slot in place
+    Lane& L = H.L();
     if (n > ctx->slot_n[slot] || !ctx->slot_mont[slot]) return fail(ctx, KZG_E_ARG, "slot must hold >= n Montgomery elements");
-    prof_begin(ctx);
-    int rc = clear_flags(ctx);
+    prof_begin(ctx, L);
+    int rc = clear_flags(ctx, L);
     if (rc) return rc;
-    rc = ntt_dev(ctx, ctx->slot[slot].as<uint32_t>(), n, inverse);
+    rc = ntt_dev(ctx, L, ctx->slot[slot].as<uint32_t>(), n, inverse);
     if (rc) return rc;
-    return finish(ctx);
+    rc = finish(ctx, L);
+    if (rc) return rc;
+    H.clean = true;
+    return KZG_OK;
 }
 
-int kzg_staging_buffer(kzg_ctx* ctx, uint64_t bytes, void** out_ptr) {
-    if (!ctx || !out_ptr) return KZG_E_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+// ---- pinned host staging: a pool of N_STAGE page-locked buffers, one per request in flight
+int kzg_staging_acquire(kzg_ctx* ctx, uint64_t bytes, void** out_ptr, int* out_token) {
+    if (!ctx || !out_ptr || !out_token) return KZG_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (bytes > ctx->stage_cap) {
-        if (ctx->stage_host) (void)hipHostFree(ctx->stage_host);
-        ctx->stage_host = nullptr;
-        ctx->stage_cap = 0;
+    int k = -1;
+    {
+        std::unique_lock<std::mutex> lk(ctx->mu);
+        for (;;) {
+            // prefer a free buffer that is already large enough
+            for (int i = 0; i < N_STAGE && k < 0; i++)
+                if (!ctx->stage[i].used && ctx->stage[i].cap >= bytes) k = i;
+            for (int i = 0; i < N_STAGE && k < 0; i++)
+                if (!ctx->stage[i].used) k = i;
+            if (k >= 0) break;
+            ctx->cv.wait(lk);
+        }
+        ctx->stage[k].used = true;
+    }
+    Stage& st = ctx->stage[k];
+    if (bytes > st.cap) {
+        if (st.p) (void)hipHostFree(st.p);
+        st.p = nullptr;
+        st.cap = 0;
         const size_t want = (size_t)bytes + ((size_t)bytes >> 3) + 4096;
-        hipError_t e = hipHostMalloc(&ctx->stage_host, want, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(&st.p, want, hipHostMallocDefault);
         if (e != hipSuccess) {
-            ctx->stage_host = nullptr;
+            st.p = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(ctx->mu);
+                st.used = false;
+            }
+            ctx->cv.notify_all();
             return fail(ctx, KZG_E_NOMEM, std::string("hipHostMalloc(staging): ") + hipGetErrorString(e));
         }
-        ctx->stage_cap = want;
+        st.cap = want;
     }
-    *out_ptr = ctx->stage_host;
+    *out_ptr = st.p;
+    *out_token = k;
+    return KZG_OK;
+}
+int kzg_staging_release(kzg_ctx* ctx, int token) {
+    if (!ctx || token < 0 || token >= N_STAGE) return KZG_E_ARG;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (!ctx->stage[token].used) return fail(ctx, KZG_E_ARG, "staging buffer is not held");
+        ctx->stage[token].used = false;
+    }
+    ctx->cv.notify_all();
     return KZG_OK;
 }
 
@@ -1114,6 +1347,17 @@ int kzg_msm_plan(kzg_ctx* ctx, uint64_t n, int32_t out[4]) {
     out[1] = (int32_t)((entries + chunk - 1) / chunk);
     out[2] = (int32_t)ctx->nbuckets;
     out[3] = ctx->nwin;
+    return KZG_OK;
+}
+// test hooks for the host-side encoder (finish_host.cpp): no GPU involved
+int kzg_host_xyzz_to_c48(const uint32_t xyzz_limbs28[56], uint8_t out48[48]) {
+    if (!xyzz_limbs28 || !out48) return KZG_E_ARG;
+    kzg_host::xyzz_to_c48(xyzz_limbs28, out48);
+    return KZG_OK;
+}
+int kzg_host_xyzz_to_partial192(const uint32_t xyzz_limbs28[56], uint8_t out192[192]) {
+    if (!xyzz_limbs28 || !out192) return KZG_E_ARG;
+    kzg_host::xyzz_to_partial192(xyzz_limbs28, out192);
     return KZG_OK;
 }
 
@@ -1158,39 +1402,43 @@ int kzg_b64_encode_fr(const uint8_t* be32, uint64_t n, char* out_packed43) {
 int kzg_test_field(kzg_ctx* ctx, int field, int op, const uint8_t* a_be, const uint8_t* b_be, uint8_t* out_be,
                    uint64_t n) {
     if (!ctx || !a_be || !b_be || !out_be || !n) return KZG_E_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (int busy = need_idle(ctx)) return busy;
+    LaneHold H(ctx);
+    if (int rc = H.take()) return rc;
+    Lane& L = H.L();
     const size_t w = field == 0 ? 48 : 32;
-    HIPCHK(ctx, ctx->in_be.ensure(2 * n * w));
-    HIPCHK(ctx, ctx->out_be.ensure(n * w));
-    uint8_t* da = ctx->in_be.as<uint8_t>();
+    HIPCHK(ctx, L.in_be.ensure(2 * n * w));
+    HIPCHK(ctx, L.out_be.ensure(n * w));
+    uint8_t* da = L.in_be.as<uint8_t>();
     uint8_t* db = da + n * w;
-    HIPCHK(ctx, hipMemcpyAsync(da, a_be, n * w, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(db, b_be, n * w, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(da, a_be, n * w, hipMemcpyHostToDevice, L.stream));
+    HIPCHK(ctx, hipMemcpyAsync(db, b_be, n * w, hipMemcpyHostToDevice, L.stream));
     uint32_t blocks = (uint32_t)((n + 255) / 256);
-    if (field == 0) k_test_fp<<<blocks, 256, 0, ctx->stream>>>(op, da, db, ctx->out_be.as<uint8_t>(), n);
-    else k_test_fr<<<blocks, 256, 0, ctx->stream>>>(op, da, db, ctx->out_be.as<uint8_t>(), n);
-    HIPCHK(ctx, hipMemcpyAsync(out_be, ctx->out_be.p, n * w, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (field == 0) k_test_fp<<<blocks, 256, 0, L.stream>>>(op, da, db, L.out_be.as<uint8_t>(), n);
+    else k_test_fr<<<blocks, 256, 0, L.stream>>>(op, da, db, L.out_be.as<uint8_t>(), n);
+    HIPCHK(ctx, hipMemcpyAsync(out_be, L.out_be.p, n * w, hipMemcpyDeviceToHost, L.stream));
+    HIPCHK(ctx, hipStreamSynchronize(L.stream));
     HIPCHK(ctx, hipGetLastError());
+    H.clean = true;
     return KZG_OK;
 }
 int kzg_test_g1(kzg_ctx* ctx, int op, const uint8_t* a_be96, const uint8_t* b_be96, uint8_t* out_be96, uint64_t n) {
     if (!ctx || !a_be96 || !b_be96 || !out_be96 || !n) return KZG_E_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (int busy = need_idle(ctx)) return busy;
-    HIPCHK(ctx, ctx->in_be.ensure(2 * n * 96));
-    HIPCHK(ctx, ctx->out_be.ensure(n * 96));
-    uint8_t* da = ctx->in_be.as<uint8_t>();
+    LaneHold H(ctx);
+    if (int rc = H.take()) return rc;
+    Lane& L = H.L();
+    HIPCHK(ctx, L.in_be.ensure(2 * n * 96));
+    HIPCHK(ctx, L.out_be.ensure(n * 96));
+    uint8_t* da = L.in_be.as<uint8_t>();
     uint8_t* db = da + n * 96;
-    HIPCHK(ctx, hipMemcpyAsync(da, a_be96, n * 96, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(db, b_be96, n * 96, hipMemcpyHostToDevice, ctx->stream));
-    k_test_g1<<<(uint32_t)((n + 255) / 256), 256, 0, ctx->stream>>>(op, da, db, ctx->out_be.as<uint8_t>(), n);
-    HIPCHK(ctx, hipMemcpyAsync(out_be96, ctx->out_be.p, n * 96, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(da, a_be96, n * 96, hipMemcpyHostToDevice, L.stream));
+    HIPCHK(ctx, hipMemcpyAsync(db, b_be96, n * 96, hipMemcpyHostToDevice, L.stream));
+    k_test_g1<<<(uint32_t)((n + 255) / 256), 256, 0, L.stream>>>(op, da, db, L.out_be.as<uint8_t>(), n);
+    HIPCHK(ctx, hipMemcpyAsync(out_be96, L.out_be.p, n * 96, hipMemcpyDeviceToHost, L.stream));
+    HIPCHK(ctx, hipStreamSynchronize(L.stream));
     HIPCHK(ctx, hipGetLastError());
+    H.clean = true;
     return KZG_OK;
 }
 

@@ -821,6 +821,26 @@ __global__ void __launch_bounds__(64) k_g1_sum(const g1_xyzz_t* __restrict__ in,
     if (tid == 0) store_xyzz(out, acc);
 }
 
+// sum of `count` affine points (table-row format: the output of k_srs_from_c48): Pianist's master aggregation
+// sum_i commit_i over the worker rows (reference neurons/validator.py:196-198, README.md:38)
+__global__ void __launch_bounds__(64) k_g1_sum_affine(const g1_affine_t* __restrict__ in, uint32_t count,
+                                                       g1_xyzz_t* __restrict__ out) {
+    tail_priority();
+    __shared__ g1_xyzz_t sm[64];
+    const uint32_t tid = threadIdx.x;
+    g1_xyzz_t acc;
+    g1_set_inf(acc);
+    for (uint32_t i = tid; i < count; i += 64) {
+        g1_aff28 q;
+        g1_load_aff(q, &in[i]);
+        g1_madd_checked(acc, q);
+    }
+    uint32_t lanes = 1;
+    while (lanes < count && lanes < 64) lanes <<= 1;
+    lds_tree_sum(sm, acc, tid, lanes);
+    if (tid == 0) store_xyzz(out, acc);
+}
+
 __global__ void __launch_bounds__(64) k_g1_compress(const g1_xyzz_t* __restrict__ in, uint8_t* __restrict__ out48) {
     tail_priority();
     if (threadIdx.x != 0) return;
@@ -1276,6 +1296,9 @@ void launch_msm_final(hipStream_t s, const g1_xyzz_t* node, const g1_xyzz_t* pre
 }
 void launch_g1_sum(hipStream_t s, const g1_xyzz_t* in, uint32_t count, g1_xyzz_t* out_xyzz) {
     k_g1_sum<<<1, 64, 0, s>>>(in, count, out_xyzz);
+}
+void launch_g1_sum_affine(hipStream_t s, const g1_affine_t* in, uint32_t count, g1_xyzz_t* out_xyzz) {
+    k_g1_sum_affine<<<1, 64, 0, s>>>(in, count, out_xyzz);
 }
 void launch_g1_compress(hipStream_t s, const g1_xyzz_t* in, uint8_t* out48) {
     k_g1_compress<<<1, 64, 0, s>>>(in, out48);

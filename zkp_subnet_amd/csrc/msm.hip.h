@@ -63,6 +63,8 @@ void launch_msm_final(hipStream_t s, const g1_xyzz_t* node, const g1_xyzz_t* pre
                       g1_xyzz_t* out_xyzz);
 // sum `count` XYZZ points (count <= 1024) into out_xyzz[0]
 void launch_g1_sum(hipStream_t s, const g1_xyzz_t* in, uint32_t count, g1_xyzz_t* out_xyzz);
+// sum `count` affine table-format points into out_xyzz[0]
+void launch_g1_sum_affine(hipStream_t s, const g1_affine_t* in, uint32_t count, g1_xyzz_t* out_xyzz);
 // affine + ZCash compression of one point
 void launch_g1_compress(hipStream_t s, const g1_xyzz_t* in, uint8_t* out48);
 // two points, one shared inversion

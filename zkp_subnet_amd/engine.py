@@ -6,7 +6,6 @@ methods to exercise the host logic on machines without a GPU."""
 from __future__ import annotations
 
 import ctypes
-import threading
 from typing import Dict, List, Optional, Sequence, Tuple
 
 from . import _native
@@ -44,7 +43,6 @@ class HipEngine:
         self.device = device
         self.scale = self.machines_scale = 0
         self.verifier = None          # host-side pairing verifier (zkp_subnet_amd.verifier.Verifier)
-        self._stage_lock = threading.Lock()   # one decoded polynomial at a time in the pinned staging buffer
         if window:
             self._chk(self._lib.kzg_set_window(self._h, window))
 
@@ -153,41 +151,54 @@ class HipEngine:
 
     # ---- the same three calls fed from the synapse's List[str] (reference neurons/miner.py:38-61): the text is decoded
     # by csrc/wire_py.c straight into the library's pinned staging buffer (no bytes object, no pageable bounce)
-    def _stage_poly(self, poly: Sequence[str]):
-        from . import codec
+    class _Staged:
+        """One pinned staging buffer of the library's pool holding the decoded polynomial; released on exit.  Concurrent
+        requests (the axon's worker threads) each hold their own buffer, so their decodes and GPU calls overlap."""
 
-        if codec._wire is None:
-            raise RuntimeError("zkp_subnet_amd._wire is not built: run `python -m zkp_subnet_amd.build`")
-        n = len(poly)
-        ptr = ctypes.c_void_p()
-        self._chk(self._lib.kzg_staging_buffer(self._h, 32 * max(n, 1), ctypes.byref(ptr)))
-        try:
-            got = codec._wire.decode_fr_list_into(poly, ptr.value, 32 * max(n, 1))
-        except ValueError as e:
-            raise codec.CodecError(str(e)) from e
-        assert got == n
-        return ctypes.cast(ptr, ctypes.c_char_p), n
+        def __init__(self, eng: "HipEngine", poly: Sequence[str]):
+            from . import codec
+
+            if codec._wire is None:
+                raise RuntimeError("zkp_subnet_amd._wire is not built: run `python -m zkp_subnet_amd.build`")
+            self.eng, self.n = eng, len(poly)
+            ptr, tok = ctypes.c_void_p(), ctypes.c_int(-1)
+            eng._chk(eng._lib.kzg_staging_acquire(eng._h, 32 * max(self.n, 1), ctypes.byref(ptr), ctypes.byref(tok)))
+            self.token = tok.value
+            try:
+                got = codec._wire.decode_fr_list_into(poly, ptr.value, 32 * max(self.n, 1))
+            except ValueError as e:
+                eng._lib.kzg_staging_release(eng._h, self.token)
+                raise codec.CodecError(str(e)) from e
+            except BaseException:
+                eng._lib.kzg_staging_release(eng._h, self.token)
+                raise
+            assert got == self.n
+            self.row = ctypes.cast(ptr, ctypes.c_char_p)
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            self.eng._lib.kzg_staging_release(self.eng._h, self.token)
+            return False
 
     def commit_list(self, i: int, poly: Sequence[str], evaluation_form: bool = True) -> bytes:
         out = ctypes.create_string_buffer(48)
-        with self._stage_lock:
-            row, n = self._stage_poly(poly)
-            self._chk(self._lib.kzg_commit(self._h, i, row, n, int(evaluation_form), out))
+        with HipEngine._Staged(self, poly) as st:
+            self._chk(self._lib.kzg_commit(self._h, i, st.row, st.n, int(evaluation_form), out))
         return out.raw
 
     def open_list(self, i: int, poly: Sequence[str], alpha_be32: bytes, evaluation_form: bool = True) -> Tuple[bytes, bytes]:
         ev, pf = ctypes.create_string_buffer(32), ctypes.create_string_buffer(48)
-        with self._stage_lock:
-            row, n = self._stage_poly(poly)
-            self._chk(self._lib.kzg_open(self._h, i, row, n, int(evaluation_form), alpha_be32, ev, pf))
+        with HipEngine._Staged(self, poly) as st:
+            self._chk(self._lib.kzg_open(self._h, i, st.row, st.n, int(evaluation_form), alpha_be32, ev, pf))
         return ev.raw, pf.raw
 
     def commit_open_list(self, i: int, poly: Sequence[str], alpha_be32: bytes,
                          evaluation_form: bool = True) -> Tuple[bytes, bytes, bytes]:
         c, ev, pf = ctypes.create_string_buffer(48), ctypes.create_string_buffer(32), ctypes.create_string_buffer(48)
-        with self._stage_lock:
-            row, n = self._stage_poly(poly)
-            self._chk(self._lib.kzg_commit_open(self._h, i, row, n, int(evaluation_form), alpha_be32, c, ev, pf))
+        with HipEngine._Staged(self, poly) as st:
+            self._chk(self._lib.kzg_commit_open(self._h, i, st.row, st.n, int(evaluation_form), alpha_be32, c, ev, pf))
         return c.raw, ev.raw, pf.raw
 
     def msm(self, scalars_be32: bytes, srs_offset: int = 0) -> bytes:
@@ -204,6 +215,16 @@ class HipEngine:
         out = ctypes.create_string_buffer(48)
         self._chk(self._lib.kzg_g1_sum(self._h, partials_xyzz192, len(partials_xyzz192) // 192, out))
         return out.raw
+
+    def g1_sum_compressed(self, points_c48: bytes) -> bytes:
+        """Sum of 48-byte compressed G1 points (Pianist master aggregation sum_i commit_i) -> 48 bytes."""
+        out = ctypes.create_string_buffer(48)
+        self._chk(self._lib.kzg_g1_sum_compressed(self._h, points_c48, len(points_c48) // 48, out))
+        return out.raw
+
+    def set_host_finish(self, enable: bool) -> None:
+        """True (default): the result point's affine conversion + compression run on the host; False: on the GPU."""
+        self._chk(self._lib.kzg_set_host_finish(self._h, int(enable)))
 
     def ntt(self, vals_be32: bytes, inverse: bool) -> bytes:
         buf = ctypes.create_string_buffer(vals_be32, len(vals_be32))
