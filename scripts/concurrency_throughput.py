@@ -29,7 +29,7 @@ for lg in sizes:
             want.append(r.json())
     reps = 24 if lg <= 16 else 8
     out = {"log2_T": lg}
-    for threads in (1, 2, 4):
+    for threads in (4, 1, 2, 4):          # the first pass (4 threads) only warms every lane's workspace
         bad = []
 
         def work(tid):
