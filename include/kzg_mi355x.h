@@ -179,7 +179,8 @@ int kzg_b64_encode_fr(const uint8_t* be32, uint64_t n, char* out_packed43);
 /* ---- unit-op hooks for the parity tests (tests/test_gpu_parity.py); not part of the serving surface */
 int kzg_test_field(kzg_ctx* ctx, int field /*0 Fp,1 Fr*/, int op /*0 mul,1 add,2 sub,3 mul(plain C ref),4 sqr*/,
                    const uint8_t* a_be, const uint8_t* b_be, uint8_t* out_be, uint64_t n);
-int kzg_test_g1(kzg_ctx* ctx, int op /*0 a+b mixed,1 2a+b full,2 2a,3 4a,4 a+20a+20b chain*/, const uint8_t* a_be96,
+int kzg_test_g1(kzg_ctx* ctx, int op /*0 a+b mixed,1 2a+b full,2 2a,3 4a,4 a+20a+20b chain; lane-parallel forms: 5 2a+b,
+                                         6 4a, 7 ten rounds r <- 2r+b from a*/, const uint8_t* a_be96,
                 const uint8_t* b_be96, uint8_t* out_be96, uint64_t n);
 
 #ifdef __cplusplus

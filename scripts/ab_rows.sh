@@ -1,0 +1,17 @@
+#!/bin/bash
+# Same-box A/B of two library builds on the commit+open rows and the headline MSM (see scripts/ab_bench.sh).
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+ROUNDS=${1:-2}
+cp zkp_subnet_amd/libkzg_mi355x.so /tmp/_orig.so
+for r in $(seq $ROUNDS); do
+  for v in A B; do
+    cp zkp_subnet_amd/ab/$v.so zkp_subnet_amd/libkzg_mi355x.so
+    python bench.py --no-adversarial --no-cpu-baseline --no-pipelined --steps 20 --kzg-rows 22,20,16,12 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+s=d['stages_ms']
+print('$v msm20 %.3f ms  acc %.3f tree %.3f final %.3f digits %.3f |' % (d['ms_per_step'], s['accumulate'], s['tree'], s['final'], s['digits']), ' '.join('%s %.3f (tree %.3f final %.3f)' % (k, v['ms'], v['stages_ms_profiled_serial']['tree'], v['stages_ms_profiled_serial']['final']) for k, v in d['kzg_commit_open'].items()))
+"
+  done
+done
+cp /tmp/_orig.so zkp_subnet_amd/libkzg_mi355x.so

@@ -72,6 +72,8 @@ def test_g1_ops_bit_exact_including_exceptional_cases(hip):
     pb[2] = None
     pa[3] = None
     pa[4] = pb[4] = None
+    pb[5] = o.g1_add(pa[5], pa[5])            # 2a + b with b == 2a: equal points inside a FULL addition (ops 1, 5)
+    pb[6] = o.g1_neg(o.g1_add(pa[6], pa[6]))  # 2a + (-2a) = infinity
     a = b"".join(o.g1_to_be96(p) for p in pa)
     b = b"".join(o.g1_to_be96(p) for p in pb)
     def chain(x, y):                      # a, then 40 alternating mixed adds of b, a, b, a ...
@@ -80,9 +82,16 @@ def test_g1_ops_bit_exact_including_exceptional_cases(hip):
             r = o.g1_add(r, x if k & 1 else y)
         return r
 
+    def chain_lp(x, y):                   # ten rounds r <- 2r + b from a (lane-parallel doubling / addition)
+        r = x
+        for _ in range(10):
+            r = o.g1_add(o.g1_add(r, r), y)
+        return r
+
     exp = {0: lambda x, y: o.g1_add(x, y), 1: lambda x, y: o.g1_add(o.g1_add(x, x), y),
-           2: lambda x, y: o.g1_add(x, x), 3: lambda x, y: o.g1_mul(x, 4) if x else None, 4: chain}
-    for op in range(5):
+           2: lambda x, y: o.g1_add(x, x), 3: lambda x, y: o.g1_mul(x, 4) if x else None, 4: chain,
+           5: lambda x, y: o.g1_add(o.g1_add(x, x), y), 6: lambda x, y: o.g1_mul(x, 4) if x else None, 7: chain_lp}
+    for op in range(8):
         out = eng.test_g1(op, a, b)
         assert out == b"".join(o.g1_to_be96(exp[op](x, y)) for x, y in zip(pa, pb)), f"g1 op {op}"
 

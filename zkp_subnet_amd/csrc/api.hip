@@ -16,6 +16,7 @@
 #include "../../include/kzg_mi355x.h"
 #include "fr_kernels.hip.h"
 #include "msm.hip.h"
+#include "fp_lp.hip.h"
 
 #define KZG_VERSION "kzg_mi355x 0.2 (gfx950)"
 #define N_SLOTS 4
@@ -377,9 +378,10 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
     HIPCHK(ctx, L.sorted.ensure(entries * 4));
     HIPCHK(ctx, L.hist.ensure(16384 * 4));
     HIPCHK(ctx, L.offsets.ensure((B + 1) * 4));
-    HIPCHK(ctx, L.bufA.ensure(B * sizeof(g1_xyzz_t)));
-    HIPCHK(ctx, L.bufB.ensure(B * sizeof(g1_xyzz_t) / 2 + 4096));   // level arrays: n/2^L nodes x L components <= B/2
-    HIPCHK(ctx, L.bufC.ensure(B * sizeof(g1_xyzz_t) / 2 + 4096));
+    // (+ 16 KB each: whichever buffer is free after the last level also holds the 2 x 32 doubled components of the final)
+    HIPCHK(ctx, L.bufA.ensure(B * sizeof(g1_xyzz_t) + 16384));
+    HIPCHK(ctx, L.bufB.ensure(B * sizeof(g1_xyzz_t) / 2 + 16384));  // level arrays: n/2^L nodes x L components <= B/2
+    HIPCHK(ctx, L.bufC.ensure(B * sizeof(g1_xyzz_t) / 2 + 16384));
     HIPCHK(ctx, L.carries.ensure((size_t)nchunks * sizeof(g1_xyzz_t)));
     HIPCHK(ctx, L.carry_key.ensure((size_t)nchunks * 4));
     uint32_t* max_len_d = L.flags() + 2;
@@ -427,7 +429,8 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
     }
     {
         Span sp(ctx, L, KZG_T_FINAL);
-        launch_msm_final(s, in, prev, ctx->c - 1, nbatch, out_xyzz);
+        // `out` (the buffer the last level did not write and no longer reads) holds the doubled components in between
+        launch_msm_final(s, in, prev, ctx->c - 1, nbatch, out_xyzz, out);
     }
     HIPCHK(ctx, hipGetLastError());
     return KZG_OK;
@@ -712,6 +715,45 @@ __global__ void __launch_bounds__(256) k_test_g1(int op, const uint8_t* a_be, co
     g1_to_aff(o, r);
     fp_to_be48(out_be + 96 * j, o.x);
     fp_to_be48(out_be + 96 * j + 48, o.y);
+}
+
+// lane-parallel point operations (fp_lp.hip.h), one wave per element: op 5 = 2a + b (full addition of two XYZZ points),
+// 6 = 2 * (2a), 7 = ten rounds of r <- 2r + b starting from a (class invariants across a long dependent chain)
+__global__ void __launch_bounds__(64) k_test_g1_lp(int op, const uint8_t* a_be, const uint8_t* b_be, uint8_t* out_be) {
+    __shared__ LpScratch sm;
+    __shared__ g1_xyzz_t pa, pb, r;
+    const uint64_t j = blockIdx.x;
+    const LpLane k = lp_lane();
+    if (threadIdx.x == 0) {
+        g1_aff28 a, b;
+        fp_from_be48(a.x, a_be + 96 * j); fp_from_be48(a.y, a_be + 96 * j + 48);
+        fp_from_be48(b.x, b_be + 96 * j); fp_from_be48(b.y, b_be + 96 * j + 48);
+        g1_xyzz_t ta, tb, t2;
+        g1_from_aff(ta, a);
+        g1_from_aff(tb, b);
+        g1_dbl(t2, ta);
+        store_xyzz(&pa, op == 7 ? ta : t2);
+        store_xyzz(&pb, tb);
+    }
+    __syncthreads();
+    if (op == 5) lp_add(sm, &r, &pa, &pb, k);
+    else if (op == 6) lp_dbl(sm, &r, &pa, k);
+    else {
+        for (int it = 0; it < 10; it++) {
+            lp_dbl(sm, &pa, &pa, k);
+            lp_add(sm, &pa, &pa, &pb, k);
+        }
+        if (threadIdx.x < 56) reinterpret_cast<uint32_t*>(&r)[threadIdx.x] = reinterpret_cast<uint32_t*>(&pa)[threadIdx.x];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        g1_xyzz_t v;
+        load_xyzz(v, &r);
+        g1_aff28 o;
+        g1_to_aff(o, v);
+        fp_to_be48(out_be + 96 * j, o.x);
+        fp_to_be48(out_be + 96 * j + 48, o.y);
+    }
 }
 
 const char B64[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
@@ -1434,7 +1476,8 @@ int kzg_test_g1(kzg_ctx* ctx, int op, const uint8_t* a_be96, const uint8_t* b_be
     uint8_t* db = da + n * 96;
     HIPCHK(ctx, hipMemcpyAsync(da, a_be96, n * 96, hipMemcpyHostToDevice, L.stream));
     HIPCHK(ctx, hipMemcpyAsync(db, b_be96, n * 96, hipMemcpyHostToDevice, L.stream));
-    k_test_g1<<<(uint32_t)((n + 255) / 256), 256, 0, L.stream>>>(op, da, db, L.out_be.as<uint8_t>(), n);
+    if (op >= 5) k_test_g1_lp<<<(uint32_t)n, 64, 0, L.stream>>>(op, da, db, L.out_be.as<uint8_t>());
+    else k_test_g1<<<(uint32_t)((n + 255) / 256), 256, 0, L.stream>>>(op, da, db, L.out_be.as<uint8_t>(), n);
     HIPCHK(ctx, hipMemcpyAsync(out_be96, L.out_be.p, n * 96, hipMemcpyDeviceToHost, L.stream));
     HIPCHK(ctx, hipStreamSynchronize(L.stream));
     HIPCHK(ctx, hipGetLastError());

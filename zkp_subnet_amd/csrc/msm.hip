@@ -2,6 +2,7 @@
 // path (reference neurons/miner.py:39,48 only calls the external prover); the algorithm is restated from the
 // published bucket method and checked bit-for-bit against oracle/ in tests/test_gpu_*.py.
 #include "msm.hip.h"
+#include "fp_lp.hip.h"
 
 #define NONE_KEY 0xffffffffu
 
@@ -755,6 +756,65 @@ __global__ void __launch_bounds__(256) k_msm_tree_level_coop(const g1_xyzz_t* __
     coop_add(sm, &out[(uint64_t)k * n_out + m], pa, pb, active);
 }
 
+// ---- lane-parallel forms (fp_lp.hip.h): ONE wave per point operation, for phases with at most LP_MAX_OPS operations.
+// Workgroups are single waves: every wave is a dependent instruction chain that owns its SIMD's issue port, so the
+// operations must spread over as many SIMDs as possible (4 waves of one 256-thread workgroup would share one CU).
+__global__ void __launch_bounds__(64) k_msm_tree_level_lp(const g1_xyzz_t* __restrict__ in,
+                                                           const g1_xyzz_t* __restrict__ prev,
+                                                           g1_xyzz_t* __restrict__ out, uint32_t n_in, int level) {
+    tail_priority();
+    __shared__ LpScratch sm;
+    const LpLane k = lp_lane();
+    const uint32_t n_out = n_in >> 1;
+    const uint32_t gid = blockIdx.x;
+    const uint32_t c = gid / n_out, m = gid - c * n_out;
+    const g1_xyzz_t *pa, *pb;
+    tree_operands(in, prev, n_in, level, c, m, pa, pb);
+    lp_add(sm, &out[(uint64_t)c * n_out + m], pa, pb, k);
+}
+// P + sum_i 2^i T_i for `nodes` roots, two launches.  (1) k_msm_final_dbl_lp: one wave per (root m, component l):
+// pts[m][l] = 2^l T_l (l doublings; the P entry, index nbits, is copied) -- the chains run on different SIMDs, the
+// longest (nbits - 1 doublings, ~1.4 us each) sets the time.  (2) k_msm_final_sum_lp: tree sum of the nbits + 1 points of
+// a root, one wave per addition, one 512-thread workgroup per root.
+#define FINAL_PTS 32
+__global__ void __launch_bounds__(64) k_msm_final_dbl_lp(const g1_xyzz_t* __restrict__ node,
+                                                          const g1_xyzz_t* __restrict__ prev, int nbits, int nodes,
+                                                          g1_xyzz_t* __restrict__ pts) {
+    tail_priority();
+    __shared__ LpScratch sm;
+    __shared__ g1_xyzz_t v;
+    const LpLane k = lp_lane();
+    const int l = (int)(blockIdx.x % (uint32_t)(nbits + 1));
+    const uint32_t m = blockIdx.x / (uint32_t)(nbits + 1);
+    const g1_xyzz_t* src = l < nbits - 1 ? &node[(uint64_t)(1 + l) * nodes + m] : l == nbits - 1 ? &prev[2 * m + 1] : &node[m];
+    if (threadIdx.x < 56) reinterpret_cast<uint32_t*>(&v)[threadIdx.x] = reinterpret_cast<const uint32_t*>(src)[threadIdx.x];
+    __syncthreads();
+    if (l < nbits)
+        for (int s = 0; s < l; s++) lp_dbl(sm, &v, &v, k);
+    __syncthreads();
+    if (threadIdx.x < 56)
+        reinterpret_cast<uint32_t*>(&pts[(uint64_t)m * FINAL_PTS + l])[threadIdx.x] = reinterpret_cast<const uint32_t*>(&v)[threadIdx.x];
+}
+__global__ void __launch_bounds__(512) k_msm_final_sum_lp(const g1_xyzz_t* __restrict__ pts_g, int nbits,
+                                                           g1_xyzz_t* __restrict__ out) {
+    tail_priority();
+    __shared__ LpScratch sm[8];
+    __shared__ g1_xyzz_t pts[FINAL_PTS];
+    const LpLane k = lp_lane();
+    const int w = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t m = blockIdx.x;
+    const int count = nbits + 1;  // <= 23
+    for (uint32_t i = threadIdx.x; i < (uint32_t)count * 56; i += 512)
+        reinterpret_cast<uint32_t*>(pts)[i] = reinterpret_cast<const uint32_t*>(pts_g + (uint64_t)m * FINAL_PTS)[i];
+    __syncthreads();
+    for (int d = 16; d >= 1; d >>= 1) {
+        for (int l = w; l < d; l += 8)
+            if (l + d < count) lp_add(sm[w], &pts[l], &pts[l], &pts[l + d], k);
+        __syncthreads();
+    }
+    if (threadIdx.x < 56) reinterpret_cast<uint32_t*>(&out[m])[threadIdx.x] = reinterpret_cast<const uint32_t*>(&pts[0])[threadIdx.x];
+}
+
 // sum of the values held by lanes [0, nthreads) (power of two <= blockDim), result in every lane's `mine`
 KZG_DEV void lds_tree_sum(g1_xyzz_t* sm, g1_xyzz_t& mine, uint32_t tid, uint32_t nthreads) {
     store_xyzz(&sm[tid], mine);
@@ -1287,12 +1347,22 @@ void launch_msm_tree_level(hipStream_t s, const g1_xyzz_t* in, const g1_xyzz_t* 
                            uint32_t n_in_nodes, int level) {
     uint32_t ops = (n_in_nodes >> 1) * (uint32_t)(level + 1);
     // wide levels are throughput-bound (one lane per addition); narrow ones are latency-bound (4 waves per addition)
+    // ... and the narrowest ones, where even that leaves the chip empty, run one WAVE per addition (fp_lp.hip.h)
     if (ops > 32768) k_msm_tree_level<<<nblk(ops, 256), 256, 0, s>>>(in, prev, out, n_in_nodes, level);
+#ifndef KZG_NO_LP
+    else if (ops <= LP_MAX_OPS) k_msm_tree_level_lp<<<ops, 64, 0, s>>>(in, prev, out, n_in_nodes, level);
+#endif
     else k_msm_tree_level_coop<<<nblk(ops, 64), 256, 0, s>>>(in, prev, out, n_in_nodes, level);
 }
 void launch_msm_final(hipStream_t s, const g1_xyzz_t* node, const g1_xyzz_t* prev, int nbits, int nodes,
-                      g1_xyzz_t* out_xyzz) {
+                      g1_xyzz_t* out_xyzz, g1_xyzz_t* scratch) {
+#ifndef KZG_NO_LP
+    k_msm_final_dbl_lp<<<nodes * (nbits + 1), 64, 0, s>>>(node, prev, nbits, nodes, scratch);
+    k_msm_final_sum_lp<<<nodes, 512, 0, s>>>(scratch, nbits, out_xyzz);
+#else
+    (void)scratch;
     k_msm_final<<<nodes, 256, 0, s>>>(node, prev, nbits, nodes, out_xyzz);
+#endif
 }
 void launch_g1_sum(hipStream_t s, const g1_xyzz_t* in, uint32_t count, g1_xyzz_t* out_xyzz) {
     k_g1_sum<<<1, 64, 0, s>>>(in, count, out_xyzz);

@@ -59,8 +59,9 @@ void launch_msm_tree_level(hipStream_t s, const g1_xyzz_t* in, const g1_xyzz_t* 
 // node = [P, T_0 .. T_{nbits-1}] ; out_xyzz = P + sum 2^i T_i
 // nodes: the bucket tree stopped at `nodes` roots (component-major: component k of root m at node[k * nodes + m];
 // T_{nbits-1} of root m is P[2m + 1] of the level below, `prev`); out_xyzz[m] = P_m + sum_i 2^i T_{i,m}
+// scratch: nodes * 32 XYZZ points (the doubled components between the two launches of the lane-parallel form)
 void launch_msm_final(hipStream_t s, const g1_xyzz_t* node, const g1_xyzz_t* prev, int nbits, int nodes,
-                      g1_xyzz_t* out_xyzz);
+                      g1_xyzz_t* out_xyzz, g1_xyzz_t* scratch);
 // sum `count` XYZZ points (count <= 1024) into out_xyzz[0]
 void launch_g1_sum(hipStream_t s, const g1_xyzz_t* in, uint32_t count, g1_xyzz_t* out_xyzz);
 // sum `count` affine table-format points into out_xyzz[0]
