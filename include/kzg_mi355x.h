@@ -183,6 +183,11 @@ int kzg_test_g1(kzg_ctx* ctx, int op /*0 a+b mixed,1 2a+b full,2 2a,3 4a,4 a+20a
                                          6 4a, 7 ten rounds r <- 2r+b from a*/, const uint8_t* a_be96,
                 const uint8_t* b_be96, uint8_t* out_be96, uint64_t n);
 
+/* ---- prototype measurement hook (zkp_subnet_amd/csrc/baff_proto.hip, scripts/proto_baff.py): times k_msm_accumulate and
+ *      three batched-affine pairwise-addition rounds on the same sorted entries.  Not part of the serving surface. */
+int kzg_proto_baff(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint32_t lanes, float out_ms[8],
+                   uint32_t out_counts[8]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,7 @@ SYMBOLS = {
     "kzg_set_profiling": (_I, [_P, _I]),
     "kzg_get_timings": (_I, [_P, ctypes.POINTER(ctypes.c_float), _I]),
     "kzg_msm_plan": (_I, [_P, _U64, ctypes.POINTER(ctypes.c_int32)]),
+    "kzg_proto_baff": (_I, [_P, _I, _U64, _U64, _U32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_U32)]),
     "kzg_b64_decode_fr": (_I, [_B, _U64, _B]),
     "kzg_b64_encode_fr": (_I, [_B, _U64, _B]),
     "kzg_test_field": (_I, [_P, _I, _I, _B, _B, _B, _U64]),

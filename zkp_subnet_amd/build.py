@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libkzg_mi355x.so")
-SOURCES = ["msm.hip", "fr_kernels.hip", "api.hip", "pairing_host.cpp", "finish_host.cpp"]
+SOURCES = ["msm.hip", "fr_kernels.hip", "api.hip", "baff_proto.hip", "pairing_host.cpp", "finish_host.cpp"]
 HEADERS = ["bigint.hip.h", "field.hip.h", "fp28.hip.h", "g1.hip.h", "msm.hip.h", "fr_kernels.hip.h", "fp_lp.hip.h", "fp_host.h",
            "../../include/kzg_mi355x.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]

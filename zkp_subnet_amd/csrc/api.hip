@@ -1391,6 +1391,82 @@ int kzg_msm_plan(kzg_ctx* ctx, uint64_t n, int32_t out[4]) {
     out[3] = ctx->nwin;
     return KZG_OK;
 }
+// ---- PROTOTYPE measurement hook (csrc/baff_proto.hip; not part of the serving surface): sorts the digits of the slot's
+// scalars exactly as an MSM does, then times (HIP events) k_msm_accumulate and three batched-affine pairwise rounds on
+// the SAME sorted entries.  out_ms: [0] sort, [1] k_msm_accumulate, [2..4] batched-affine rounds 1..3;
+// out_counts: [0] entries, [1..3] pairs per round, [4..6] mismatches against the XYZZ formulas (sampled), [7] pairs
+// with equal x (skipped by the prototype).
+int kzg_proto_baff(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint32_t lanes, float out_ms[8],
+                   uint32_t out_counts[8]) {
+    if (!ctx || !out_ms || !out_counts || slot < 0 || slot >= N_SLOTS || !lanes) return KZG_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    LaneHold H(ctx);
+    if (int rc = H.take()) return rc;
+    Lane& L = H.L();
+    int rc = need_srs(ctx);
+    if (rc) return rc;
+    if (n > ctx->slot_n[slot] || srs_offset + n > ctx->stride) return fail(ctx, KZG_E_ARG, "range");
+    hipStream_t s = L.stream;
+    const uint64_t entries_max = n * (uint64_t)ctx->nwin;
+    MsmShape sh;
+    sh.c = ctx->c; sh.nwin = ctx->nwin; sh.lay = ctx->lay; sh.nbuckets = ctx->nbuckets; sh.n = n; sh.nbatch = 1;
+    sh.srs_offset = srs_offset; sh.srs_stride = ctx->stride; sh.chunk = pick_chunk(entries_max);
+    const uint32_t nchunks = (uint32_t)((entries_max + sh.chunk - 1) / sh.chunk);
+    const size_t B = sh.nbuckets;
+    HIPCHK(ctx, L.rank.ensure(entries_max * 8));
+    HIPCHK(ctx, L.sorted.ensure(entries_max * 4 + 64));
+    HIPCHK(ctx, L.hist.ensure(16384 * 4));
+    HIPCHK(ctx, L.offsets.ensure((B + 1) * 4));
+    HIPCHK(ctx, L.bufA.ensure(B * sizeof(g1_xyzz_t) + 16384));
+    HIPCHK(ctx, L.carries.ensure((size_t)nchunks * sizeof(g1_xyzz_t)));
+    HIPCHK(ctx, L.carry_key.ensure((size_t)nchunks * 4));
+    DevBuf prefix, o1, o2, o3, cnt;
+    HIPCHK(ctx, prefix.ensure((entries_max / 2 + 1) * 64));
+    HIPCHK(ctx, o1.ensure((entries_max / 2 + 1) * sizeof(g1_affine_t)));
+    HIPCHK(ctx, o2.ensure((entries_max / 4 + 1) * sizeof(g1_affine_t)));
+    HIPCHK(ctx, o3.ensure((entries_max / 8 + 1) * sizeof(g1_affine_t)));
+    HIPCHK(ctx, cnt.ensure(64));
+    HIPCHK(ctx, hipMemsetAsync(cnt.p, 0, 64, s));
+    hipEvent_t ev[8];
+    for (auto& e : ev) HIPCHK(ctx, hipEventCreate(&e));
+    HIPCHK(ctx, hipMemsetAsync(L.bufA.p, 0, B * sizeof(g1_xyzz_t), s));
+    HIPCHK(ctx, hipEventRecord(ev[0], s));
+    launch_msm_sort(s, sh, ctx->slot[slot].as<uint32_t>(), ctx->slot_mont[slot], nullptr, 0, L.hist.as<uint32_t>(),
+                    L.rank.as<uint2>(), L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>());
+    HIPCHK(ctx, hipEventRecord(ev[1], s));
+    uint32_t entries = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&entries, L.offsets.as<uint32_t>() + B, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    HIPCHK(ctx, hipEventRecord(ev[2], s));
+    launch_msm_accumulate(s, sh, ctx->table.as<g1_affine_t>(), L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(),
+                          L.bufA.as<g1_xyzz_t>(), L.carries.as<g1_xyzz_t>(), L.carry_key.as<uint32_t>(), nchunks);
+    HIPCHK(ctx, hipEventRecord(ev[3], s));
+    const uint32_t np1 = entries / 2, np2 = np1 / 2, np3 = np2 / 2;
+    uint32_t* c = cnt.as<uint32_t>();
+    launch_baff_round(s, ctx->table.as<g1_affine_t>(), L.sorted.as<uint32_t>(), np1, lanes, prefix.p, o1.as<g1_affine_t>(), c + 7);
+    HIPCHK(ctx, hipEventRecord(ev[4], s));
+    launch_baff_round(s, o1.as<g1_affine_t>(), nullptr, np2, lanes, prefix.p, o2.as<g1_affine_t>(), c + 7);
+    HIPCHK(ctx, hipEventRecord(ev[5], s));
+    launch_baff_round(s, o2.as<g1_affine_t>(), nullptr, np3, lanes, prefix.p, o3.as<g1_affine_t>(), c + 7);
+    HIPCHK(ctx, hipEventRecord(ev[6], s));
+    launch_baff_check(s, ctx->table.as<g1_affine_t>(), L.sorted.as<uint32_t>(), np1, 997, o1.as<g1_affine_t>(), c + 4);
+    launch_baff_check(s, o1.as<g1_affine_t>(), nullptr, np2, 499, o2.as<g1_affine_t>(), c + 5);
+    launch_baff_check(s, o2.as<g1_affine_t>(), nullptr, np3, 251, o3.as<g1_affine_t>(), c + 6);
+    HIPCHK(ctx, hipMemcpyAsync(out_counts, c, 32, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    HIPCHK(ctx, hipGetLastError());
+    for (int i = 0; i < 8; i++) out_ms[i] = 0.f;
+    (void)hipEventElapsedTime(&out_ms[0], ev[0], ev[1]);
+    (void)hipEventElapsedTime(&out_ms[1], ev[2], ev[3]);
+    (void)hipEventElapsedTime(&out_ms[2], ev[3], ev[4]);
+    (void)hipEventElapsedTime(&out_ms[3], ev[4], ev[5]);
+    (void)hipEventElapsedTime(&out_ms[4], ev[5], ev[6]);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    out_counts[0] = entries; out_counts[1] = np1; out_counts[2] = np2; out_counts[3] = np3;
+    H.clean = true;
+    return KZG_OK;
+}
+
 // test hooks for the host-side encoder (finish_host.cpp): no GPU involved
 int kzg_host_xyzz_to_c48(const uint32_t xyzz_limbs28[56], uint8_t out48[48]) {
     if (!xyzz_limbs28 || !out48) return KZG_E_ARG;

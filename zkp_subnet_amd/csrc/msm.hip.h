@@ -86,3 +86,9 @@ void launch_srs_precompute(hipStream_t s, g1_affine_t* table, uint64_t stride, u
 // (global index j_base + j); gtab: 32*255 affine scratch (built when build_gtab); tmp: count XYZZ + count*32 B
 void launch_srs_generate(hipStream_t s, g1_affine_t* out, uint64_t count, uint64_t j_base, const uint32_t* tau_mont,
                          const uint32_t* s0_mont, g1_affine_t* gtab, g1_xyzz_t* tmp, bool build_gtab);
+
+// PROTOTYPE (csrc/baff_proto.hip): batched-affine pairwise addition rounds, measured against k_msm_accumulate
+void launch_baff_round(hipStream_t s, const g1_affine_t* table, const uint32_t* idx, uint32_t npairs, uint32_t lanes,
+                       void* prefix, g1_affine_t* out, uint32_t* n_equal_x);
+void launch_baff_check(hipStream_t s, const g1_affine_t* table, const uint32_t* idx, uint32_t npairs, uint32_t stride,
+                       const g1_affine_t* out, uint32_t* bad);
