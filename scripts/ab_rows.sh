@@ -10,7 +10,7 @@ for r in $(seq $ROUNDS); do
 import json,sys
 d=json.loads(sys.stdin.read())
 s=d['stages_ms']
-print('$v msm20 %.3f ms  acc %.3f tree %.3f final %.3f digits %.3f |' % (d['ms_per_step'], s['accumulate'], s['tree'], s['final'], s['digits']), ' '.join('%s %.3f (tree %.3f final %.3f)' % (k, v['ms'], v['stages_ms_profiled_serial']['tree'], v['stages_ms_profiled_serial']['final']) for k, v in d['kzg_commit_open'].items()))
+print('$v msm20 %.3f ms  acc %.3f tree %.3f final %.3f digits %.3f |' % (d['ms_per_step'], s['accumulate'], s['tree'], s['final'], s['digits']), ' '.join('%s %.3f (ntt %.3f poly %.3f dig %.3f fix %.3f tree %.3f fin %.3f)' % (k, v['ms'], v['stages_ms_profiled_serial']['ntt'], v['stages_ms_profiled_serial']['poly'], v['stages_ms_profiled_serial']['digits'], v['stages_ms_profiled_serial']['fixup'], v['stages_ms_profiled_serial']['tree'], v['stages_ms_profiled_serial']['final']) for k, v in d['kzg_commit_open'].items()))
 "
   done
 done

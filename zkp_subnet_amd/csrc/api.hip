@@ -576,8 +576,8 @@ int commit_open_dev(kzg_ctx* ctx, LaneHold& H, uint32_t i, const uint32_t* row_d
         HIPCHK(ctx, hipMemcpyAsync(A.tail + TB_ALPHA_BE, alpha_be32, 32, hipMemcpyHostToDevice, so));
         launch_fr_from_be(so, A.tail + TB_ALPHA_BE, alpha_m, 1, 1, A.flags());
         const uint64_t nchunks = (T + 3) / 4;
-        HIPCHK(ctx, O.hbuf.ensure((nchunks + (nchunks >> 3) + 64) * 32));
-        HIPCHK(ctx, O.hnext.ensure((nchunks + (nchunks >> 3) + 64) * 32));
+        HIPCHK(ctx, O.hbuf.ensure((nchunks + (nchunks >> 1) + 64) * 32));
+        HIPCHK(ctx, O.hnext.ensure((nchunks + (nchunks >> 1) + 64) * 32));
         HIPCHK(ctx, O.qbuf.ensure(T * 32));
         {
             Span sp(ctx, A, KZG_T_POLY, so);
@@ -1146,8 +1146,8 @@ int kzg_eval(kzg_ctx* ctx, const uint8_t* coeffs_be32, uint64_t n, const uint8_t
     if (rc) return rc;
     HIPCHK(ctx, L.coeffA.ensure(n * 32));
     const uint64_t nchunks = (n + 3) / 4;
-    HIPCHK(ctx, L.hbuf.ensure((nchunks + (nchunks >> 3) + 64) * 32));
-    HIPCHK(ctx, L.hnext.ensure((nchunks + (nchunks >> 3) + 64) * 32));
+    HIPCHK(ctx, L.hbuf.ensure((nchunks + (nchunks >> 1) + 64) * 32));
+    HIPCHK(ctx, L.hnext.ensure((nchunks + (nchunks >> 1) + 64) * 32));
     rc = upload_fr(ctx, L, coeffs_be32, n, L.coeffA.as<uint32_t>(), 1);
     if (rc) return rc;
     uint32_t* x_m = reinterpret_cast<uint32_t*>(L.tail + TB_ALPHA_M);

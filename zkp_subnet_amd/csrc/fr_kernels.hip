@@ -113,7 +113,8 @@ __global__ void k_fr_inv_pow2(uint32_t* __restrict__ out, int log_n) {
 #define NTT_TILE_ELEMS 1024 // rows x columns
 KZG_DEV uint32_t brev_bits(uint32_t v, int bits) { return bits ? (__brev(v) >> (32 - bits)) : 0u; }
 
-__global__ void __launch_bounds__(256) k_fr_ntt_pass(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+template <uint32_t NT_>
+__global__ void __launch_bounds__(NT_) k_fr_ntt_pass(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                       int log_n, int s0, int S, int logC,
                                                       const uint32_t* __restrict__ tw,
                                                       const uint32_t* __restrict__ scale_or_null) {
@@ -125,7 +126,7 @@ __global__ void __launch_bounds__(256) k_fr_ntt_pass(const uint32_t* __restrict_
     if (first) {
         const uint64_t NT = (uint64_t)1 << log_nt;
         const uint64_t u = blockIdx.x;
-        for (uint32_t e = threadIdx.x; e < E; e += 256) {
+        for (uint32_t e = threadIdx.x; e < E; e += NT_) {
             const uint32_t rp = e >> logC, c = e & (C - 1);  // source row, tile
             const uint4* src = reinterpret_cast<const uint4*>(in + 8 * ((uint64_t)rp * NT + u * C + c));
             const uint32_t slot = (c << S) + brev_bits(rp, S);  // LDS layout [tile][row]
@@ -136,7 +137,7 @@ __global__ void __launch_bounds__(256) k_fr_ntt_pass(const uint32_t* __restrict_
         const uint64_t groups = ((uint64_t)1 << s0) >> logC;  // column groups per block of 2^(s0+S) elements
         const uint64_t h = blockIdx.x / groups, cg = blockIdx.x - h * groups;
         const uint64_t base = (h << (s0 + S)) + (cg << logC);
-        for (uint32_t e = threadIdx.x; e < E; e += 256) {
+        for (uint32_t e = threadIdx.x; e < E; e += NT_) {
             const uint32_t r = e >> logC, c = e & (C - 1);
             const uint4* src = reinterpret_cast<const uint4*>(out + 8 * (base + ((uint64_t)r << s0) + c));
             sm[2 * e] = src[0];  // LDS layout [row][column]
@@ -149,7 +150,7 @@ __global__ void __launch_bounds__(256) k_fr_ntt_pass(const uint32_t* __restrict_
     for (int l = 0; l < S; l++) {
         const uint32_t half = 1u << l;
         const int s = s0 + l;
-        for (uint32_t b = threadIdx.x; b < E / 2; b += 256) {
+        for (uint32_t b = threadIdx.x; b < E / 2; b += NT_) {
             uint32_t ei, ej;
             uint64_t k;
             if (first) {
@@ -186,7 +187,7 @@ __global__ void __launch_bounds__(256) k_fr_ntt_pass(const uint32_t* __restrict_
         const uint32_t u = blockIdx.x;
         const uint64_t tiles_per_c = ((uint64_t)1 << log_nt) >> logC;
         const uint64_t t_low = brev_bits(u, log_nt - logC);
-        for (uint32_t e = threadIdx.x; e < E; e += 256) {
+        for (uint32_t e = threadIdx.x; e < E; e += NT_) {
             const uint32_t c = e >> S, r = e & (R - 1);
             const uint64_t t = (uint64_t)brev_bits(c, logC) * tiles_per_c + t_low;
             fr_t v;
@@ -198,7 +199,7 @@ __global__ void __launch_bounds__(256) k_fr_ntt_pass(const uint32_t* __restrict_
         const uint64_t groups = ((uint64_t)1 << s0) >> logC;
         const uint64_t h = blockIdx.x / groups, cg = blockIdx.x - h * groups;
         const uint64_t base = (h << (s0 + S)) + (cg << logC);
-        for (uint32_t e = threadIdx.x; e < E; e += 256) {
+        for (uint32_t e = threadIdx.x; e < E; e += NT_) {
             const uint32_t r = e >> logC, c = e & (C - 1);
             fr_t v;
             fr_load(v, reinterpret_cast<const uint32_t*>(&sm[2 * e]));
@@ -379,8 +380,15 @@ void launch_fr_ntt(hipStream_t s, const uint32_t* in, uint32_t* out, int log_n, 
         if (logC > avail) logC = avail;
         if (p == 0 && logC > 2) logC = 2;  // first pass: 4 tiles (128 B source rows) keep the tiles' stores long
         const uint64_t blocks = n >> (S + logC);
-        k_fr_ntt_pass<<<(uint32_t)blocks, 256, 0, s>>>(in, out, log_n, s0, S, logC, tw,
-                                                       p == passes - 1 ? scale_or_null : nullptr);
+        // one butterfly per thread and stage when the tile allows it (512 threads for a full 1024-element tile): a stage
+        // is then ONE dependent Fr product deep instead of two -- what counts for short rows (2^16: two passes on 64
+        // workgroups, pure latency) -- and long rows just run more waves per CU
+        if ((1u << (S + logC)) >= 1024)
+            k_fr_ntt_pass<512><<<(uint32_t)blocks, 512, 0, s>>>(in, out, log_n, s0, S, logC, tw,
+                                                                p == passes - 1 ? scale_or_null : nullptr);
+        else
+            k_fr_ntt_pass<256><<<(uint32_t)blocks, 256, 0, s>>>(in, out, log_n, s0, S, logC, tw,
+                                                                p == passes - 1 ? scale_or_null : nullptr);
         s0 += S;
     }
 }
@@ -391,20 +399,21 @@ void launch_poly_open(hipStream_t s, const uint32_t* f_mont, uint64_t n, const u
     // values are left for the single-workgroup scan; then the suffix values H are expanded back down level by
     // level.  Every serial loop is <= 16 long (each step is one dependent Fr product, ~1 us for a lone wave), and
     // all levels but the scan fill the GPU.  The level arrays are stacked in h / hnext (api.hip sizes them for
-    // (n+3)/4 * 9/8 + 64 entries; the levels above the first sum to < 1/15 of it).
+    // (n+3)/4 * 3/2 + 64 entries; the levels above the first sum to < 1/3 of it).
     const int l0 = poly_lchunk(n);
-    int lv_l[12], lv_sq[12];
-    uint64_t lv_n[12], lv_off[12];
+    const int lup = 4;   // log2 chunk of the levels above the first (4-long chunks + more levels measured no faster on short rows)
+    int lv_l[16], lv_sq[16];
+    uint64_t lv_n[16], lv_off[16];
     int K = 1;
     lv_l[0] = l0; lv_sq[0] = 0; lv_n[0] = n; lv_off[0] = 0;           // level 0 = f itself (offset unused)
     lv_n[1] = (n + ((uint64_t)1 << l0) - 1) >> l0; lv_sq[1] = l0; lv_off[1] = 0;
     k_poly_chunk_eval<<<nblk(lv_n[1], 256), 256, 0, s>>>(f_mont, n, l0, alpha_mont, 0, h);
-    while (lv_n[K] > 2048 && K < 10) {
-        lv_l[K] = 4;
-        lv_n[K + 1] = (lv_n[K] + 15) >> 4;
-        lv_sq[K + 1] = lv_sq[K] + 4;
+    while (lv_n[K] > 2048 && K < 14) {
+        lv_l[K] = lup;
+        lv_n[K + 1] = (lv_n[K] + ((uint64_t)1 << lup) - 1) >> lup;
+        lv_sq[K + 1] = lv_sq[K] + lup;
         lv_off[K + 1] = lv_off[K] + lv_n[K];
-        k_poly_chunk_eval<<<nblk(lv_n[K + 1], 256), 256, 0, s>>>(h + 8 * lv_off[K], lv_n[K], 4, alpha_mont, lv_sq[K],
+        k_poly_chunk_eval<<<nblk(lv_n[K + 1], 256), 256, 0, s>>>(h + 8 * lv_off[K], lv_n[K], lup, alpha_mont, lv_sq[K],
                                                                  h + 8 * lv_off[K + 1]);
         K++;
     }

@@ -12,6 +12,6 @@ void launch_fr_inv_pow2(hipStream_t s, uint32_t* out, int log_n);
 void launch_fr_ntt(hipStream_t s, const uint32_t* in, uint32_t* out, int log_n, const uint32_t* tw,
                    const uint32_t* scale_or_null);
 // y = f(alpha) (Montgomery) and, if q is given, the n-1 canonical coefficients of (f - y)/(X - alpha)
-// h, hnext: ceil(n/4) Fr scratch each (the chunk length shrinks to 4 for small polynomials)
+// h, hnext: ceil(n/4) * 3/2 + 64 Fr scratch each (level arrays stacked; the chunk length shrinks to 4 for small rows)
 void launch_poly_open(hipStream_t s, const uint32_t* f_mont, uint64_t n, const uint32_t* alpha_mont, uint32_t* h,
                       uint32_t* hnext, uint32_t* y_mont, uint32_t* q_canon_or_null);
