@@ -38,13 +38,12 @@ sys.path.insert(0, ROOT)
 R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy peak
 HBM_COPY_GBS = 6290.0
-# v_mad_u64_u32 (the only wide integer multiply): 5.0 cycles per wave-instruction per SIMD measured with 1, 2 and 4
-# waves per SIMD (scripts/ubench/valu_rates.hip -> profiles/ubench_valu_rates.txt) => 1024 SIMDs x clock / 5.
+# v_mad_u64_u32 (the only wide integer multiply): 2.30 ns per wave-instruction per SIMD measured with 2 and 4 waves per
+# SIMD (scripts/ubench/valu_rates.hip -> profiles/ubench_valu_rates.txt) => 1024 SIMDs / 2.30 ns = 445 G mads/s.
 # For scale: the guide's full-rate figure for simple VALU (wave64 v_fma_f32 in 2 cycles on a SIMD-32 once >= 2 waves
 # share the SIMD) is 1024 x 2.4 GHz / 2 = 1228.8 G wave-instructions/s; integer multiplies do not issue at that rate.
-MAD_CYCLES = 5.0
+MAD_NS = 2.30                  # ns per v_mad_u64_u32 wave-instruction per SIMD at >= 2 waves/SIMD (4.5 ns for a lone wave)
 SIMDS = 1024
-CLOCK_GHZ_HELD = 2.15          # GRBM_GUI_ACTIVE / 8 / kernel time under this load (profiles/*_pmc.csv)
 VALU_FULL_RATE_GINST_S = SIMDS * 2.4 / 2
 TAU = 0x2F6C7A1D3B5E9F80412D6A7C93E1B5F7086A4D2C1E9B3F5A7D6C8E0F1A2B3C4D % R_MOD
 
@@ -444,7 +443,7 @@ def main():
                 mads = pmc.get("wave_mads_per_launch")
         except (OSError, KeyError, ValueError):
             pass
-        mad_peak = SIMDS * CLOCK_GHZ_HELD / MAD_CYCLES
+        mad_peak = SIMDS / MAD_NS
         out = {
             "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -469,8 +468,9 @@ def main():
             "mad_issue": ({"wave_mads_per_launch": mads, "wave_valu_insts_per_launch": valu_insts,
                            "achieved_gmad_s": mads / per_launch_s / 1e9, "peak_gmad_s": mad_peak,
                            "frac": mads / per_launch_s / 1e9 / mad_peak,
-                           "peak_basis": f"{SIMDS} SIMDs x {CLOCK_GHZ_HELD} GHz held / {MAD_CYCLES} cycles per v_mad_u64_u32 "
-                                         "(profiles/ubench_valu_rates.txt)",
+                           "peak_basis": f"{SIMDS} SIMDs / {MAD_NS} ns per v_mad_u64_u32 wave-instruction "
+                                         "(profiles/ubench_valu_rates.txt, 2 and 4 waves per SIMD); mads per launch from "
+                                         "the ISA (profiles/isa_counts.json) x additions per lane x waves",
                            "simd32_full_rate_ginst_s": VALU_FULL_RATE_GINST_S}
                           if mads and acc_ms else None),
             "result_hex": results[0].hex() if isinstance(results[0], (bytes, bytearray)) else b"".join(results[0]).hex(),

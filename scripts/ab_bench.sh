@@ -3,7 +3,7 @@
 # numbers from different gpurun calls are not comparable).  Put the candidates at zkp_subnet_amd/ab/A.so and B.so
 # (git-ignored), then:  gpurun -- 'bash scripts/ab_bench.sh "<bench.py args>" [rounds]'
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-ARGS=${1:---no-adversarial --no-cpu-baseline --steps 15}
+ARGS=${1:---headline-only --steps 15}
 ROUNDS=${2:-3}
 cp zkp_subnet_amd/libkzg_mi355x.so /tmp/_orig.so
 for r in $(seq $ROUNDS); do

@@ -16,7 +16,7 @@ for path in glob.glob(os.path.join(src, "*", "*counter_collection.csv")):
         d[r["Dispatch_Id"]] = d.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
 with open(out_csv, "w") as f:
     f.write("# rocprofv3 --pmc <group> --kernel-trace, one pass per counter group (scripts/pmc_round.sh): python3 bench.py "
-            "--steps 3 --warmup 1 --no-cpu-baseline --no-adversarial (2^20 MSM, c=20)\n")
+            "--steps 3 --warmup 1 --headline-only (2^20 MSM, c=20)\n")
     f.write("# raw counter values per dispatch, averaged over dispatches; FETCH_SIZE/WRITE_SIZE in KB; gfx950: FETCH_SIZE "
             "under-reports wide coalesced reads by 2x\n")
     f.write("kernel,counter,dispatches,avg_per_dispatch\n")
@@ -28,7 +28,16 @@ if fs and ws:
     fkb, wkb = sum(fs.values()) / len(fs), sum(ws.values()) / len(ws)
     cfg = json.loads(open(glob.glob(os.path.join(src, "FETCH_SIZE.json"))[0]).read().strip().splitlines()[-1])["config"]
     iv = acc.get(("k_msm_accumulate", "SQ_INSTS_VALU"))
-    json.dump({"workload": "msm20", "sq_insts_valu_per_launch": (sum(iv.values()) / len(iv)) if iv else None, "points_per_gpu": cfg["points_per_gpu"], "window_bits": cfg["window_bits"],
+    # v_mad_u64_u32 wave-instructions per launch: ISA count per mixed addition (scripts/count_mads.py) x additions per
+    # lane x waves (every lane sums `entries_per_lane` sorted entries)
+    try:
+        isa = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
+                                          "isa_counts.json")))
+        wave_mads = isa["mads_per_mixed_add"] * cfg["entries_per_lane"] * cfg["lanes"] / 64.0
+    except (OSError, KeyError):
+        wave_mads = None
+    json.dump({"workload": "msm20", "sq_insts_valu_per_launch": (sum(iv.values()) / len(iv)) if iv else None,
+               "wave_mads_per_launch": wave_mads, "points_per_gpu": cfg["points_per_gpu"], "window_bits": cfg["window_bits"],
                "kernel": "k_msm_accumulate", "fetch_size_kb_raw": fkb, "write_size_kb_raw": wkb,
                "traffic_bytes_per_launch": 2 * fkb * 1024 + wkb * 1024,
                "correction": "2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE counts 128-B requests as 64 B; "
