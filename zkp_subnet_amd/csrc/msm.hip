@@ -1343,12 +1343,15 @@ void launch_fold_heads(hipStream_t s, const uint32_t* offsets, const uint32_t* c
     else
         k_fold_heads_coop<<<nblk(nchunks, 64), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, carries, buckets);
 }
+#ifndef KZG_TREE_WIDE_MIN
+#define KZG_TREE_WIDE_MIN 32768
+#endif
 void launch_msm_tree_level(hipStream_t s, const g1_xyzz_t* in, const g1_xyzz_t* prev, g1_xyzz_t* out,
                            uint32_t n_in_nodes, int level) {
     uint32_t ops = (n_in_nodes >> 1) * (uint32_t)(level + 1);
     // wide levels are throughput-bound (one lane per addition); narrow ones are latency-bound (4 waves per addition)
     // ... and the narrowest ones, where even that leaves the chip empty, run one WAVE per addition (fp_lp.hip.h)
-    if (ops > 32768) k_msm_tree_level<<<nblk(ops, 256), 256, 0, s>>>(in, prev, out, n_in_nodes, level);
+    if (ops > KZG_TREE_WIDE_MIN) k_msm_tree_level<<<nblk(ops, 256), 256, 0, s>>>(in, prev, out, n_in_nodes, level);
 #ifndef KZG_NO_LP
     else if (ops <= LP_MAX_OPS) k_msm_tree_level_lp<<<ops, 64, 0, s>>>(in, prev, out, n_in_nodes, level);
 #endif

@@ -87,7 +87,9 @@ static void* dec_worker(void* p) {
 
 #define POOL_MAX 15
 static int pick_threads(long want, Py_ssize_t n) {
-    if (want <= 0) want = n < 8192 ? 4 : 8; /* measured on the GPU box's EPYC: 2^12 4 threads, 2^14 and up 8 */
+    /* measured on the GPU box's EPYC: 2^12 4 threads, 2^14 and up 8; long rows (one cache miss per str object: the walk is
+     * memory-latency bound) use the box's whole 16-core share */
+    if (want <= 0) want = n < 8192 ? 4 : n < (1 << 18) ? 8 : 16;
     if (want > POOL_MAX + 1) want = POOL_MAX + 1;
     if (n < 1024) return 1;
     return (int)want;
