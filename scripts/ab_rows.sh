@@ -4,7 +4,7 @@ cd ${GRAFT_REPO_ROOT:-/root/repo}
 ROUNDS=${1:-2}
 cp zkp_subnet_amd/libkzg_mi355x.so /tmp/_orig.so
 for r in $(seq $ROUNDS); do
-  for v in A B; do
+  for v in ${VARIANTS:-A B}; do
     cp zkp_subnet_amd/ab/$v.so zkp_subnet_amd/libkzg_mi355x.so
     python bench.py --no-adversarial --no-cpu-baseline --no-pipelined --steps 20 --kzg-rows 22,20,16,12 2>/dev/null | tail -1 | python -c "
 import json,sys

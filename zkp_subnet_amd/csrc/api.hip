@@ -573,8 +573,7 @@ int commit_open_dev(kzg_ctx* ctx, LaneHold& H, uint32_t i, const uint32_t* row_d
     if (out_p48) {
         uint32_t* alpha_m = reinterpret_cast<uint32_t*>(A.tail + TB_ALPHA_M);
         uint32_t* y_m = reinterpret_cast<uint32_t*>(A.tail + TB_Y_M);
-        HIPCHK(ctx, hipMemcpyAsync(A.tail + TB_ALPHA_BE, alpha_be32, 32, hipMemcpyHostToDevice, so));
-        launch_fr_from_be(so, A.tail + TB_ALPHA_BE, alpha_m, 1, 1, A.flags());
+        launch_fr_from_host32(so, alpha_be32, alpha_m, 1, A.flags());
         const uint64_t nchunks = (T + 3) / 4;
         HIPCHK(ctx, O.hbuf.ensure((nchunks + (nchunks >> 1) + 64) * 32));
         HIPCHK(ctx, O.hnext.ensure((nchunks + (nchunks >> 1) + 64) * 32));
@@ -1152,8 +1151,7 @@ int kzg_eval(kzg_ctx* ctx, const uint8_t* coeffs_be32, uint64_t n, const uint8_t
     if (rc) return rc;
     uint32_t* x_m = reinterpret_cast<uint32_t*>(L.tail + TB_ALPHA_M);
     uint32_t* y_m = reinterpret_cast<uint32_t*>(L.tail + TB_Y_M);
-    HIPCHK(ctx, hipMemcpyAsync(L.tail + TB_ALPHA_BE, x_be32, 32, hipMemcpyHostToDevice, L.stream));
-    launch_fr_from_be(L.stream, L.tail + TB_ALPHA_BE, x_m, 1, 1, L.flags());
+    launch_fr_from_host32(L.stream, x_be32, x_m, 1, L.flags());
     launch_poly_open(L.stream, L.coeffA.as<uint32_t>(), n, x_m, L.hbuf.as<uint32_t>(), L.hnext.as<uint32_t>(), y_m, nullptr);
     launch_fr_to_be(L.stream, y_m, L.tail + TB_EVAL, 1, 1);
     rc = finish(ctx, L);

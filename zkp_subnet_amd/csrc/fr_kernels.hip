@@ -3,6 +3,8 @@
 // Replaces what the external prover does behind fft(poly,left,inverse) / eval / the implicit IFFT + synthetic
 // division of worker_commit / worker_open (reference neurons/validator.py:59-65,98-104; neurons/miner.py:39,48).
 // Domain convention: w_n = 7^((r-1)/n), natural order in and out, inverse carries 1/n.
+#include <cstring>
+
 #include "fr_kernels.hip.h"
 
 static inline uint32_t nblk(uint64_t n, uint32_t b) { return (uint32_t)((n + b - 1) / b); }
@@ -32,6 +34,22 @@ __global__ void __launch_bounds__(256) k_fr_from_be(const uint8_t* __restrict__ 
     if (bi_ge<8>(v.l, rm)) atomicOr(bad, 1u);  // non-canonical scalar: the call fails (SURVEY 8b errors)
     if (to_mont) f_to_mont(v, v);
     fr_store(out + 8 * j, v);
+}
+struct FrArg {
+    uint32_t w[8];  // the 32 big-endian bytes, as they lie in memory
+};
+__global__ void __launch_bounds__(64) k_fr_from_arg(const FrArg a, uint32_t* __restrict__ out, int to_mont,
+                                                     uint32_t* __restrict__ bad) {
+    if (threadIdx.x || blockIdx.x) return;
+    fr_t v;
+#pragma unroll
+    for (int i = 0; i < 8; i++) v.l[i] = bswap32(a.w[7 - i]);
+    uint32_t rm[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) rm[i] = FrParams::mod(i);
+    if (bi_ge<8>(v.l, rm)) atomicOr(bad, 1u);
+    if (to_mont) f_to_mont(v, v);
+    fr_store(out, v);
 }
 __global__ void __launch_bounds__(256) k_fr_to_be(const uint32_t* __restrict__ in, uint8_t* __restrict__ be,
                                                    uint64_t n, int from_mont) {
@@ -250,12 +268,13 @@ __global__ void __launch_bounds__(256) k_poly_chunk_eval(const uint32_t* __restr
 // Suffix recurrence over chunks, H_t = h_t + beta H_{t+1}, beta = alpha^L: one 1024-lane block; lane v serially
 // folds m consecutive chunks, then a Hillis-Steele suffix scan whose multiplier (beta^m)^(2^step) is uniform.
 // Writes hnext[t] = H_{t+1} and y = H_0 = f(alpha).
-__global__ void __launch_bounds__(1024) k_poly_chunk_scan(const uint32_t* __restrict__ h, uint64_t nchunks, int lchunk,
+template <uint32_t NT_>
+__global__ void __launch_bounds__(NT_) k_poly_chunk_scan(const uint32_t* __restrict__ h, uint64_t nchunks, int lchunk,
                                                            const uint32_t* __restrict__ alpha_mont,
                                                            uint32_t* __restrict__ hnext, uint32_t* __restrict__ y_mont) {
-    __shared__ uint4 sm[1024 * 2];
+    __shared__ uint4 sm[NT_ * 2];
     const uint32_t v = threadIdx.x;
-    const uint64_t m = (nchunks + 1023) / 1024;
+    const uint64_t m = (nchunks + NT_ - 1) / NT_;
     const uint64_t lo = (uint64_t)v * m;
     const uint64_t hi = lo + m < nchunks ? lo + m : nchunks;
     fr_t beta, g, c, mult;
@@ -278,10 +297,10 @@ __global__ void __launch_bounds__(1024) k_poly_chunk_scan(const uint32_t* __rest
     }
     fr_store(reinterpret_cast<uint32_t*>(&sm[2 * v]), g);
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
+    for (uint32_t d = 1; d < NT_; d <<= 1) {
         fr_t other;
         f_zero(other);
-        if (v + d < 1024) fr_load(other, reinterpret_cast<const uint32_t*>(&sm[2 * (v + d)]));
+        if (v + d < NT_) fr_load(other, reinterpret_cast<const uint32_t*>(&sm[2 * (v + d)]));
         __syncthreads();
         f_mul(other, other, mult);
         f_add(g, g, other);
@@ -292,7 +311,7 @@ __global__ void __launch_bounds__(1024) k_poly_chunk_scan(const uint32_t* __rest
     // g == H_{lo}; walk the lane's own chunks downward from H_{hi}
     fr_t s;
     f_zero(s);
-    if (v + 1 < 1024) fr_load(s, reinterpret_cast<const uint32_t*>(&sm[2 * (v + 1)]));
+    if (v + 1 < NT_) fr_load(s, reinterpret_cast<const uint32_t*>(&sm[2 * (v + 1)]));
     for (uint64_t u = hi; u-- > lo && lo < nchunks;) {
         fr_store(hnext + 8 * u, s);
         fr_load(c, h + 8 * u);
@@ -349,6 +368,11 @@ __global__ void __launch_bounds__(256) k_poly_quotient(const uint32_t* __restric
 // ------------------------------------------------------------------------------------------------ launchers
 void launch_fr_from_be(hipStream_t s, const uint8_t* be, uint32_t* out, uint64_t n, int to_mont, uint32_t* bad) {
     if (n) k_fr_from_be<<<nblk(n, 256), 256, 0, s>>>(be, out, n, to_mont, bad);
+}
+void launch_fr_from_host32(hipStream_t s, const uint8_t be32[32], uint32_t* out, int to_mont, uint32_t* bad) {
+    FrArg a;
+    memcpy(a.w, be32, 32);
+    k_fr_from_arg<<<1, 64, 0, s>>>(a, out, to_mont, bad);
 }
 void launch_fr_to_be(hipStream_t s, const uint32_t* in, uint8_t* be, uint64_t n, int from_mont) {
     if (n) k_fr_to_be<<<nblk(n, 256), 256, 0, s>>>(in, be, n, from_mont);
@@ -417,7 +441,12 @@ void launch_poly_open(hipStream_t s, const uint32_t* f_mont, uint64_t n, const u
                                                                  h + 8 * lv_off[K + 1]);
         K++;
     }
-    k_poly_chunk_scan<<<1, 1024, 0, s>>>(h + 8 * lv_off[K], lv_n[K], lv_sq[K], alpha_mont, hnext + 8 * lv_off[K], y_mont);
+    // the scan is one workgroup of dependent Fr products: 256 lanes (one wave per SIMD, <= 8 values each) run the chain
+    // at a lone wave's issue rate; 1024 lanes (four waves per SIMD) only when there is more than that to fold
+    if (lv_n[K] <= 1024)
+        k_poly_chunk_scan<256><<<1, 256, 0, s>>>(h + 8 * lv_off[K], lv_n[K], lv_sq[K], alpha_mont, hnext + 8 * lv_off[K], y_mont);
+    else
+        k_poly_chunk_scan<1024><<<1, 1024, 0, s>>>(h + 8 * lv_off[K], lv_n[K], lv_sq[K], alpha_mont, hnext + 8 * lv_off[K], y_mont);
     for (int k = K - 1; k >= 1; k--)
         k_poly_chunk_expand<<<nblk(lv_n[k + 1], 256), 256, 0, s>>>(h + 8 * lv_off[k], lv_n[k], lv_l[k], alpha_mont,
                                                                    lv_sq[k], hnext + 8 * lv_off[k + 1],

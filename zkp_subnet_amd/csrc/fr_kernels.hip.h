@@ -3,6 +3,8 @@
 #include "g1.hip.h"
 
 void launch_fr_from_be(hipStream_t s, const uint8_t* be, uint32_t* out, uint64_t n, int to_mont, uint32_t* bad);
+// one scalar from HOST memory, handed over as a kernel argument (no copy on the stream)
+void launch_fr_from_host32(hipStream_t s, const uint8_t be32[32], uint32_t* out, int to_mont, uint32_t* bad);
 void launch_fr_to_be(hipStream_t s, const uint32_t* in, uint8_t* be, uint64_t n, int from_mont);
 void launch_fr_from_mont(hipStream_t s, const uint32_t* in, uint32_t* out, uint64_t n);
 // tw: 2^(log_n-1) Montgomery-form powers of w_n (inverse: of w_n^-1)

@@ -82,25 +82,27 @@ KZG_DEV void for_each_entry(const uint32_t* __restrict__ scalars, const SortShap
         }
     }
 }
-// partition sizes: 1024 lanes x 4 scalars each (all four loads in flight before the first digit is extracted)
+// partition sizes: 1024 lanes x R scalars each.  R = 4 for long inputs (all four loads in flight before the first digit is
+// extracted); R = 1 for short ones, where 4 scalars x nwin LDS atomics per lane on a handful of workgroups is a ~50 us chain
+template <int R>
 __global__ void __launch_bounds__(1024) k_sort_count(const uint32_t* __restrict__ scalars, const SortShape ss,
                                                       const WinLayout lay, uint32_t* __restrict__ part_count) {
     __shared__ uint32_t h[SORT_MAXPART];
     const uint32_t npart = 1u << ss.hbits;
     for (uint32_t i = threadIdx.x; i < npart; i += 1024) h[i] = 0;
     __syncthreads();
-    uint32_t sc[4][8];
-    bool live[4], second[4];
+    uint32_t sc[R][8];
+    bool live[R], second[R];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const uint64_t g = (uint64_t)blockIdx.x * 4096 + r * 1024 + threadIdx.x;
+    for (int r = 0; r < R; r++) {
+        const uint64_t g = (uint64_t)blockIdx.x * (1024 * R) + r * 1024 + threadIdx.x;
         live[r] = g < ss.total;
         second[r] = live[r] && g >= ss.n;
         const uint64_t j = second[r] ? g - ss.n : g;
         if (live[r]) load_scalar(sc[r], second[r] ? ss.scalars2 : scalars, j, second[r] ? ss.mont2 : ss.mont);
     }
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < R; r++) {
         if (!live[r]) continue;
         const uint32_t set_bit = second[r] ? 1u << ss.keybits : 0u;
         uint32_t carry = 0, neg;
@@ -1307,7 +1309,8 @@ void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars,
     uint32_t* part_cursor = part_ws + 2 * SORT_MAXPART + 8;
     (void)hipMemsetAsync(part_count, 0, npart * 4, s);
     const uint32_t blocks = nblk(ss.total, ss.spb);
-    k_sort_count<<<nblk(ss.total, 4096), 1024, 0, s>>>(scalars, ss, sh.lay, part_count);
+    if (ss.total > (1u << 18)) k_sort_count<4><<<nblk(ss.total, 4096), 1024, 0, s>>>(scalars, ss, sh.lay, part_count);
+    else k_sort_count<1><<<nblk(ss.total, 1024), 1024, 0, s>>>(scalars, ss, sh.lay, part_count);
     k_sort_part_scan<<<1, 1024, 0, s>>>(part_count, npart, part_base, part_cursor);
     if (sh.nwin <= SORT1_MAXW) {
         uint32_t spb2 = (SORT1_STAGE / (uint32_t)sh.nwin) & ~63u;  // one scalar per lane, <= SORT1_STAGE entries
@@ -1329,16 +1332,19 @@ void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t*
 void launch_fold_maxlen(hipStream_t s, const uint32_t* offsets, uint32_t nbuckets, uint32_t chunk, uint32_t* max_len) {
     k_fold_maxlen<<<nblk(nbuckets, 256), 256, 0, s>>>(offsets, nbuckets, chunk, max_len);
 }
+#ifndef KZG_FOLD_COOP_MAX
+#define KZG_FOLD_COOP_MAX 32768
+#endif
 void launch_fold_step(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
                       uint32_t nchunks, uint32_t d, g1_xyzz_t* carries) {
     if (!nchunks) return;
-    if (nchunks > 32768) k_fold_step<<<nblk(nchunks, 256), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, d, carries);
+    if (nchunks > KZG_FOLD_COOP_MAX) k_fold_step<<<nblk(nchunks, 256), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, d, carries);
     else k_fold_step_coop<<<nblk(nchunks, 64), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, d, carries);
 }
 void launch_fold_heads(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
                        uint32_t nchunks, const g1_xyzz_t* carries, g1_xyzz_t* buckets) {
     if (!nchunks) return;
-    if (nchunks > 32768)
+    if (nchunks > KZG_FOLD_COOP_MAX)
         k_fold_heads<<<nblk(nchunks, 256), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, carries, buckets);
     else
         k_fold_heads_coop<<<nblk(nchunks, 64), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, carries, buckets);
