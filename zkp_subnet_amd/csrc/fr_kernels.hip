@@ -9,31 +9,22 @@
 
 static inline uint32_t nblk(uint64_t n, uint32_t b) { return (uint32_t)((n + b - 1) / b); }
 
-KZG_DEV void fr_load(fr_t& v, const uint32_t* p) {
-    const uint4* q = reinterpret_cast<const uint4*>(p);
-    uint4 a = q[0], b = q[1];
-    v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w;
-    v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
-}
-KZG_DEV void fr_store(uint32_t* p, const fr_t& v) {
-    uint4* q = reinterpret_cast<uint4*>(p);
-    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
-}
+// All arithmetic below is fr29.hip.h's: 9 x 29-bit limbs, Montgomery radix 2^261; memory holds 8-word values.
+// "Montgomery form" in this file (rows, coefficients, twiddles, 1/n) therefore means a * 2^261 mod r, canonical.
+KZG_DEV void words_from_be(uint32_t* w, const uint8_t* be) { limbs_from_be<8>(w, be); }
 
 // ------------------------------------------------------------------------------------------------ codec
 __global__ void __launch_bounds__(256) k_fr_from_be(const uint8_t* __restrict__ be, uint32_t* __restrict__ out,
                                                      uint64_t n, int to_mont, uint32_t* __restrict__ bad) {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    fr_t v;
-    limbs_from_be<8>(v.l, be + 32 * j);
-    uint32_t rm[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) rm[i] = FrParams::mod(i);
-    if (bi_ge<8>(v.l, rm)) atomicOr(bad, 1u);  // non-canonical scalar: the call fails (SURVEY 8b errors)
-    if (to_mont) f_to_mont(v, v);
-    fr_store(out + 8 * j, v);
+    uint32_t w[8];
+    words_from_be(w, be + 32 * j);
+    if (fr_words_ge_r(w)) atomicOr(bad, 1u);  // non-canonical scalar: the call fails (SURVEY 8b errors)
+    fr9_t v;
+    fr9_from_words(v, w);
+    if (to_mont) fr9_to_mont(v, v);
+    fr9_store(out + 8 * j, v);
 }
 struct FrArg {
     uint32_t w[8];  // the 32 big-endian bytes, as they lie in memory
@@ -41,45 +32,48 @@ struct FrArg {
 __global__ void __launch_bounds__(64) k_fr_from_arg(const FrArg a, uint32_t* __restrict__ out, int to_mont,
                                                      uint32_t* __restrict__ bad) {
     if (threadIdx.x || blockIdx.x) return;
-    fr_t v;
+    uint32_t w[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) v.l[i] = bswap32(a.w[7 - i]);
-    uint32_t rm[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) rm[i] = FrParams::mod(i);
-    if (bi_ge<8>(v.l, rm)) atomicOr(bad, 1u);
-    if (to_mont) f_to_mont(v, v);
-    fr_store(out, v);
+    for (int i = 0; i < 8; i++) w[i] = bswap32(a.w[7 - i]);
+    if (fr_words_ge_r(w)) atomicOr(bad, 1u);
+    fr9_t v;
+    fr9_from_words(v, w);
+    if (to_mont) fr9_to_mont(v, v);
+    fr9_store(out, v);
 }
 __global__ void __launch_bounds__(256) k_fr_to_be(const uint32_t* __restrict__ in, uint8_t* __restrict__ be,
                                                    uint64_t n, int from_mont) {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    fr_t v;
-    fr_load(v, in + 8 * j);
-    if (from_mont) f_from_mont(v, v);
-    limbs_to_be<8>(be + 32 * j, v.l);
+    fr9_t v;
+    fr9_load(v, in + 8 * j);
+    if (from_mont) fr9_from_mont(v, v);
+    uint32_t w[8];
+    fr9_to_words(w, v);
+    limbs_to_be<8>(be + 32 * j, w);
 }
 __global__ void __launch_bounds__(256) k_fr_from_mont(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                        uint64_t n) {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    fr_t v;
-    fr_load(v, in + 8 * j);
-    f_from_mont(v, v);
-    fr_store(out + 8 * j, v);
+    fr9_t v;
+    fr9_load(v, in + 8 * j);
+    fr9_from_mont(v, v);
+    fr9_store(out + 8 * j, v);
 }
 
 // ------------------------------------------------------------------------------------------------ twiddles
 // w_{2^32} = 7^((r-1)/2^32) and its inverse, canonical limbs (re-derived in oracle/bls12_381.py)
-KZG_DEV void fr_root_2_32(fr_t& w, int inverse) {
+KZG_DEV void fr_root_2_32(fr9_t& w, int inverse) {
     constexpr uint32_t W[8] = {0x439f0d2bu, 0x3829971fu, 0x8c2280b9u, 0xb6368350u,
                                0x22c813b4u, 0xd09b6819u, 0xdfe81f20u, 0x16a2a19eu};
     constexpr uint32_t WI[8] = {0x3cf19a78u, 0x0fb4d6e1u, 0xb566f833u, 0x6f67d4a2u,
                                 0xa35d0168u, 0xed4f2f74u, 0x6e19c653u, 0x0538a6f6u};
+    uint32_t t[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) w.l[i] = inverse ? WI[i] : W[i];
-    f_to_mont(w, w);
+    for (int i = 0; i < 8; i++) t[i] = inverse ? WI[i] : W[i];
+    fr9_from_words(w, t);
+    fr9_to_mont(w, w);
 }
 // tw[k] = w_n^(+-k), k < n/2, Montgomery form; 64 consecutive k per lane
 __global__ void __launch_bounds__(256) k_fr_twiddles(uint32_t* __restrict__ tw, int log_n, int inverse) {
@@ -87,18 +81,21 @@ __global__ void __launch_bounds__(256) k_fr_twiddles(uint32_t* __restrict__ tw, 
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t k0 = t * 64;
     if (k0 >= half) return;
-    fr_t w, cur, pw;
+    fr9_t w, cur, pw;
     fr_root_2_32(w, inverse);
-    for (int i = log_n; i < 32; i++) f_mul(w, w, w);
-    f_one(cur);
+    for (int i = log_n; i < 32; i++) { fr9_mul(w, w, w); }       // N class in, N class out
+    fr9_canon(w, w);
+    fr9_one(cur);
     pw = w;
     for (uint64_t e = k0; e; e >>= 1) {
-        if (e & 1) f_mul(cur, cur, pw);
-        f_mul(pw, pw, pw);
+        if (e & 1) fr9_mul(cur, cur, pw);
+        fr9_mul(pw, pw, pw);
     }
     for (uint64_t k = k0; k < k0 + 64 && k < half; k++) {
-        fr_store(tw + 8 * k, cur);
-        f_mul(cur, cur, w);
+        fr9_t c;
+        fr9_canon(c, cur);
+        fr9_store(tw + 8 * k, c);
+        fr9_mul(cur, cur, w);
     }
 }
 // out[0] = 2^-log_n in Montgomery form
@@ -106,13 +103,16 @@ __global__ void k_fr_inv_pow2(uint32_t* __restrict__ out, int log_n) {
     if (threadIdx.x || blockIdx.x) return;
     constexpr uint32_t HALF[8] = {0x80000001u, 0x7fffffffu, 0x7fff2dffu, 0xa9ded201u,
                                   0x04d0ec02u, 0x199cec04u, 0x94cebea4u, 0x39f6d3a9u};  // (r+1)/2
-    fr_t h, acc;
+    uint32_t t[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) h.l[i] = HALF[i];
-    f_to_mont(h, h);
-    f_one(acc);
-    for (int i = 0; i < log_n; i++) f_mul(acc, acc, h);
-    fr_store(out, acc);
+    for (int i = 0; i < 8; i++) t[i] = HALF[i];
+    fr9_t h, acc;
+    fr9_from_words(h, t);
+    fr9_to_mont(h, h);
+    fr9_one(acc);
+    for (int i = 0; i < log_n; i++) fr9_mul(acc, acc, h);
+    fr9_canon(acc, acc);
+    fr9_store(out, acc);
 }
 
 // ------------------------------------------------------------------------------------------------ NTT
@@ -131,12 +131,25 @@ __global__ void k_fr_inv_pow2(uint32_t* __restrict__ out, int log_n) {
 #define NTT_TILE_ELEMS 1024 // rows x columns
 KZG_DEV uint32_t brev_bits(uint32_t v, int bits) { return bits ? (__brev(v) >> (32 - bits)) : 0u; }
 
+// LDS tile: limb-major (9 arrays of 1024 words), values kept as normalised 9-limb residues between stages; they are
+// only canonicalised (one product by R mod r, or by the 1/n of the inverse transform) when the pass stores to HBM.
+struct NttTile {
+    uint32_t l[9][NTT_TILE_ELEMS];
+};
+KZG_DEV void tile_get(fr9_t& v, const NttTile& sm, uint32_t e) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) v.l[i] = sm.l[i][e];
+}
+KZG_DEV void tile_put(NttTile& sm, uint32_t e, const fr9_t& v) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) sm.l[i][e] = v.l[i];
+}
 template <uint32_t NT_>
 __global__ void __launch_bounds__(NT_) k_fr_ntt_pass(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                       int log_n, int s0, int S, int logC,
                                                       const uint32_t* __restrict__ tw,
                                                       const uint32_t* __restrict__ scale_or_null) {
-    __shared__ uint4 sm[NTT_TILE_ELEMS * 2];
+    __shared__ NttTile sm;
     const uint32_t R = 1u << S, C = 1u << logC, E = R << logC;
     const bool first = s0 == 0;
     const int log_nt = log_n - S;  // first pass: tiles
@@ -146,10 +159,9 @@ __global__ void __launch_bounds__(NT_) k_fr_ntt_pass(const uint32_t* __restrict_
         const uint64_t u = blockIdx.x;
         for (uint32_t e = threadIdx.x; e < E; e += NT_) {
             const uint32_t rp = e >> logC, c = e & (C - 1);  // source row, tile
-            const uint4* src = reinterpret_cast<const uint4*>(in + 8 * ((uint64_t)rp * NT + u * C + c));
-            const uint32_t slot = (c << S) + brev_bits(rp, S);  // LDS layout [tile][row]
-            sm[2 * slot] = src[0];
-            sm[2 * slot + 1] = src[1];
+            fr9_t v;
+            fr9_load(v, in + 8 * ((uint64_t)rp * NT + u * C + c));
+            tile_put(sm, (c << S) + brev_bits(rp, S), v);    // LDS layout [tile][row]
         }
     } else {
         const uint64_t groups = ((uint64_t)1 << s0) >> logC;  // column groups per block of 2^(s0+S) elements
@@ -157,13 +169,14 @@ __global__ void __launch_bounds__(NT_) k_fr_ntt_pass(const uint32_t* __restrict_
         const uint64_t base = (h << (s0 + S)) + (cg << logC);
         for (uint32_t e = threadIdx.x; e < E; e += NT_) {
             const uint32_t r = e >> logC, c = e & (C - 1);
-            const uint4* src = reinterpret_cast<const uint4*>(out + 8 * (base + ((uint64_t)r << s0) + c));
-            sm[2 * e] = src[0];  // LDS layout [row][column]
-            sm[2 * e + 1] = src[1];
+            fr9_t v;
+            fr9_load(v, out + 8 * (base + ((uint64_t)r << s0) + c));
+            tile_put(sm, e, v);                              // LDS layout [row][column]
         }
     }
     __syncthreads();
-    // ---- butterflies
+    // ---- butterflies: t = v w (N class), u' = u + t, v' = u + 4r - t, both renormalised.  A value grows by at most 4r
+    // per stage: < 33r after the 8 stages of a pass, inside what fr9_mul accepts as its first operand (< 64r).
     const uint64_t col0 = first ? 0 : ((uint64_t)(blockIdx.x % (((uint64_t)1 << s0) >> logC)) << logC);
     for (int l = 0; l < S; l++) {
         const uint32_t half = 1u << l;
@@ -186,21 +199,24 @@ __global__ void __launch_bounds__(NT_) k_fr_ntt_pass(const uint32_t* __restrict_
                 ej = ei + (half << logC);
                 k = ((uint64_t)kk << s0) + col0 + c;
             }
-            fr_t u, v, w, t;
-            fr_load(u, reinterpret_cast<const uint32_t*>(&sm[2 * ei]));
-            fr_load(v, reinterpret_cast<const uint32_t*>(&sm[2 * ej]));
-            fr_load(w, tw + 8 * (k << (log_n - s - 1)));
-            f_mul(t, v, w);
-            f_add(v, u, t);
-            f_sub(w, u, t);
-            fr_store(reinterpret_cast<uint32_t*>(&sm[2 * ei]), v);
-            fr_store(reinterpret_cast<uint32_t*>(&sm[2 * ej]), w);
+            fr9_t u, v, w, t;
+            tile_get(u, sm, ei);
+            tile_get(v, sm, ej);
+            fr9_load(w, tw + 8 * (k << (log_n - s - 1)));
+            fr9_mul(t, v, w);
+            fr9_add(v, u, t);
+            fr9_sub4(w, u, t);
+            fr9_norm(v, v);
+            fr9_norm(w, w);
+            tile_put(sm, ei, v);
+            tile_put(sm, ej, w);
         }
         __syncthreads();
     }
-    // ---- store (+ 1/n on the last pass of an inverse transform)
-    fr_t f;
-    if (scale_or_null) fr_load(f, scale_or_null);
+    // ---- store: canonical again; the same product applies the 1/n on the last pass of an inverse transform
+    fr9_t f;
+    if (scale_or_null) fr9_load(f, scale_or_null);
+    else fr9_one(f);
     if (first) {
         const uint32_t u = blockIdx.x;
         const uint64_t tiles_per_c = ((uint64_t)1 << log_nt) >> logC;
@@ -208,10 +224,11 @@ __global__ void __launch_bounds__(NT_) k_fr_ntt_pass(const uint32_t* __restrict_
         for (uint32_t e = threadIdx.x; e < E; e += NT_) {
             const uint32_t c = e >> S, r = e & (R - 1);
             const uint64_t t = (uint64_t)brev_bits(c, logC) * tiles_per_c + t_low;
-            fr_t v;
-            fr_load(v, reinterpret_cast<const uint32_t*>(&sm[2 * e]));
-            if (scale_or_null) f_mul(v, v, f);
-            fr_store(out + 8 * ((t << S) + r), v);
+            fr9_t v;
+            tile_get(v, sm, e);
+            fr9_mul(v, v, f);
+            fr9_canon(v, v);
+            fr9_store(out + 8 * ((t << S) + r), v);
         }
     } else {
         const uint64_t groups = ((uint64_t)1 << s0) >> logC;
@@ -219,31 +236,27 @@ __global__ void __launch_bounds__(NT_) k_fr_ntt_pass(const uint32_t* __restrict_
         const uint64_t base = (h << (s0 + S)) + (cg << logC);
         for (uint32_t e = threadIdx.x; e < E; e += NT_) {
             const uint32_t r = e >> logC, c = e & (C - 1);
-            fr_t v;
-            fr_load(v, reinterpret_cast<const uint32_t*>(&sm[2 * e]));
-            if (scale_or_null) f_mul(v, v, f);
-            fr_store(out + 8 * (base + ((uint64_t)r << s0) + c), v);
+            fr9_t v;
+            tile_get(v, sm, e);
+            fr9_mul(v, v, f);
+            fr9_canon(v, v);
+            fr9_store(out + 8 * (base + ((uint64_t)r << s0) + c), v);
         }
     }
-}
-__global__ void __launch_bounds__(256) k_fr_scale(uint32_t* __restrict__ data, uint64_t n,
-                                                   const uint32_t* __restrict__ factor) {
-    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    fr_t v, f;
-    fr_load(v, data + 8 * j);
-    fr_load(f, factor);
-    f_mul(v, v, f);
-    fr_store(data + 8 * j, v);
 }
 
 // ------------------------------------------------------------------------------------------------ eval + quotient
 // Chunk length L = 2^lchunk coefficients per lane: 16 for large polynomials, down to 4 for small rows: the chunk loops
-// are chains of dependent Fr products (a lone wave needs ~1 us each), so short chunks + more levels beat long ones.
+// are chains of dependent Fr products, so short chunks + more levels beat long ones.  Inside a chain the running value
+// stays lazy (product output + one canonical coefficient: < 3r) and is canonicalised once, when it is stored.
 static inline int poly_lchunk(uint64_t n) {
     int l = 2;
     while (l < 4 && (n >> (l + 1)) >= 16384) l++;
     return l;
+}
+KZG_DEV void fr9_pow2k(fr9_t& a, int k) {  // a <- a^(2^k), canonical in and out
+    for (int i = 0; i < k; i++) fr9_mul(a, a, a);
+    fr9_canon(a, a);
 }
 // h[t] = sum_k f[t*L + k] a^k with a = alpha^(2^sq)  (sq > 0: f is itself an array of chunk values, second level)
 __global__ void __launch_bounds__(256) k_poly_chunk_eval(const uint32_t* __restrict__ f, uint64_t n, int lchunk,
@@ -254,71 +267,87 @@ __global__ void __launch_bounds__(256) k_poly_chunk_eval(const uint32_t* __restr
     uint64_t lo = t * L;
     if (lo >= n) return;
     uint64_t hi = lo + L < n ? lo + L : n;
-    fr_t a, s, c;
-    fr_load(a, alpha_mont);
-    for (int i = 0; i < sq; i++) f_mul(a, a, a);
-    f_zero(s);
+    fr9_t a, s, c;
+    fr9_load(a, alpha_mont);
+    fr9_pow2k(a, sq);
+    fr9_zero(s);
     for (uint64_t j = hi; j-- > lo;) {
-        fr_load(c, f + 8 * j);
-        f_mul(s, s, a);
-        f_add(s, s, c);
+        fr9_load(c, f + 8 * j);
+        fr9_mul(s, s, a);
+        fr9_add(s, s, c);
     }
-    fr_store(h + 8 * t, s);
+    fr9_reduce(s, s);
+    fr9_store(h + 8 * t, s);
 }
-// Suffix recurrence over chunks, H_t = h_t + beta H_{t+1}, beta = alpha^L: one 1024-lane block; lane v serially
+// Suffix recurrence over chunks, H_t = h_t + beta H_{t+1}, beta = alpha^L: one NT_-lane block; lane v serially
 // folds m consecutive chunks, then a Hillis-Steele suffix scan whose multiplier (beta^m)^(2^step) is uniform.
 // Writes hnext[t] = H_{t+1} and y = H_0 = f(alpha).
 template <uint32_t NT_>
 __global__ void __launch_bounds__(NT_) k_poly_chunk_scan(const uint32_t* __restrict__ h, uint64_t nchunks, int lchunk,
                                                            const uint32_t* __restrict__ alpha_mont,
                                                            uint32_t* __restrict__ hnext, uint32_t* __restrict__ y_mont) {
-    __shared__ uint4 sm[NT_ * 2];
+    __shared__ uint32_t sm[9][NT_];
     const uint32_t v = threadIdx.x;
     const uint64_t m = (nchunks + NT_ - 1) / NT_;
     const uint64_t lo = (uint64_t)v * m;
     const uint64_t hi = lo + m < nchunks ? lo + m : nchunks;
-    fr_t beta, g, c, mult;
-    fr_load(beta, alpha_mont);
-    for (int i = 0; i < lchunk; i++) f_mul(beta, beta, beta);  // alpha^L
-    f_zero(g);
+    fr9_t beta, g, c, mult;
+    fr9_load(beta, alpha_mont);
+    fr9_pow2k(beta, lchunk);  // alpha^L
+    fr9_zero(g);
     for (uint64_t u = hi; u-- > lo && lo < nchunks;) {
-        fr_load(c, h + 8 * u);
-        f_mul(g, g, beta);
-        f_add(g, g, c);
+        fr9_load(c, h + 8 * u);
+        fr9_mul(g, g, beta);
+        fr9_add(g, g, c);
     }
-    // mult = beta^m
-    f_one(mult);
+    fr9_norm(g, g);           // < 3r, normalised
+    // mult = beta^m (N class, renormalised products)
+    fr9_one(mult);
     {
-        fr_t pw = beta;
+        fr9_t pw = beta;
         for (uint64_t e = m; e; e >>= 1) {
-            if (e & 1) f_mul(mult, mult, pw);
-            f_mul(pw, pw, pw);
+            if (e & 1) fr9_mul(mult, mult, pw);
+            fr9_mul(pw, pw, pw);
         }
     }
-    fr_store(reinterpret_cast<uint32_t*>(&sm[2 * v]), g);
+#pragma unroll
+    for (int i = 0; i < 9; i++) sm[i][v] = g.l[i];
     __syncthreads();
-    for (uint32_t d = 1; d < NT_; d <<= 1) {
-        fr_t other;
-        f_zero(other);
-        if (v + d < NT_) fr_load(other, reinterpret_cast<const uint32_t*>(&sm[2 * (v + d)]));
+    for (uint32_t d = 1; d < NT_; d <<= 1) {   // g grows by < 2r per step: < 3r + 20r at the end, always normalised
+        fr9_t other;
+        fr9_zero(other);
+        if (v + d < NT_) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) other.l[i] = sm[i][v + d];
+        }
         __syncthreads();
-        f_mul(other, other, mult);
-        f_add(g, g, other);
-        fr_store(reinterpret_cast<uint32_t*>(&sm[2 * v]), g);
-        f_mul(mult, mult, mult);
+        fr9_mul(other, other, mult);
+        fr9_add(g, g, other);
+        fr9_norm(g, g);
+#pragma unroll
+        for (int i = 0; i < 9; i++) sm[i][v] = g.l[i];
+        fr9_mul(mult, mult, mult);
         __syncthreads();
     }
     // g == H_{lo}; walk the lane's own chunks downward from H_{hi}
-    fr_t s;
-    f_zero(s);
-    if (v + 1 < NT_) fr_load(s, reinterpret_cast<const uint32_t*>(&sm[2 * (v + 1)]));
-    for (uint64_t u = hi; u-- > lo && lo < nchunks;) {
-        fr_store(hnext + 8 * u, s);
-        fr_load(c, h + 8 * u);
-        f_mul(s, s, beta);
-        f_add(s, s, c);
+    fr9_t s;
+    fr9_zero(s);
+    if (v + 1 < NT_) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) s.l[i] = sm[i][v + 1];
     }
-    if (v == 0) fr_store(y_mont, s);
+    for (uint64_t u = hi; u-- > lo && lo < nchunks;) {
+        fr9_t o;
+        fr9_reduce(o, s);
+        fr9_store(hnext + 8 * u, o);
+        fr9_load(c, h + 8 * u);
+        fr9_mul(s, s, beta);
+        fr9_add(s, s, c);
+    }
+    if (v == 0) {
+        fr9_reduce(s, s);
+        fr9_store(y_mont, s);
+    }
 }
 // second level back down: hnext2[g] = H_{(g+1) * L2} over groups of L2 = 2^l2 first-level chunks -> hnext[u] = H_{u+1}
 __global__ void __launch_bounds__(256) k_poly_chunk_expand(const uint32_t* __restrict__ h, uint64_t nchunks, int l2,
@@ -330,15 +359,17 @@ __global__ void __launch_bounds__(256) k_poly_chunk_expand(const uint32_t* __res
     uint64_t lo = g * L;
     if (lo >= nchunks) return;
     uint64_t hi = lo + L < nchunks ? lo + L : nchunks;
-    fr_t beta, s, c;
-    fr_load(beta, alpha_mont);
-    for (int i = 0; i < sq; i++) f_mul(beta, beta, beta);
-    fr_load(s, hnext2 + 8 * g);
+    fr9_t beta, s, c;
+    fr9_load(beta, alpha_mont);
+    fr9_pow2k(beta, sq);
+    fr9_load(s, hnext2 + 8 * g);
     for (uint64_t u = hi; u-- > lo;) {
-        fr_store(hnext + 8 * u, s);
-        fr_load(c, h + 8 * u);
-        f_mul(s, s, beta);
-        f_add(s, s, c);
+        fr9_t o;
+        fr9_reduce(o, s);
+        fr9_store(hnext + 8 * u, o);
+        fr9_load(c, h + 8 * u);
+        fr9_mul(s, s, beta);
+        fr9_add(s, s, c);
     }
 }
 // q[j-1] = sum_{k>=j} f_k alpha^(k-j), written canonical (ready to be MSM scalars); q has n-1 entries
@@ -351,16 +382,16 @@ __global__ void __launch_bounds__(256) k_poly_quotient(const uint32_t* __restric
     uint64_t lo = t * L;
     if (lo >= n) return;
     uint64_t hi = lo + L < n ? lo + L : n;
-    fr_t a, s, c, o;
-    fr_load(a, alpha_mont);
-    fr_load(s, hnext + 8 * t);
+    fr9_t a, s, c, o;
+    fr9_load(a, alpha_mont);
+    fr9_load(s, hnext + 8 * t);
     for (uint64_t j = hi; j-- > lo;) {
-        fr_load(c, f + 8 * j);
-        f_mul(s, s, a);
-        f_add(s, s, c);
+        fr9_load(c, f + 8 * j);
+        fr9_mul(s, s, a);
+        fr9_add(s, s, c);
         if (j >= 1) {
-            f_from_mont(o, s);
-            fr_store(q_canon + 8 * (j - 1), o);
+            fr9_from_mont(o, s);
+            fr9_store(q_canon + 8 * (j - 1), o);
         }
     }
 }

@@ -9,6 +9,7 @@
 #pragma once
 #include "field.hip.h"
 #include "fp28.hip.h"
+#include "fr29.hip.h"
 
 // HBM form of a table point: one 128-byte line = x, y as 14 canonical 28-bit limbs each (the working representation:
 // no unpacking in the hot loop) + 16 bytes of padding.  A 96-byte packed row straddled two 128-B lines for 3 rows in 4.

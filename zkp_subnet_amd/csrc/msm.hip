@@ -22,12 +22,14 @@ KZG_DEV uint32_t window_bits(const uint32_t* s, int lo, int c) {
 KZG_DEV void load_scalar(uint32_t* s, const uint32_t* scalars, uint64_t j, int mont) {
     const uint4* p = reinterpret_cast<const uint4*>(scalars + 8 * j);
     uint4 a = p[0], b = p[1];
-    fr_t v;
-    v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w;
-    v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
-    if (mont) f_from_mont(v, v);
-#pragma unroll
-    for (int i = 0; i < 8; i++) s[i] = v.l[i];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
+    s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+    if (mont) {  // Montgomery-form row (the coefficients of a commitment): back to the canonical integer
+        fr9_t v;
+        fr9_from_words(v, s);
+        fr9_from_mont(v, v);
+        fr9_to_words(s, v);
+    }
 }
 // signed-digit recoding: digit in [-2^(c-1)+1, 2^(c-1)]; returns magnitude (0 = skip), sets neg, updates carry
 KZG_DEV uint32_t signed_digit(const uint32_t* s, int w, const WinLayout& lay, uint32_t& carry, uint32_t& neg) {
@@ -1209,21 +1211,19 @@ __global__ void __launch_bounds__(256) k_srs_scalars(uint32_t* __restrict__ scal
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t j0 = t * 64;
     if (j0 >= count) return;
-    fr_t tau, cur, pw;
-#pragma unroll
-    for (int i = 0; i < 8; i++) { tau.l[i] = tau_mont[i]; cur.l[i] = s0_mont[i]; }
+    fr9_t tau, cur, pw;
+    fr9_load(tau, tau_mont);
+    fr9_load(cur, s0_mont);
     pw = tau;  // cur *= tau^(j_base + j0)
     for (uint64_t e = j_base + j0; e; e >>= 1) {
-        if (e & 1) f_mul(cur, cur, pw);
-        f_mul(pw, pw, pw);
+        if (e & 1) fr9_mul(cur, cur, pw);
+        fr9_mul(pw, pw, pw);
     }
     for (uint64_t j = j0; j < j0 + 64 && j < count; j++) {
-        fr_t c;
-        f_from_mont(c, cur);
-        uint4* o = reinterpret_cast<uint4*>(scal + 8 * j);
-        o[0] = make_uint4(c.l[0], c.l[1], c.l[2], c.l[3]);
-        o[1] = make_uint4(c.l[4], c.l[5], c.l[6], c.l[7]);
-        f_mul(cur, cur, tau);
+        fr9_t c;
+        fr9_from_mont(c, cur);
+        fr9_store(scal + 8 * j, c);
+        fr9_mul(cur, cur, tau);
     }
 }
 __global__ void __launch_bounds__(256) k_srs_fixed_mul(const uint32_t* __restrict__ scal, uint64_t count,
