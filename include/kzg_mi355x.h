@@ -159,6 +159,8 @@ int kzg_set_host_finish(kzg_ctx* ctx, int enable);
 /* the host encoder itself (no GPU): 4 x 14 limbs of 28 bits (X, Y, ZZ, ZZZ; lazy limbs < 2^32; residues with
  * R = 2^392) -> 48-byte compressed point / 192-byte partial record.  Test hooks. */
 int kzg_host_xyzz_to_c48(const uint32_t xyzz_limbs28[56], uint8_t out48[48]);
+int kzg_host_xyzz_pair_to_c48(const uint32_t a_limbs28[56], const uint32_t b_limbs28[56], uint8_t out_a48[48],
+                              uint8_t out_b48[48]); /* two points, one shared inversion (commit + open) */
 int kzg_host_xyzz_to_partial192(const uint32_t xyzz_limbs28[56], uint8_t out192[192]);
 
 /* ---- per-stage HIP-event timings of the last hot-path call (events recorded on the ctx's own stream) */

@@ -156,6 +156,25 @@ def test_host_encoder_matches_oracle(lib):
         assert lib.kzg_host_xyzz_to_partial192(arr, part) == 0
         for k, v in enumerate(vals):
             assert int.from_bytes(part.raw[48 * k:48 * k + 48], "little") == v * R392 % o.P
+    # pair form (commit + open share one inversion), incl. one or both at infinity
+    pts, arrs = [], []
+    for case in range(6):
+        pt = o.g1_mul(o.G1, rnd.randrange(1, o.R))
+        z = rnd.randrange(1, o.P)
+        zz, zzz = z * z % o.P, z * z * z % o.P
+        limbs = []
+        for v in (pt[0] * zz % o.P, pt[1] * zzz % o.P, zz, zzz):
+            limbs += _limbs28(v * R392 % o.P + o.P, rnd)
+        pts.append(pt)
+        arrs.append((ctypes.c_uint32 * 56)(*limbs))
+    inf_arr = (ctypes.c_uint32 * 56)(*([7] * 28 + [0] * 28))
+    oa, ob = ctypes.create_string_buffer(48), ctypes.create_string_buffer(48)
+    for i in range(0, 6, 2):
+        assert lib.kzg_host_xyzz_pair_to_c48(arrs[i], arrs[i + 1], oa, ob) == 0
+        assert (oa.raw, ob.raw) == (o.g1_compress(pts[i]), o.g1_compress(pts[i + 1]))
+    assert lib.kzg_host_xyzz_pair_to_c48(arrs[0], inf_arr, oa, ob) == 0
+    assert (oa.raw, ob.raw) == (o.g1_compress(pts[0]), b"\xc0" + bytes(47))
+    assert lib.kzg_host_xyzz_pair_to_c48(inf_arr, inf_arr, oa, ob) == 0 and oa.raw == ob.raw == b"\xc0" + bytes(47)
     inf = (ctypes.c_uint32 * 56)(*([5] * 28 + [0] * 28))
     out = ctypes.create_string_buffer(48)
     assert lib.kzg_host_xyzz_to_c48(inf, out) == 0 and out.raw == b"\xc0" + bytes(47)

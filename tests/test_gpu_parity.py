@@ -518,6 +518,30 @@ def test_two_processes_sharded_msm_on_one_gpu(hip):
     eng.close()
 
 
+def test_g1_sum_of_k_partials_any_count(hip):
+    """kzg_g1_sum over k = 1..40 partial sums (the lane-parallel tree for 2..32, the one-lane form beyond), including
+    infinities (empty ranges) and repeated points (P + P inside the tree): equals the MSM over the union."""
+    lg = 10
+    n = 1 << lg
+    eng = hip()
+    tx = 0x5A5A5A5A11
+    eng.gen_srs(tx, 1, lg, 0)
+    sc = rand_scalars_bytes(n, 909)
+    step = 25
+    parts = [eng.msm_partial(sc[32 * j:32 * (j + step)], j) for j in range(0, n, step)]     # 41 partials
+    for k in (1, 2, 3, 5, 7, 8, 13, 16, 17, 31, 32, 33, 40):
+        m = min(n, k * step)
+        assert eng.g1_sum(b"".join(parts[:k])) == oc.g1_mul_gen(oc.fr_eval(sc[:32 * m], tx.to_bytes(32, "big"))), k
+    inf = eng.msm_partial(b"", 0)
+    assert inf == bytes(192)
+    assert eng.g1_sum(inf + parts[0] + inf + inf + parts[1]) == eng.g1_sum(parts[0] + parts[1])
+    assert eng.g1_sum(inf * 5) == b"\xc0" + bytes(47)
+    twice = eng.g1_sum(parts[0] * 2 + parts[1] * 2)                          # equal operands inside the tree
+    want = o.g1_mul(o.g1_decompress(eng.g1_sum(parts[0] + parts[1])), 2)
+    assert twice == o.g1_compress(want)
+    eng.close()
+
+
 def test_host_and_gpu_result_encoding_agree(hip):
     """The result point's affine conversion + compression runs on the host by default (finish_host.cpp); the GPU encoder
     (k_g1_compress[_pair], k_xyzz_pack) must give the same bytes on every entry point."""

@@ -57,6 +57,7 @@ SYMBOLS = {
     "kzg_staging_release": (_I, [_P, _I]),
     "kzg_set_host_finish": (_I, [_P, _I]),
     "kzg_host_xyzz_to_c48": (_I, [_P, _B]),
+    "kzg_host_xyzz_pair_to_c48": (_I, [_P, _P, _B, _B]),
     "kzg_host_xyzz_to_partial192": (_I, [_P, _B]),
     "kzg_g1_sum_compressed": (_I, [_P, _B, _U32, _B]),
     "kzg_set_profiling": (_I, [_P, _I]),

@@ -25,6 +25,7 @@
 
 namespace kzg_host {  // finish_host.cpp
 void xyzz_to_c48(const uint32_t* xyzz, uint8_t out48[48]);
+void xyzz_pair_to_c48(const uint32_t* xyzz0, const uint32_t* xyzz1, uint8_t out0[48], uint8_t out1[48]);
 void xyzz_to_partial192(const uint32_t* xyzz, uint8_t out192[192]);
 }  // namespace kzg_host
 
@@ -99,6 +100,8 @@ struct Lane {
     DevBuf in_be, scal, coeffA, coeffB, qbuf, hbuf, hnext, out_be;                 // request buffers
     uint8_t* tail = nullptr;      // device, TB_SIZE
     uint8_t* pin = nullptr;       // host pinned, 4096
+    uint8_t* pin_dev = nullptr;   // the same page as the GPU addresses it
+    bool sort_ws_clean = false;   // the sort's partition counts are zero (left so by every completed sort)
     hipEvent_t ev_sorted = nullptr, ev_done = nullptr, ev_coeffs = nullptr;
     int state = LANE_FREE;
     bool partial = false;         // outstanding ticket wants the 192-byte partial
@@ -248,7 +251,11 @@ struct LaneHold {
         if (li < 0) return;
         if (!clean) {
             (void)hipStreamSynchronize(ctx->lane[li].stream);
-            if (li2 >= 0) (void)hipStreamSynchronize(ctx->lane[li2].stream);
+            ctx->lane[li].sort_ws_clean = false;
+            if (li2 >= 0) {
+                (void)hipStreamSynchronize(ctx->lane[li2].stream);
+                ctx->lane[li2].sort_ws_clean = false;
+            }
             (void)hipGetLastError();
         }
         if (all) { lanes_release_all(ctx); return; }
@@ -389,13 +396,13 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
     {
         Span sp(ctx, L, KZG_T_DIGITS);
         HIPCHK(ctx, hipMemsetAsync(L.bufA.p, 0, B * sizeof(g1_xyzz_t), s));
-        launch_msm_sort(s, sh, scalars, mont, scalars2, mont2, L.hist.as<uint32_t>(), L.rank.as<uint2>(),
-                        L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>());
+        launch_msm_sort(s, sh, scalars, mont, scalars2, mont2, L.hist.as<uint32_t>(), L.sort_ws_clean, L.rank.as<uint2>(),
+                        L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(), max_len_d);
+        L.sort_ws_clean = true;
         // the longest run of carries decides how many fold steps are launched; it depends on the offsets only, so
         // its 4-byte read-back completes while the accumulate kernel runs and costs no bubble
-        HIPCHK(ctx, hipMemsetAsync(max_len_d, 0, 4, s));
         launch_fold_maxlen(s, L.offsets.as<uint32_t>(), sh.nbuckets, (uint32_t)sh.chunk, max_len_d);
-        HIPCHK(ctx, hipMemcpyAsync(max_len_h, max_len_d, 4, hipMemcpyDeviceToHost, s));
+        launch_publish(s, max_len_d, L.pin_dev + PIN_MAXLEN, 4);
         HIPCHK(ctx, hipEventRecord(L.ev_sorted, s));
     }
     {
@@ -447,7 +454,7 @@ int clear_flags(kzg_ctx* ctx, Lane& L) {
 // ends a request: the lane's tail record comes back in ONE copy (result points, eval, flags, GPU-side encodings)
 int finish(kzg_ctx* ctx, Lane& L) {
     prof_close(ctx, L);
-    HIPCHK(ctx, hipMemcpyAsync(L.pin, L.tail, TB_COPY, hipMemcpyDeviceToHost, L.stream));
+    launch_publish(L.stream, L.tail, L.pin_dev, TB_COPY);
     HIPCHK(ctx, hipStreamSynchronize(L.stream));
     prof_end(ctx, L);
     const uint32_t* f = reinterpret_cast<const uint32_t*>(L.pin + TB_FLAGS);
@@ -585,8 +592,8 @@ int commit_open_dev(kzg_ctx* ctx, LaneHold& H, uint32_t i, const uint32_t* row_d
             launch_fr_to_be(so, y_m, A.tail + TB_EVAL, 1, 1);
         }
         if (batched) {
-            // the quotient has T - 1 coefficients; a zero in slot T - 1 lets it ride as a second length-T scalar set
-            HIPCHK(ctx, hipMemsetAsync(O.qbuf.as<uint32_t>() + 8 * (T - 1), 0, 32, s));
+            // the quotient has T - 1 coefficients; k_poly_quotient leaves a zero in slot T - 1, so it rides as a second
+            // length-T scalar set
             rc = msm_core(ctx, A, coeffs, 1, T, offset, res, O.qbuf.as<uint32_t>(), 0);
         } else {
             rc = msm_core(ctx, O, O.qbuf.as<uint32_t>(), 0, T - 1, offset, res + 1);
@@ -600,11 +607,14 @@ int commit_open_dev(kzg_ctx* ctx, LaneHold& H, uint32_t i, const uint32_t* row_d
     queue_encode(ctx, A, out_c48 != nullptr, out_p48 != nullptr);
     rc = finish(ctx, A);
     if (rc) return rc;
-    if (out_c48) result_c48(ctx, A, 0, out_c48);
-    if (out_p48) {
-        result_c48(ctx, A, 1, out_p48);
-        memcpy(out_eval32, A.pin + TB_EVAL, 32);
+    if (out_c48 && out_p48 && ctx->host_finish)     // both points, one shared inversion
+        kzg_host::xyzz_pair_to_c48(reinterpret_cast<const uint32_t*>(A.pin + TB_RES0),
+                                   reinterpret_cast<const uint32_t*>(A.pin + TB_RES1), out_c48, out_p48);
+    else {
+        if (out_c48) result_c48(ctx, A, 0, out_c48);
+        if (out_p48) result_c48(ctx, A, 1, out_p48);
     }
+    if (out_p48) memcpy(out_eval32, A.pin + TB_EVAL, 32);
     H.clean = true;
     return KZG_OK;
 }
@@ -807,6 +817,7 @@ int kzg_create(int device_id, kzg_ctx** out) {
         ok = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess &&
              hipMalloc((void**)&L.tail, TB_SIZE) == hipSuccess && hipMemset(L.tail, 0, TB_SIZE) == hipSuccess &&
              hipHostMalloc((void**)&L.pin, 4096, hipHostMallocDefault) == hipSuccess &&
+             hipHostGetDevicePointer((void**)&L.pin_dev, L.pin, 0) == hipSuccess &&
              hipEventCreateWithFlags(&L.ev_sorted, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&L.ev_coeffs, hipEventDisableTiming) == hipSuccess;
@@ -1255,12 +1266,13 @@ int kzg_msm_submit(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, int 
         if (partial) queue_pack(ctx, L);
         else queue_encode(ctx, L, true, false);
         prof_close(ctx, L);
-        hipError_t e = hipMemcpyAsync(L.pin, L.tail, TB_COPY, hipMemcpyDeviceToHost, L.stream);
-        if (e == hipSuccess) e = hipEventRecord(L.ev_done, L.stream);
+        launch_publish(L.stream, L.tail, L.pin_dev, TB_COPY);
+        hipError_t e = hipEventRecord(L.ev_done, L.stream);
         if (e == hipSuccess) e = hipGetLastError();
         if (e != hipSuccess) rc = fail(ctx, KZG_E_HIP, std::string("kzg_msm_submit: ") + hipGetErrorString(e));
     }
     if (rc) {  // nothing may still be running on the lane's buffers when it becomes reusable
+        L.sort_ws_clean = false;
         (void)hipStreamSynchronize(L.stream);
         (void)hipGetLastError();
         lane_release(ctx, li);
@@ -1443,8 +1455,8 @@ int kzg_proto_baff(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint
     for (auto& e : ev) HIPCHK(ctx, hipEventCreate(&e));
     HIPCHK(ctx, hipMemsetAsync(L.bufA.p, 0, B * sizeof(g1_xyzz_t), s));
     HIPCHK(ctx, hipEventRecord(ev[0], s));
-    launch_msm_sort(s, sh, ctx->slot[slot].as<uint32_t>(), ctx->slot_mont[slot], nullptr, 0, L.hist.as<uint32_t>(),
-                    L.rank.as<uint2>(), L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>());
+    launch_msm_sort(s, sh, ctx->slot[slot].as<uint32_t>(), ctx->slot_mont[slot], nullptr, 0, L.hist.as<uint32_t>(), false,
+                    L.rank.as<uint2>(), L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(), L.flags() + 2);
     HIPCHK(ctx, hipEventRecord(ev[1], s));
     uint32_t entries = 0;
     HIPCHK(ctx, hipMemcpyAsync(&entries, L.offsets.as<uint32_t>() + B, 4, hipMemcpyDeviceToHost, s));
@@ -1483,6 +1495,12 @@ int kzg_proto_baff(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint
 int kzg_host_xyzz_to_c48(const uint32_t xyzz_limbs28[56], uint8_t out48[48]) {
     if (!xyzz_limbs28 || !out48) return KZG_E_ARG;
     kzg_host::xyzz_to_c48(xyzz_limbs28, out48);
+    return KZG_OK;
+}
+int kzg_host_xyzz_pair_to_c48(const uint32_t a_limbs28[56], const uint32_t b_limbs28[56], uint8_t out_a48[48],
+                              uint8_t out_b48[48]) {
+    if (!a_limbs28 || !b_limbs28 || !out_a48 || !out_b48) return KZG_E_ARG;
+    kzg_host::xyzz_pair_to_c48(a_limbs28, b_limbs28, out_a48, out_b48);
     return KZG_OK;
 }
 int kzg_host_xyzz_to_partial192(const uint32_t xyzz_limbs28[56], uint8_t out192[192]) {

@@ -61,24 +61,47 @@ static bool limbs_all_zero(const uint32_t* l) {
     return t == 0;
 }
 
-// xyzz: 56 words (X, Y, ZZ, ZZZ); ZZ all-zero limbs = infinity
-void xyzz_to_c48(const uint32_t* xyzz, uint8_t out48[48]) {
-    if (limbs_all_zero(xyzz + 28)) {
-        memset(out48, 0, 48);
-        out48[0] = 0xC0;
-        return;
-    }
-    // the common factor 2^392 of the four residues cancels in X/ZZ and Y/ZZZ
-    const Fp X = fp_from_limbs28(xyzz), Y = fp_from_limbs28(xyzz + 14), ZZ = fp_from_limbs28(xyzz + 28),
-             ZZZ = fp_from_limbs28(xyzz + 42);
-    const Fp i = inv(ZZ * ZZZ);
-    const Fp x = X * (i * ZZZ), y = Y * (i * ZZ);
+static void affine_to_c48(const Fp& x, const Fp& y, uint8_t out48[48]) {
     u64 yl[6], twice[6];
     fp_to_limbs(yl, y);
     const u64 c = add6(twice, yl, yl);
     const bool larger = c || ge6(twice, PM);  // y > (p - 1) / 2  <=>  2y >= p
     fp_to_be48(out48, x);
     out48[0] |= larger ? 0xA0 : 0x80;
+}
+static void infinity_c48(uint8_t out48[48]) {
+    memset(out48, 0, 48);
+    out48[0] = 0xC0;
+}
+// xyzz: 56 words (X, Y, ZZ, ZZZ); ZZ all-zero limbs = infinity
+void xyzz_to_c48(const uint32_t* xyzz, uint8_t out48[48]) {
+    if (limbs_all_zero(xyzz + 28)) {
+        infinity_c48(out48);
+        return;
+    }
+    // the common factor 2^392 of the four residues cancels in X/ZZ and Y/ZZZ
+    const Fp X = fp_from_limbs28(xyzz), Y = fp_from_limbs28(xyzz + 14), ZZ = fp_from_limbs28(xyzz + 28),
+             ZZZ = fp_from_limbs28(xyzz + 42);
+    const Fp i = inv(ZZ * ZZZ);
+    affine_to_c48(X * (i * ZZZ), Y * (i * ZZ), out48);
+}
+// the two points of a commit+open share ONE inversion (Montgomery's trick)
+void xyzz_pair_to_c48(const uint32_t* xyzz0, const uint32_t* xyzz1, uint8_t out0[48], uint8_t out1[48]) {
+    const bool inf0 = limbs_all_zero(xyzz0 + 28), inf1 = limbs_all_zero(xyzz1 + 28);
+    if (inf0 || inf1) {
+        xyzz_to_c48(xyzz0, out0);
+        xyzz_to_c48(xyzz1, out1);
+        return;
+    }
+    const Fp X0 = fp_from_limbs28(xyzz0), Y0 = fp_from_limbs28(xyzz0 + 14), ZZ0 = fp_from_limbs28(xyzz0 + 28),
+             ZZZ0 = fp_from_limbs28(xyzz0 + 42);
+    const Fp X1 = fp_from_limbs28(xyzz1), Y1 = fp_from_limbs28(xyzz1 + 14), ZZ1 = fp_from_limbs28(xyzz1 + 28),
+             ZZZ1 = fp_from_limbs28(xyzz1 + 42);
+    const Fp d0 = ZZ0 * ZZZ0, d1 = ZZ1 * ZZZ1;
+    const Fp i = inv(d0 * d1);
+    const Fp i0 = i * d1, i1 = i * d0;   // 1 / d0, 1 / d1
+    affine_to_c48(X0 * (i0 * ZZZ0), Y0 * (i0 * ZZ0), out0);
+    affine_to_c48(X1 * (i1 * ZZZ1), Y1 * (i1 * ZZ1), out1);
 }
 // 192-byte partial-sum record: X, Y, ZZ, ZZZ as canonical residues (still Montgomery, R = 2^392), 12 x u32 LE each;
 // all zeros = infinity (include/kzg_mi355x.h, kzg_msm_partial)

@@ -394,6 +394,10 @@ __global__ void __launch_bounds__(256) k_poly_quotient(const uint32_t* __restric
             fr9_store(q_canon + 8 * (j - 1), o);
         }
     }
+    if (hi == n) {  // slot n - 1: a zero, so that the n - 1 coefficients can ride as a length-n scalar set (batched commit+open)
+        fr9_zero(o);
+        fr9_store(q_canon + 8 * (n - 1), o);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ launchers

@@ -117,10 +117,13 @@ __global__ void __launch_bounds__(1024) k_sort_count(const uint32_t* __restrict_
     for (uint32_t i = threadIdx.x; i < npart; i += 1024)
         if (h[i]) atomicAdd(&part_count[i], h[i]);
 }
-// part_base[0..npart] = exclusive scan of part_count (npart <= 4096); cursors zeroed
-__global__ void __launch_bounds__(1024) k_sort_part_scan(const uint32_t* __restrict__ part_count, uint32_t npart,
+// part_base[0..npart] = exclusive scan of part_count (npart <= 4096); cursors zeroed.  Housekeeping that would otherwise
+// be three more memsets on the stream (~4.5 us each, and short rows are nothing but such latencies): the counts are
+// zeroed again once read (so the NEXT sort finds them clean) and the fold-depth word of this MSM is reset.
+__global__ void __launch_bounds__(1024) k_sort_part_scan(uint32_t* __restrict__ part_count, uint32_t npart,
                                                           uint32_t* __restrict__ part_base,
-                                                          uint32_t* __restrict__ part_cursor) {
+                                                          uint32_t* __restrict__ part_cursor,
+                                                          uint32_t* __restrict__ max_len_word) {
     __shared__ uint32_t part[1024];
     const uint32_t t = threadIdx.x;
     const uint32_t per = (npart + 1023u) / 1024u;
@@ -140,8 +143,10 @@ __global__ void __launch_bounds__(1024) k_sort_part_scan(const uint32_t* __restr
         part_base[i] = run;
         part_cursor[i] = 0;
         run += part_count[i];
+        part_count[i] = 0;
     }
     if (t == 1023) part_base[npart] = part[1023];
+    if (t == 0) *max_len_word = 0;
 }
 __global__ void __launch_bounds__(256) k_sort_partition(const uint32_t* __restrict__ scalars, const SortShape ss,
                                                          const WinLayout lay, const uint32_t* __restrict__ part_base,
@@ -885,6 +890,27 @@ __global__ void __launch_bounds__(64) k_g1_sum(const g1_xyzz_t* __restrict__ in,
     if (tid == 0) store_xyzz(out, acc);
 }
 
+// sum of up to 32 XYZZ points by lane-parallel additions (one wave per addition, log2 depth of ~2 us steps): the sum of
+// the all_gathered partials of an SRS-sharded MSM is on every step's critical path (8 ranks: 3 levels instead of the
+// 4 x 16 us of dependent one-lane additions of k_g1_sum)
+__global__ void __launch_bounds__(512) k_g1_sum_lp(const g1_xyzz_t* __restrict__ in, uint32_t count,
+                                                    g1_xyzz_t* __restrict__ out) {
+    tail_priority();
+    __shared__ LpScratch sm[8];
+    __shared__ g1_xyzz_t pts[32];
+    const LpLane k = lp_lane();
+    const int w = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (uint32_t i = threadIdx.x; i < 32 * 56; i += 512)
+        reinterpret_cast<uint32_t*>(pts)[i] = i < count * 56 ? reinterpret_cast<const uint32_t*>(in)[i] : 0u;   // zeros = infinity
+    __syncthreads();
+    for (int d = 16; d >= 1; d >>= 1) {
+        if ((uint32_t)d < count)
+            for (int l = w; l < d; l += 8)
+                if ((uint32_t)(l + d) < count) lp_add(sm[w], &pts[l], &pts[l], &pts[l + d], k);
+        __syncthreads();
+    }
+    if (threadIdx.x < 56) reinterpret_cast<uint32_t*>(out)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&pts[0])[threadIdx.x];
+}
 // sum of `count` affine points (table-row format: the output of k_srs_from_c48): Pianist's master aggregation
 // sum_i commit_i over the worker rows (reference neurons/validator.py:196-198, README.md:38)
 __global__ void __launch_bounds__(64) k_g1_sum_affine(const g1_affine_t* __restrict__ in, uint32_t count,
@@ -946,6 +972,11 @@ __global__ void __launch_bounds__(64) k_g1_compress_pair(const g1_xyzz_t* __rest
     }
     g1_compress(out0, a0);
     g1_compress(out1, a1);
+}
+// the lane's tail record -> its pinned host page (device-visible host memory): a 1-wave store instead of a copy-engine
+// transfer (~16 us on this stack for 832 bytes); the stream synchronisation that follows makes it visible to the host
+__global__ void __launch_bounds__(256) k_publish(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst_host, uint32_t words) {
+    for (uint32_t i = threadIdx.x; i < words; i += 256) dst_host[i] = src[i];
 }
 // XYZZ working form <-> the 192-byte partial-sum format of the C-ABI (4 x 12 u32: canonical Montgomery residues)
 __global__ void __launch_bounds__(64) k_xyzz_pack(const g1_xyzz_t* __restrict__ in, uint32_t* __restrict__ out48w,
@@ -1286,8 +1317,8 @@ __global__ void __launch_bounds__(256) k_batch_affine(const g1_xyzz_t* __restric
 static inline uint32_t nblk(uint64_t n, uint32_t b) { return (uint32_t)((n + b - 1) / b); }
 
 void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars, int scalars_mont,
-                     const uint32_t* scalars2, int scalars2_mont, uint32_t* part_ws, uint2* parted, uint32_t* offsets,
-                     uint32_t* sorted) {
+                     const uint32_t* scalars2, int scalars2_mont, uint32_t* part_ws, bool part_ws_clean, uint2* parted,
+                     uint32_t* offsets, uint32_t* sorted, uint32_t* max_len_word) {
     const int setbits = sh.nbatch > 1 ? 1 : 0;
     const int keybits = sh.c - 1 + setbits;
     SortShape ss;
@@ -1307,11 +1338,11 @@ void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars,
     uint32_t* part_count = part_ws;                      // [npart]
     uint32_t* part_base = part_ws + SORT_MAXPART;        // [npart + 1]
     uint32_t* part_cursor = part_ws + 2 * SORT_MAXPART + 8;
-    (void)hipMemsetAsync(part_count, 0, npart * 4, s);
+    if (!part_ws_clean) (void)hipMemsetAsync(part_count, 0, SORT_MAXPART * 4, s);   // afterwards k_sort_part_scan keeps it zero
     const uint32_t blocks = nblk(ss.total, ss.spb);
     if (ss.total > (1u << 18)) k_sort_count<4><<<nblk(ss.total, 4096), 1024, 0, s>>>(scalars, ss, sh.lay, part_count);
     else k_sort_count<1><<<nblk(ss.total, 1024), 1024, 0, s>>>(scalars, ss, sh.lay, part_count);
-    k_sort_part_scan<<<1, 1024, 0, s>>>(part_count, npart, part_base, part_cursor);
+    k_sort_part_scan<<<1, 1024, 0, s>>>(part_count, npart, part_base, part_cursor, max_len_word);
     if (sh.nwin <= SORT1_MAXW) {
         uint32_t spb2 = (SORT1_STAGE / (uint32_t)sh.nwin) & ~63u;  // one scalar per lane, <= SORT1_STAGE entries
         if (spb2 > 1024) spb2 = 1024;
@@ -1374,7 +1405,8 @@ void launch_msm_final(hipStream_t s, const g1_xyzz_t* node, const g1_xyzz_t* pre
 #endif
 }
 void launch_g1_sum(hipStream_t s, const g1_xyzz_t* in, uint32_t count, g1_xyzz_t* out_xyzz) {
-    k_g1_sum<<<1, 64, 0, s>>>(in, count, out_xyzz);
+    if (count >= 2 && count <= 32) k_g1_sum_lp<<<1, 512, 0, s>>>(in, count, out_xyzz);
+    else k_g1_sum<<<1, 64, 0, s>>>(in, count, out_xyzz);
 }
 void launch_g1_sum_affine(hipStream_t s, const g1_affine_t* in, uint32_t count, g1_xyzz_t* out_xyzz) {
     k_g1_sum_affine<<<1, 64, 0, s>>>(in, count, out_xyzz);
@@ -1384,6 +1416,9 @@ void launch_g1_compress(hipStream_t s, const g1_xyzz_t* in, uint8_t* out48) {
 }
 void launch_g1_compress_pair(hipStream_t s, const g1_xyzz_t* in0, const g1_xyzz_t* in1, uint8_t* out0, uint8_t* out1) {
     k_g1_compress_pair<<<1, 64, 0, s>>>(in0, in1, out0, out1);
+}
+void launch_publish(hipStream_t s, const void* src_dev, void* dst_host_devptr, uint32_t bytes) {
+    k_publish<<<1, 256, 0, s>>>(reinterpret_cast<const uint32_t*>(src_dev), reinterpret_cast<uint32_t*>(dst_host_devptr), bytes / 4);
 }
 void launch_xyzz_pack(hipStream_t s, const g1_xyzz_t* in, uint32_t* out48w, uint32_t count) {
     if (count) k_xyzz_pack<<<nblk(count, 64), 64, 0, s>>>(in, out48w, count);
