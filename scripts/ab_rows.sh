@@ -6,7 +6,7 @@ cp zkp_subnet_amd/libkzg_mi355x.so /tmp/_orig.so
 for r in $(seq $ROUNDS); do
   for v in ${VARIANTS:-A B}; do
     cp zkp_subnet_amd/ab/$v.so zkp_subnet_amd/libkzg_mi355x.so
-    python bench.py --no-adversarial --no-cpu-baseline --no-pipelined --steps 20 --kzg-rows 22,20,16,12 2>/dev/null | tail -1 | python -c "
+    python bench.py --no-adversarial --no-cpu-baseline --no-pipelined --steps 20 --kzg-rows ${ROWS:-22,20,16,12} 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 s=d['stages_ms']

@@ -342,11 +342,14 @@ void set_window(kzg_ctx* ctx, int c) {
 // lanes (2 waves per SIMD on 256 CUs: the second wave hides the point loads) so that the last round is not a partially
 // filled tail; chunks stay <= 512 entries.  Small MSMs (latency-bound: one wave already saturates a SIMD's integer
 // issue, ~10.5 us per mixed addition): 65536 lanes = one wave per SIMD, which halves the number of carries to fold.
+#ifndef KZG_MIN_CHUNK
+#define KZG_MIN_CHUNK 8
+#endif
 int pick_chunk(uint64_t entries) {
     const uint64_t lanes = 131072;
     if (entries <= lanes * 16) {
         const uint64_t k = (entries + lanes / 2 - 1) / (lanes / 2);
-        return (int)(k < 8 ? 8 : k);
+        return (int)(k < KZG_MIN_CHUNK ? KZG_MIN_CHUNK : k);
     }
     const uint64_t rounds = (entries + lanes * 512 - 1) / (lanes * 512);
     const uint64_t k = (entries + lanes * rounds - 1) / (lanes * rounds);
