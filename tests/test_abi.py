@@ -180,3 +180,47 @@ def test_host_encoder_matches_oracle(lib):
     assert lib.kzg_host_xyzz_to_c48(inf, out) == 0 and out.raw == b"\xc0" + bytes(47)
     part = ctypes.create_string_buffer(192)
     assert lib.kzg_host_xyzz_to_partial192(inf, part) == 0 and part.raw == bytes(192)
+
+
+_WIRE_EXHAUSTIVE = r'''
+import base64, os, sys
+sys.path.insert(0, %r)
+from zkp_subnet_amd import codec
+w = codec._wire
+assert w is not None
+A = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/"
+good = base64.b64encode(bytes(range(7, 39))).decode().rstrip("=")
+for pos in range(43):
+    for b in range(1, 128):
+        s = good[:pos] + chr(b) + good[pos + 1:]
+        ok = chr(b) in A and not (A.index(s[42]) & 3)
+        want = base64.b64decode(s + "=") if ok else None
+        try:
+            got = w.decode_fr_list([s])
+        except ValueError:
+            got = None
+        assert got == want, (pos, b)
+for n in (1, 5, 1023, 1024, 5000):
+    raw = os.urandom(32 * n)
+    assert w.decode_fr_list(codec.be32_to_fr_list(raw)) == raw
+print("simd", w.simd_level())
+'''
+
+
+def test_wire_decoder_every_byte_in_every_position_both_paths():
+    """The AVX2 base64 decoder (csrc/wire_py.c, SURVEY 8f-4) and the scalar one accept exactly the 64 alphabet
+    characters in every one of the 43 positions (and only a last character whose low two bits are zero), and produce
+    Python's bytes.  Each path runs in its own interpreter (the choice is made at import)."""
+    import subprocess
+    import sys
+
+    from zkp_subnet_amd.build import build_wire
+
+    build_wire()
+    seen = set()
+    for env_extra in ({}, {"KZG_WIRE_NO_AVX2": "1"}):
+        out = subprocess.run([sys.executable, "-c", _WIRE_EXHAUSTIVE % ROOT], capture_output=True, text=True, timeout=300,
+                             env=dict(os.environ, **env_extra))
+        assert out.returncode == 0, out.stderr[-2000:]
+        seen.add(out.stdout.strip().splitlines()[-1])
+    assert "simd 0" in seen          # the scalar path was exercised; "simd 2" too wherever the CPU has AVX2
