@@ -1,6 +1,7 @@
-"""Randomised cross-check of the HIP path against the C oracle (dev tool; needs the GPU):
+"""Randomised cross-check of the HIP path against the C oracle (not collected by pytest; needs the GPU; lives under
+tests/ because it uses the oracle):
 MSM (random size / window / scalar distribution / offset), NTT round trips and oracle equality, commit / open /
-commit+open on random rows incl. special alphas.  `python scripts/fuzz_gpu.py [seconds] [seed]`"""
+commit+open on random rows incl. special alphas.  `python tests/fuzz_gpu.py [seconds] [seed]`"""
 import os
 import random
 import sys
