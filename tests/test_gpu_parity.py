@@ -607,6 +607,38 @@ def test_aggregate_commitments_and_api_commit_on_hip_engine(hip):
     miner.stop()
 
 
+def test_mainnet_configuration_scale_24_machines_scale_8(hip):
+    """The reference's mainnet prover flags (Makefile:63-74: --scale 24 --machines_scale 8): the whole 2^24-point SRS
+    resident as 256 worker slices of T = 2^16 (16 window tables: 34 GB), commit+open of full-length rows for several
+    worker indices, each bit-exact against the trapdoor identities with L_i(tau_y) of ITS slice."""
+    scale, ms = 24, 8
+    T = 1 << (scale - ms)
+    eng = hip()
+    tx, ty = 0x24242424DEADBEEF2424, 0x80808080CAFE
+    eng.gen_srs(tx, ty, scale, ms)
+    assert eng.srs_points == 1 << 24 and eng.window == 16
+    alpha_b = rand_scalars_bytes(1, 2408)
+    alpha = int.from_bytes(alpha_b, "big")
+    txb = tx.to_bytes(32, "big")
+    for i in (0, 1, 137, 255):
+        row = rand_scalars_bytes(T, 2400 + i)
+        c, ev, pf = eng.commit_open(i, row, alpha_b, True)
+        coeffs_b = oc.fr_ntt(row, True)
+        y = oc.fr_eval(coeffs_b, alpha_b)
+        ft = int.from_bytes(oc.fr_eval(coeffs_b, txb), "big")
+        li = o.lagrange_at(i, 1 << ms, ty)
+        assert ev == y
+        assert c == oc.g1_mul_gen((li * ft % o.R).to_bytes(32, "big")), i
+        qt = (ft - int.from_bytes(y, "big")) * o.fr_inv(tx - alpha) % o.R
+        assert pf == oc.g1_mul_gen((li * qt % o.R).to_bytes(32, "big")), i
+        assert eng.verify(i, pf, alpha_b, ev, c)
+    # spot-check resident points of the last slice against the oracle's fixed-base multiplication
+    for j in (0, T - 1):
+        want = o.g1_table().mul(pow(tx, j, o.R) * o.lagrange_at(255, 1 << ms, ty) % o.R)
+        assert eng.srs_read(255 * T + j, 1) == o.g1_to_be96(want)
+    eng.close()
+
+
 def test_client_and_miner_on_hip_engine(hip, fr_kat):
     """The reference miner test (tests/test_miner.py:62-121) on the HIP engine: 16-coefficient TEST_POLY at
     scale 6 / machines_scale 2; forward() returns the client's commitment and proof; oracle agrees bit for bit."""
