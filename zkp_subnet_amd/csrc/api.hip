@@ -398,13 +398,12 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
     uint32_t* max_len_h = reinterpret_cast<uint32_t*>(L.pin + PIN_MAXLEN);
     {
         Span sp(ctx, L, KZG_T_DIGITS);
-        HIPCHK(ctx, hipMemsetAsync(L.bufA.p, 0, B * sizeof(g1_xyzz_t), s));
         launch_msm_sort(s, sh, scalars, mont, scalars2, mont2, L.hist.as<uint32_t>(), L.sort_ws_clean, L.rank.as<uint2>(),
                         L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(), max_len_d);
         L.sort_ws_clean = true;
         // the longest run of carries decides how many fold steps are launched; it depends on the offsets only, so
         // its 4-byte read-back completes while the accumulate kernel runs and costs no bubble
-        launch_fold_maxlen(s, L.offsets.as<uint32_t>(), sh.nbuckets, (uint32_t)sh.chunk, max_len_d);
+        launch_fold_maxlen(s, L.offsets.as<uint32_t>(), sh.nbuckets, (uint32_t)sh.chunk, max_len_d, L.bufA.as<g1_xyzz_t>());
         launch_publish(s, max_len_d, L.pin_dev + PIN_MAXLEN, 4);
         HIPCHK(ctx, hipEventRecord(L.ev_sorted, s));
     }
@@ -819,7 +818,8 @@ int kzg_create(int device_id, kzg_ctx** out) {
         L.index = l;
         ok = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess &&
              hipMalloc((void**)&L.tail, TB_SIZE) == hipSuccess && hipMemset(L.tail, 0, TB_SIZE) == hipSuccess &&
-             hipHostMalloc((void**)&L.pin, 4096, hipHostMallocDefault) == hipSuccess &&
+             // coherent (fine-grained) and mapped: k_publish stores results straight into this page
+             hipHostMalloc((void**)&L.pin, 4096, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
              hipHostGetDevicePointer((void**)&L.pin_dev, L.pin, 0) == hipSuccess &&
              hipEventCreateWithFlags(&L.ev_sorted, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) == hipSuccess &&

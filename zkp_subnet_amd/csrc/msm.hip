@@ -451,13 +451,22 @@ KZG_DEV bool carry_pos(const uint32_t* __restrict__ offsets, const uint32_t* __r
     len = t1 - t0;
     return true;
 }
-// longest carry run, from the bucket offsets alone (so it can be read back while the accumulate kernel runs)
+// longest carry run, from the bucket offsets alone (so it can be read back while the accumulate kernel runs).  The same
+// pass marks the EMPTY buckets as infinity: the accumulate kernel stores every non-empty bucket exactly once (the lane in
+// whose chunk its run begins), so nothing else needs clearing -- this replaces a memset of the whole bucket array
+// (117 MB, ~25 us, at c = 20) by stores for the buckets that actually are empty (none for well-spread scalars).
 __global__ void __launch_bounds__(256) k_fold_maxlen(const uint32_t* __restrict__ offsets, uint32_t nbuckets,
-                                                      uint32_t chunk, uint32_t* __restrict__ max_len) {
+                                                      uint32_t chunk, uint32_t* __restrict__ max_len,
+                                                      g1_xyzz_t* __restrict__ buckets) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nbuckets) return;
     const uint32_t lo = offsets[b], hi = offsets[b + 1];
-    if (hi == lo) return;
+    if (hi == lo) {
+        uint4* q = reinterpret_cast<uint4*>(&buckets[b]);
+#pragma unroll
+        for (int i = 0; i < 14; i++) q[i] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
     const uint32_t len = (hi - 1u) / chunk - lo / chunk;
     if (len > 1) atomicMax(max_len, len);
 }
@@ -1360,8 +1369,9 @@ void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t*
     k_msm_accumulate<<<nblk(nchunks, 256), 256, 0, s>>>(table, offsets, sorted, sh.nbuckets, (uint32_t)sh.chunk,
                                                         nchunks, buckets, carries, carry_key);
 }
-void launch_fold_maxlen(hipStream_t s, const uint32_t* offsets, uint32_t nbuckets, uint32_t chunk, uint32_t* max_len) {
-    k_fold_maxlen<<<nblk(nbuckets, 256), 256, 0, s>>>(offsets, nbuckets, chunk, max_len);
+void launch_fold_maxlen(hipStream_t s, const uint32_t* offsets, uint32_t nbuckets, uint32_t chunk, uint32_t* max_len,
+                        g1_xyzz_t* buckets) {
+    k_fold_maxlen<<<nblk(nbuckets, 256), 256, 0, s>>>(offsets, nbuckets, chunk, max_len, buckets);
 }
 #ifndef KZG_FOLD_COOP_MAX
 #define KZG_FOLD_COOP_MAX 32768

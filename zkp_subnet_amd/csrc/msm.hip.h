@@ -49,7 +49,9 @@ void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t*
                            uint32_t nchunks);
 // carries -> buckets: per-bucket binary tree over the carries (positions derived from the bucket offsets).
 // max_len: device word, maximum number of carries of one bucket (stays 0 when every run has <= 1 carry)
-void launch_fold_maxlen(hipStream_t s, const uint32_t* offsets, uint32_t nbuckets, uint32_t chunk, uint32_t* max_len);
+// (also marks the empty buckets as infinity: the bucket array needs no memset)
+void launch_fold_maxlen(hipStream_t s, const uint32_t* offsets, uint32_t nbuckets, uint32_t chunk, uint32_t* max_len,
+                        g1_xyzz_t* buckets);
 void launch_fold_step(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
                       uint32_t nchunks, uint32_t d, g1_xyzz_t* carries);
 void launch_fold_heads(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
