@@ -102,6 +102,7 @@ struct Lane {
     uint8_t* pin = nullptr;       // host pinned, 4096
     uint8_t* pin_dev = nullptr;   // the same page as the GPU addresses it
     bool sort_ws_clean = false;   // the sort's partition counts are zero (left so by every completed sort)
+    int skew_hint = 0;            // > 0: the last fast sort overflowed (skewed scalars): go straight to the exact sort
     hipEvent_t ev_sorted = nullptr, ev_done = nullptr, ev_coeffs = nullptr;
     int state = LANE_FREE;
     bool partial = false;         // outstanding ticket wants the 192-byte partial
@@ -384,7 +385,12 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
     sh.srs_offset = srs_offset; sh.srs_stride = ctx->stride; sh.chunk = pick_chunk(entries);
     const uint32_t nchunks = (uint32_t)((entries + sh.chunk - 1) / sh.chunk);
     const size_t B = sh.nbuckets;
-    HIPCHK(ctx, L.rank.ensure(entries * 8));          // partitioned (key_low, value) pairs
+    // Sort mode.  Fast: no count pass, fixed-capacity partition regions -- right for well-spread scalars (field elements
+    // of a polynomial), wrong for skewed ones, where a region overflows: that is detected on the device, costs one wasted
+    // sort (the queued accumulate sees an empty MSM), and is remembered for the lane's next few calls.
+    bool fast = msm_sort_fast_ok(sh) && L.skew_hint == 0;
+    if (L.skew_hint > 0) L.skew_hint--;
+    HIPCHK(ctx, L.rank.ensure(msm_sort_parted_entries(sh, msm_sort_fast_ok(sh)) * 8));   // partitioned (key_low, value) pairs
     HIPCHK(ctx, L.sorted.ensure(entries * 4));
     HIPCHK(ctx, L.hist.ensure(16384 * 4));
     HIPCHK(ctx, L.offsets.ensure((B + 1) * 4));
@@ -399,12 +405,12 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
     {
         Span sp(ctx, L, KZG_T_DIGITS);
         launch_msm_sort(s, sh, scalars, mont, scalars2, mont2, L.hist.as<uint32_t>(), L.sort_ws_clean, L.rank.as<uint2>(),
-                        L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(), max_len_d);
+                        L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(), max_len_d, fast, max_len_d + 1);
         L.sort_ws_clean = true;
         // the longest run of carries decides how many fold steps are launched; it depends on the offsets only, so
-        // its 4-byte read-back completes while the accumulate kernel runs and costs no bubble
+        // its read-back (with the sort's overflow word) completes while the accumulate kernel runs and costs no bubble
         launch_fold_maxlen(s, L.offsets.as<uint32_t>(), sh.nbuckets, (uint32_t)sh.chunk, max_len_d, L.bufA.as<g1_xyzz_t>());
-        launch_publish(s, max_len_d, L.pin_dev + PIN_MAXLEN, 4);
+        launch_publish(s, max_len_d, L.pin_dev + PIN_MAXLEN, 8);
         HIPCHK(ctx, hipEventRecord(L.ev_sorted, s));
     }
     {
@@ -413,6 +419,23 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
                               L.bufA.as<g1_xyzz_t>(), L.carries.as<g1_xyzz_t>(), L.carry_key.as<uint32_t>(), nchunks);
     }
     HIPCHK(ctx, hipEventSynchronize(L.ev_sorted));
+    if (fast && max_len_h[1]) {   // a region overflowed: skewed scalars.  Exact sort + accumulate once more.
+        L.skew_hint = 16;
+        {
+            Span sp(ctx, L, KZG_T_DIGITS);
+            launch_msm_sort(s, sh, scalars, mont, scalars2, mont2, L.hist.as<uint32_t>(), true, L.rank.as<uint2>(),
+                            L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(), max_len_d, false, max_len_d + 1);
+            launch_fold_maxlen(s, L.offsets.as<uint32_t>(), sh.nbuckets, (uint32_t)sh.chunk, max_len_d, L.bufA.as<g1_xyzz_t>());
+            launch_publish(s, max_len_d, L.pin_dev + PIN_MAXLEN, 8);
+            HIPCHK(ctx, hipEventRecord(L.ev_sorted, s));
+        }
+        {
+            Span sp(ctx, L, KZG_T_ACCUMULATE);
+            launch_msm_accumulate(s, sh, ctx->table.as<g1_affine_t>(), L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(),
+                                  L.bufA.as<g1_xyzz_t>(), L.carries.as<g1_xyzz_t>(), L.carry_key.as<uint32_t>(), nchunks);
+        }
+        HIPCHK(ctx, hipEventSynchronize(L.ev_sorted));
+    }
     {
         Span sp(ctx, L, KZG_T_FIXUP);
         for (uint32_t d = 1; d < *max_len_h; d <<= 1)
@@ -1459,7 +1482,7 @@ int kzg_proto_baff(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint
     HIPCHK(ctx, hipMemsetAsync(L.bufA.p, 0, B * sizeof(g1_xyzz_t), s));
     HIPCHK(ctx, hipEventRecord(ev[0], s));
     launch_msm_sort(s, sh, ctx->slot[slot].as<uint32_t>(), ctx->slot_mont[slot], nullptr, 0, L.hist.as<uint32_t>(), false,
-                    L.rank.as<uint2>(), L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(), L.flags() + 2);
+                    L.rank.as<uint2>(), L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(), L.flags() + 2, false, L.flags() + 3);
     HIPCHK(ctx, hipEventRecord(ev[1], s));
     uint32_t entries = 0;
     HIPCHK(ctx, hipMemcpyAsync(&entries, L.offsets.as<uint32_t>() + B, 4, hipMemcpyDeviceToHost, s));

@@ -117,19 +117,21 @@ __global__ void __launch_bounds__(1024) k_sort_count(const uint32_t* __restrict_
     for (uint32_t i = threadIdx.x; i < npart; i += 1024)
         if (h[i]) atomicAdd(&part_count[i], h[i]);
 }
-// part_base[0..npart] = exclusive scan of part_count (npart <= 4096); cursors zeroed.  Housekeeping that would otherwise
-// be three more memsets on the stream (~4.5 us each, and short rows are nothing but such latencies): the counts are
-// zeroed again once read (so the NEXT sort finds them clean) and the fold-depth word of this MSM is reset.
-__global__ void __launch_bounds__(1024) k_sort_part_scan(uint32_t* __restrict__ part_count, uint32_t npart,
+// part_base[0..npart] = exclusive scan of min(counts, clamp) (npart <= 4096).  `counts` is the count pass's histogram
+// (exact mode) or the partition pass's cursors (fast mode, clamp = region capacity).  Housekeeping that would otherwise
+// be more memsets on the stream (~4.5 us each, and short rows are nothing but such latencies): the counts are zeroed
+// again once read (so the NEXT sort finds them clean), the fold-depth word of this MSM is reset, and the exact mode
+// clears the overflow word a failed fast attempt left behind.
+__global__ void __launch_bounds__(1024) k_sort_part_scan(uint32_t* __restrict__ counts, uint32_t npart, uint32_t clamp,
                                                           uint32_t* __restrict__ part_base,
-                                                          uint32_t* __restrict__ part_cursor,
-                                                          uint32_t* __restrict__ max_len_word) {
+                                                          uint32_t* __restrict__ max_len_word,
+                                                          uint32_t* __restrict__ overflow_word_or_null) {
     __shared__ uint32_t part[1024];
     const uint32_t t = threadIdx.x;
     const uint32_t per = (npart + 1023u) / 1024u;
     const uint32_t lo = t * per, hi = min(lo + per, npart);
     uint32_t v = 0;
-    for (uint32_t i = lo; i < hi; i++) v += part_count[i];
+    for (uint32_t i = lo; i < hi; i++) v += min(counts[i], clamp);
     part[t] = v;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -141,12 +143,14 @@ __global__ void __launch_bounds__(1024) k_sort_part_scan(uint32_t* __restrict__ 
     uint32_t run = part[t] - v;
     for (uint32_t i = lo; i < hi; i++) {
         part_base[i] = run;
-        part_cursor[i] = 0;
-        run += part_count[i];
-        part_count[i] = 0;
+        run += min(counts[i], clamp);
+        counts[i] = 0;
     }
     if (t == 1023) part_base[npart] = part[1023];
-    if (t == 0) *max_len_word = 0;
+    if (t == 0) {
+        *max_len_word = 0;
+        if (overflow_word_or_null) *overflow_word_or_null = 0;
+    }
 }
 __global__ void __launch_bounds__(256) k_sort_partition(const uint32_t* __restrict__ scalars, const SortShape ss,
                                                          const WinLayout lay, const uint32_t* __restrict__ part_base,
@@ -175,18 +179,24 @@ __global__ void __launch_bounds__(256) k_sort_partition(const uint32_t* __restri
 // (the direct scatter wrote 3.5x the bytes it stored).  Used when nwin <= 32 (c >= 8); otherwise k_sort_partition.
 #define SORT1_MAXW 32
 #define SORT1_STAGE 13312  // entries per workgroup: 104 KB of (key_low | partition << 16, value); 1024 scalars at 13 windows
+// region_cap != 0 (FAST mode, no count pass): partition q owns the fixed region [q * region_cap, (q + 1) * region_cap) of
+// `parted`; a workgroup whose run would not fit raises *overflow and drops that partition's entries -- the host then
+// reruns the sort in exact mode (count pass + exact bases), see msm_core.  region_cap == 0: exact bases from part_base.
 __global__ void __launch_bounds__(1024) k_sort_partition_staged(const uint32_t* __restrict__ scalars, const SortShape ss,
                                                                  const WinLayout lay, uint32_t spb,
                                                                  const uint32_t* __restrict__ part_base,
                                                                  uint32_t* __restrict__ part_cursor,
-                                                                 uint2* __restrict__ parted) {
+                                                                 uint2* __restrict__ parted, uint32_t region_cap,
+                                                                 uint32_t* __restrict__ overflow) {
     __shared__ uint32_t h[SORT_MAXPART];     // counts, then (global base - local offset) per partition
+    __shared__ uint32_t skip[SORT_MAXPART / 32];
     __shared__ uint32_t loff[SORT_MAXPART];  // local exclusive offsets
     __shared__ uint32_t wsum[1024];
     __shared__ uint2 stage[SORT1_STAGE];  // .x = key_low (<= 12 bits) | partition << 16
     const uint32_t t = threadIdx.x;
     const uint32_t npart = 1u << ss.hbits;
     for (uint32_t i = t; i < npart; i += 1024) h[i] = 0;
+    if (t < SORT_MAXPART / 32) skip[t] = 0;
     __syncthreads();
     // 1. digits -> registers, rank inside (workgroup, partition)
     uint32_t keyn[SORT1_MAXW], rk[SORT1_MAXW];
@@ -233,7 +243,15 @@ __global__ void __launch_bounds__(1024) k_sort_partition_staged(const uint32_t* 
     for (uint32_t i = b0; i < b1; i++) {
         const uint32_t c = h[i];
         loff[i] = run;
-        if (c) h[i] = part_base[i] + atomicAdd(&part_cursor[i], c) - run;
+        if (c) {
+            const uint32_t old = atomicAdd(&part_cursor[i], c);
+            if (!region_cap) h[i] = part_base[i] + old - run;
+            else if (old + c <= region_cap) h[i] = i * region_cap + old - run;
+            else {
+                atomicOr(&skip[i >> 5], 1u << (i & 31));
+                atomicOr(overflow, 1u);
+            }
+        }
         run += c;
     }
     __syncthreads();
@@ -255,15 +273,21 @@ __global__ void __launch_bounds__(1024) k_sort_partition_staged(const uint32_t* 
     // 5. copy out: consecutive lanes -> consecutive addresses inside each partition's run
     for (uint32_t i = t; i < count; i += 1024) {
         const uint2 v = stage[i];
-        parted[h[v.x >> 16] + i] = make_uint2(v.x & 0xffffu, v.y);
+        const uint32_t q = v.x >> 16;
+        if (!((skip[q >> 5] >> (q & 31)) & 1u)) parted[h[q] + i] = make_uint2(v.x & 0xffffu, v.y);
     }
 }
 
 #define SORT_STAGE 28672  // 112 KB: one 1024-thread workgroup per CU; fewer, larger partitions keep level 1's runs longer (A/B)
 // one workgroup per partition: LDS histogram of the low bits -> bucket offsets -> scatter inside the partition
-__global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__ parted, const uint32_t* __restrict__ part_base,
+// region_cap != 0: the partition's entries are read from its fixed region q * region_cap (fast mode), written at the
+// contiguous part_base[q] as always.  A raised overflow word means the fast attempt failed: every offset becomes 0, so the
+// accumulate kernel that is already queued behind this one sees an empty MSM and exits (nothing stale is dereferenced).
+__global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__ parted_in, const uint32_t* __restrict__ part_base,
                                                         int lbits, uint32_t* __restrict__ offsets,
-                                                        uint32_t* __restrict__ sorted, uint32_t npart) {
+                                                        uint32_t* __restrict__ sorted, uint32_t npart, uint32_t region_cap,
+                                                        const uint32_t* __restrict__ overflow,
+                                                        uint32_t* __restrict__ part_cursor) {
     __shared__ uint32_t h[4096];
     __shared__ uint32_t wsum[1024];
     // a partition of up to SORT_STAGE entries is scattered inside LDS and leaves as whole lines (the 4-byte scatter
@@ -272,6 +296,14 @@ __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__
     const uint32_t q = blockIdx.x, t = threadIdx.x;
     const uint32_t nb = 1u << lbits;
     const uint32_t lo = part_base[q], hi = part_base[q + 1];
+    if (t == 0) part_cursor[q] = 0;   // the next sort finds the cursors clean
+    if (region_cap && *overflow) {
+        for (uint32_t i = t; i < nb; i += 1024) offsets[((uint64_t)q << lbits) + i] = 0;
+        if (q == npart - 1 && t == 0) offsets[(uint64_t)npart << lbits] = 0;
+        return;
+    }
+    // entry e of the output range [lo, hi) lies at parted[e] (exact mode) or at its region's start + (e - lo)
+    const uint2* parted = region_cap ? parted_in + ((uint64_t)q * region_cap - lo) : parted_in;
     for (uint32_t i = t; i < nb; i += 1024) h[i] = 0;
     __syncthreads();
     // four independent loads in flight per lane: the loop is otherwise a chain of dependent global-load latencies
@@ -1325,12 +1357,19 @@ __global__ void __launch_bounds__(256) k_batch_affine(const g1_xyzz_t* __restric
 // ------------------------------------------------------------------------------------------------ launchers
 static inline uint32_t nblk(uint64_t n, uint32_t b) { return (uint32_t)((n + b - 1) / b); }
 
-void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars, int scalars_mont,
-                     const uint32_t* scalars2, int scalars2_mont, uint32_t* part_ws, bool part_ws_clean, uint2* parted,
-                     uint32_t* offsets, uint32_t* sorted, uint32_t* max_len_word) {
+uint64_t msm_sort_region_cap(uint64_t entries, uint32_t npart) {
+    // a partition's share of the entries is not uniform: windows one bit narrower than the widest put their digits in the
+    // lower half of the key space, and the top window is cut short by the field size -- up to ~2x the mean
+    return (entries / npart) * 9 / 4 + 2048;
+}
+// which of the sort's two modes can run: the fast one needs the staged partition kernel and 32-bit region addressing
+bool msm_sort_fast_ok(const MsmShape& sh) {
+    const uint64_t entries = (uint64_t)sh.n * sh.nbatch * sh.nwin;
+    return sh.nwin <= SORT1_MAXW && entries * 9 / 4 + ((uint64_t)SORT_MAXPART << 11) < ((uint64_t)1 << 32);
+}
+static void sort_shape(const MsmShape& sh, const uint32_t* scalars2, int scalars_mont, int scalars2_mont, SortShape& ss) {
     const int setbits = sh.nbatch > 1 ? 1 : 0;
     const int keybits = sh.c - 1 + setbits;
-    SortShape ss;
     ss.n = sh.n; ss.total = sh.n << setbits; ss.srs_offset = sh.srs_offset; ss.srs_stride = sh.srs_stride;
     ss.mont = scalars_mont; ss.scalars2 = scalars2; ss.mont2 = scalars2_mont; ss.keybits = sh.c - 1;
     // 1024 partitions (level 2 runs one workgroup per partition), up to 4096 when that brings a partition down to what
@@ -1343,24 +1382,50 @@ void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars,
     ss.hbits = hbits;
     ss.lbits = keybits - hbits;
     ss.spb = ss.total >= (1u << 21) ? 4096u : 1024u;
+}
+uint64_t msm_sort_parted_entries(const MsmShape& sh, bool fast) {  // capacity of `parted`, in entries
+    const uint64_t entries = (uint64_t)sh.n * sh.nbatch * sh.nwin;
+    if (!fast) return entries;
+    SortShape ss;
+    sort_shape(sh, nullptr, 0, 0, ss);
+    return msm_sort_region_cap(entries, 1u << ss.hbits) << ss.hbits;
+}
+// FAST mode (uniform-ish scalars: the common case): no count pass -- partition straight into fixed-capacity regions, scan
+// the cursors, level 2 reads the regions.  If a region overflows (skewed scalars) *overflow_word is raised, the offsets
+// come out all zero (the queued accumulate sees an empty MSM) and the caller reruns in EXACT mode: count pass, exact
+// bases, no overflow possible.  Both leave the partition counts / cursors zero for the next sort.
+void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars, int scalars_mont,
+                     const uint32_t* scalars2, int scalars2_mont, uint32_t* part_ws, bool part_ws_clean, uint2* parted,
+                     uint32_t* offsets, uint32_t* sorted, uint32_t* max_len_word, bool fast, uint32_t* overflow_word) {
+    SortShape ss;
+    sort_shape(sh, scalars2, scalars_mont, scalars2_mont, ss);
+    const uint64_t entries = ss.total * (uint64_t)sh.nwin;
     const uint32_t npart = 1u << ss.hbits;
     uint32_t* part_count = part_ws;                      // [npart]
     uint32_t* part_base = part_ws + SORT_MAXPART;        // [npart + 1]
     uint32_t* part_cursor = part_ws + 2 * SORT_MAXPART + 8;
-    if (!part_ws_clean) (void)hipMemsetAsync(part_count, 0, SORT_MAXPART * 4, s);   // afterwards k_sort_part_scan keeps it zero
+    if (!part_ws_clean) (void)hipMemsetAsync(part_ws, 0, 16384 * 4, s);   // afterwards the kernels keep counts / cursors zero
+    uint32_t spb2 = (SORT1_STAGE / (uint32_t)sh.nwin) & ~63u;  // staged partition: one scalar per lane, <= SORT1_STAGE entries
+    if (spb2 > 1024) spb2 = 1024;
+    if (fast) {
+        const uint32_t cap = (uint32_t)msm_sort_region_cap(entries, npart);
+        k_sort_partition_staged<<<nblk(ss.total, spb2), 1024, 0, s>>>(scalars, ss, sh.lay, spb2, part_base, part_cursor,
+                                                                     parted, cap, overflow_word);
+        k_sort_part_scan<<<1, 1024, 0, s>>>(part_cursor, npart, cap, part_base, max_len_word, nullptr);
+        k_sort_buckets<<<npart, 1024, 0, s>>>(parted, part_base, ss.lbits, offsets, sorted, npart, cap, overflow_word,
+                                              part_cursor);
+        return;
+    }
     const uint32_t blocks = nblk(ss.total, ss.spb);
     if (ss.total > (1u << 18)) k_sort_count<4><<<nblk(ss.total, 4096), 1024, 0, s>>>(scalars, ss, sh.lay, part_count);
     else k_sort_count<1><<<nblk(ss.total, 1024), 1024, 0, s>>>(scalars, ss, sh.lay, part_count);
-    k_sort_part_scan<<<1, 1024, 0, s>>>(part_count, npart, part_base, part_cursor, max_len_word);
-    if (sh.nwin <= SORT1_MAXW) {
-        uint32_t spb2 = (SORT1_STAGE / (uint32_t)sh.nwin) & ~63u;  // one scalar per lane, <= SORT1_STAGE entries
-        if (spb2 > 1024) spb2 = 1024;
+    k_sort_part_scan<<<1, 1024, 0, s>>>(part_count, npart, 0xffffffffu, part_base, max_len_word, overflow_word);
+    if (sh.nwin <= SORT1_MAXW)
         k_sort_partition_staged<<<nblk(ss.total, spb2), 1024, 0, s>>>(scalars, ss, sh.lay, spb2, part_base, part_cursor,
-                                                                     parted);
-    } else {
+                                                                     parted, 0u, overflow_word);
+    else
         k_sort_partition<<<blocks, 256, 0, s>>>(scalars, ss, sh.lay, part_base, part_cursor, parted);
-    }
-    k_sort_buckets<<<npart, 1024, 0, s>>>(parted, part_base, ss.lbits, offsets, sorted, npart);
+    k_sort_buckets<<<npart, 1024, 0, s>>>(parted, part_base, ss.lbits, offsets, sorted, npart, 0u, overflow_word, part_cursor);
 }
 void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t* table, const uint32_t* offsets,
                            const uint32_t* sorted, g1_xyzz_t* buckets, g1_xyzz_t* carries, uint32_t* carry_key,

@@ -37,11 +37,15 @@ struct MsmShape {
 // part_ws: 16384 u32 scratch; parted: one uint2 per entry
 // With sh.nbatch == 2 the second scalar set (scalars2, same length, same points) is sorted into the second bucket set:
 // the key gets one more high bit, everything downstream just sees 2 * nbuckets buckets.
-// part_ws_clean: the partition counts are known to be zero (a completed sort leaves them so); max_len_word: the MSM's
-// fold-depth word, reset here (launch_fold_maxlen accumulates into it)
+// part_ws_clean: the partition counts / cursors are known to be zero (a completed sort leaves them so); max_len_word: the
+// MSM's fold-depth word, reset here (launch_fold_maxlen accumulates into it).  fast: no count pass, fixed-capacity
+// partition regions (parted must hold msm_sort_parted_entries(sh, true) entries); when a region overflows,
+// *overflow_word is raised, the offsets come out all zero, and the caller reruns with fast = false (which clears the word).
 void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars, int scalars_mont,
                      const uint32_t* scalars2, int scalars2_mont, uint32_t* part_ws, bool part_ws_clean, uint2* parted,
-                     uint32_t* offsets, uint32_t* sorted, uint32_t* max_len_word);
+                     uint32_t* offsets, uint32_t* sorted, uint32_t* max_len_word, bool fast, uint32_t* overflow_word);
+bool msm_sort_fast_ok(const MsmShape& sh);
+uint64_t msm_sort_parted_entries(const MsmShape& sh, bool fast);
 // bytes (multiple of 4) from device memory to a device-visible host pointer, by a kernel
 void launch_publish(hipStream_t s, const void* src_dev, void* dst_host_devptr, uint32_t bytes);
 void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t* table, const uint32_t* offsets,
