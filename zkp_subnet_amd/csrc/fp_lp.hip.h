@@ -14,7 +14,9 @@
 #pragma once
 #include "g1.hip.h"
 
+#ifndef LP_MAX_OPS
 #define LP_MAX_OPS 3072
+#endif
 
 template <int CTRL>
 KZG_DEV uint32_t lp_dpp(uint32_t v) {  // out-of-row sources read as zero
