@@ -6,7 +6,7 @@ import sys
 
 for lg in (int(a) for a in sys.argv[1:] or ["16"]):
     for c in range(max(6, lg - 6), min(22, lg + 3) + 1):
-        out = subprocess.run([sys.executable, "bench.py", "--steps", "10", "--warmup", "2", "--workload", "kzg22", "--log-n",
+        out = subprocess.run([sys.executable, "bench.py", "--steps", "10", "--warmup", "2", "--workload", "kzg22", "--no-cpu-baseline", "--log-n",
                               str(lg), "--window", str(c)], capture_output=True, text=True).stdout.strip().splitlines()
         try:
             d = json.loads(out[-1])
