@@ -431,7 +431,7 @@ def test_cfg4_msm_2_26_in_eight_srs_segments(hip):
     eng = hip()
     tx = 0x26262626262626262626262626
     eng.gen_srs(tx, 1, lg, 0)
-    assert eng.window == 22
+    assert eng.window == 24
     seg = n // 8
     y = 0
     txs = tx.to_bytes(32, "big")

@@ -324,7 +324,8 @@ int choose_window(uint64_t T) {
     if (lg <= 15) return 14;
     if (lg <= 19) return 16;
     if (lg <= 23) return 20;
-    return 22;
+    if (lg <= 25) return 22;
+    return 24;   // 2^26: 11 windows, 2^23 buckets -- 132.2 -> 128.4 ms (the tree grows 1.2 -> 4.4 ms, the accumulate drops 8 %)
 }
 // nwin = ceil(256/c) windows of width base or base+1 (256 = nwin*base + extra): the widest is <= c bits
 void set_window(kzg_ctx* ctx, int c) {
@@ -887,7 +888,7 @@ const char* kzg_last_error(kzg_ctx*) { return tl_err.c_str(); }
 int kzg_set_window(kzg_ctx* ctx, int c) {
     if (!ctx) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    if (c != 0 && (c < 4 || c > 22)) return fail(ctx, KZG_E_ARG, "window bits must be 0 (auto) or in [4, 22]");
+    if (c != 0 && (c < 4 || c > 24)) return fail(ctx, KZG_E_ARG, "window bits must be 0 (auto) or in [4, 24]");
     if (ctx->table.p) return fail(ctx, KZG_E_ARG, "window must be set before the SRS is loaded");
     ctx->c_user = c;
     return KZG_OK;

@@ -278,6 +278,7 @@ __global__ void __launch_bounds__(1024) k_sort_partition_staged(const uint32_t* 
     }
 }
 
+#define SORT_LONG_RUN 256
 #define SORT_STAGE 28672  // 112 KB: one 1024-thread workgroup per CU; fewer, larger partitions keep level 1's runs longer (A/B)
 // one workgroup per partition: LDS histogram of the low bits -> bucket offsets -> scatter inside the partition
 // region_cap != 0: the partition's entries are read from its fixed region q * region_cap (fast mode), written at the
@@ -289,9 +290,11 @@ __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__
                                                         const uint32_t* __restrict__ overflow,
                                                         uint32_t* __restrict__ part_cursor) {
     __shared__ uint32_t h[4096];
+    __shared__ uint32_t th[4096];   // per-tile histogram / cursors of the oversized-partition path
+    __shared__ uint32_t longb[SORT_STAGE / SORT_LONG_RUN + 1], nlong, maxc;
     __shared__ uint32_t wsum[1024];
     // a partition of up to SORT_STAGE entries is scattered inside LDS and leaves as whole lines (the 4-byte scatter
-    // straight to HBM wrote 3.7x the bytes: lines left L2 partly filled); larger (skewed) partitions scatter directly
+    // straight to HBM wrote 3.7x the bytes: lines left L2 partly filled); larger (long inputs, skewed scalars) partitions go through it tile by tile
     __shared__ uint32_t stage[SORT_STAGE];
     const uint32_t q = blockIdx.x, t = threadIdx.x;
     const uint32_t nb = 1u << lbits;
@@ -305,6 +308,7 @@ __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__
     // entry e of the output range [lo, hi) lies at parted[e] (exact mode) or at its region's start + (e - lo)
     const uint2* parted = region_cap ? parted_in + ((uint64_t)q * region_cap - lo) : parted_in;
     for (uint32_t i = t; i < nb; i += 1024) h[i] = 0;
+    if (t == 0) maxc = 0;
     __syncthreads();
     // four independent loads in flight per lane: the loop is otherwise a chain of dependent global-load latencies
     {
@@ -329,13 +333,15 @@ __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__
         wsum[t] += x;
         __syncthreads();
     }
-    uint32_t run = lo + wsum[t] - s;
+    uint32_t run = lo + wsum[t] - s, cmax = 0;
     for (uint32_t i = b0; i < b1; i++) {
         const uint32_t c = h[i];
         offsets[((uint64_t)q << lbits) + i] = run;
         h[i] = run;  // becomes the scatter cursor
         run += c;
+        cmax = max(cmax, c);
     }
+    if (cmax * 4u > hi - lo) atomicMax(&maxc, cmax);   // only a dominant bucket matters (see below)
     if (q == npart - 1 && t == 1023) offsets[(uint64_t)npart << lbits] = hi;
     __syncthreads();
     if (hi - lo <= SORT_STAGE) {
@@ -353,7 +359,9 @@ __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__
         }
         __syncthreads();
         for (uint32_t i = t; i < hi - lo; i += 1024) sorted[lo + i] = stage[i];
-    } else {
+    } else if (maxc * 4u > hi - lo) {
+        // oversized because ONE bucket dominates (all-equal / sparse scalars): its entries are consecutive in entry order
+        // too, so the direct scatter is already a stream of whole lines -- and spares the per-tile passes
         uint32_t e = lo + t;
         for (; e + 3 * 1024 < hi; e += 4 * 1024) {
             const uint2 v0 = parted[e], v1 = parted[e + 1024], v2 = parted[e + 2048], v3 = parted[e + 3072];
@@ -365,6 +373,83 @@ __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__
         for (; e < hi; e += 1024) {
             const uint2 v = parted[e];
             sorted[lds_bump(h, v.x)] = v.y;
+        }
+    } else {
+        // Oversized partition (long inputs: 2^26 points leave 180 k entries per partition; or skewed scalars): TILES of
+        // SORT_STAGE entries are ordered by bucket inside LDS and leave as one run per bucket and tile.  The entry-order
+        // 4-byte scatter this replaces wrote 6.6x the bytes it stored at 2^26 (rocprofv3 WRITE_SIZE: 19.4 GB for
+        // 2.95 GB; every store found its line already evicted) and was two thirds of the sort's time there.
+        const uint32_t lane = t & 63u, wave = t >> 6;
+        for (uint32_t ts = lo; ts < hi; ts += SORT_STAGE) {
+            const uint32_t te = min(ts + (uint32_t)SORT_STAGE, hi);
+            for (uint32_t i = t; i < nb; i += 1024) th[i] = 0;
+            __syncthreads();
+            {
+                uint32_t e = ts + t;
+                for (; e + 3 * 1024 < te; e += 4 * 1024) {
+                    const uint32_t k0 = parted[e].x, k1 = parted[e + 1024].x, k2 = parted[e + 2048].x, k3 = parted[e + 3072].x;
+                    lds_bump(th, k0); lds_bump(th, k1); lds_bump(th, k2); lds_bump(th, k3);
+                }
+                for (; e < te; e += 1024) lds_bump(th, parted[e].x);
+            }
+            __syncthreads();
+            uint32_t ts_sum = 0;
+            for (uint32_t i = b0; i < b1; i++) ts_sum += th[i];
+            wsum[t] = ts_sum;
+            __syncthreads();
+            for (uint32_t d = 1; d < 1024; d <<= 1) {
+                uint32_t x = (t >= d) ? wsum[t - d] : 0;
+                __syncthreads();
+                wsum[t] += x;
+                __syncthreads();
+            }
+            uint32_t trun = wsum[t] - ts_sum;
+            if (t == 0) nlong = 0;
+            __syncthreads();
+            for (uint32_t i = b0; i < b1; i++) {
+                const uint32_t c = th[i];
+                th[i] = trun;  // the tile-local cursor; after the placement it is the END of the bucket's run in `stage`
+                trun += c;
+                if (c > SORT_LONG_RUN) longb[atomicAdd(&nlong, 1u)] = i;   // at most SORT_STAGE / SORT_LONG_RUN of them
+            }
+            __syncthreads();
+            {
+                uint32_t e = ts + t;
+                for (; e + 3 * 1024 < te; e += 4 * 1024) {
+                    const uint2 v0 = parted[e], v1 = parted[e + 1024], v2 = parted[e + 2048], v3 = parted[e + 3072];
+                    stage[lds_bump(th, v0.x)] = v0.y;
+                    stage[lds_bump(th, v1.x)] = v1.y;
+                    stage[lds_bump(th, v2.x)] = v2.y;
+                    stage[lds_bump(th, v3.x)] = v3.y;
+                }
+                for (; e < te; e += 1024) {
+                    const uint2 v = parted[e];
+                    stage[lds_bump(th, v.x)] = v.y;
+                }
+            }
+            __syncthreads();
+            // one wave per bucket: its run [end of bucket i-1, end of bucket i) goes to the bucket's global cursor ...
+            for (uint32_t i = wave; i < nb; i += 16) {
+                const uint32_t s0 = i ? th[i - 1] : 0u, s1 = th[i];
+                if (s1 - s0 > SORT_LONG_RUN) continue;
+                const uint32_t g = h[i];
+                for (uint32_t k = s0 + lane; k < s1; k += 64) sorted[g + (k - s0)] = stage[k];
+                if (lane == 0) h[i] = g + (s1 - s0);
+            }
+            // ... except the few long runs (skewed scalars: a tile may be ONE bucket), which the whole workgroup copies
+            const uint32_t nl = nlong;
+            for (uint32_t j = 0; j < nl; j++) {
+                const uint32_t i = longb[j];
+                const uint32_t s0 = i ? th[i - 1] : 0u, s1 = th[i];
+                const uint32_t g = h[i];
+                for (uint32_t k = s0 + t; k < s1; k += 1024) sorted[g + (k - s0)] = stage[k];
+            }
+            __syncthreads();
+            if (t < nl) {
+                const uint32_t i = longb[t];
+                h[i] += th[i] - (i ? th[i - 1] : 0u);
+            }
+            __syncthreads();
         }
     }
 }
