@@ -215,6 +215,22 @@ def test_msm_long_carry_runs_small_and_mid_sizes(hip, lg, window):
         assert eng.msm(o.fr_to_be32(sc), 0) == oc.g1_mul_gen(o.poly_eval(sc, tx).to_bytes(32, "big"))
 
 
+@pytest.mark.parametrize("lg,window,spread_bits", [(17, 0, 6), (17, 18, 9), (18, 18, 9)])
+def test_msm_clustered_digits_oversized_sort_partitions(hip, lg, window, spread_bits):
+    """Scalars base + delta, delta < 2^spread_bits: the low window's digits fill a few ADJACENT buckets, so one or a few
+    level-2 sort partitions receive far more entries than fit LDS and none of their buckets dominates -- the tile-staged
+    path of k_sort_buckets, with runs above (6 bits) and below (9 bits) the whole-workgroup copy threshold; every
+    other window piles on ONE bucket (the direct-scatter path).  The count-free sort overflows first and is rerun exactly."""
+    n = 1 << lg
+    eng = hip(window)
+    tx = 0x5EED5 + lg
+    eng.gen_srs(tx, 1, lg, 0)
+    rnd = random.Random(lg * 100 + spread_bits)
+    base = rnd.randrange(o.R >> 1) & ~((1 << 40) - 1)
+    sc = [base + rnd.randrange(1 << spread_bits) for _ in range(n)]
+    assert eng.msm(o.fr_to_be32(sc), 0) == oc.g1_mul_gen(o.poly_eval(sc, tx).to_bytes(32, "big"))
+
+
 def test_msm_2_20_full_size_trapdoor_and_linearity(hip):
     """BASELINE.json configs[1]: 2^20-point MSM, random scalars, cached SRS.  Bit-exact against [f(tau)]G, which the
     oracle computes without any MSM; plus MSM(s) + MSM(t) == MSM(s + t) through the partial-sum ABI."""
