@@ -257,9 +257,9 @@ def main():
         n = 1 << lg
         n_total = n * world
         # this rank's SRS segment: points [rank*n, (rank+1)*n) of the 2^lg * world point SRS [tau^j] G
-        eng.gen_srs(TAU, 1, lg, 0, factors=[pow(TAU, rank * n, R_MOD)])
-        scal = uniform_fr(n, seed=rank)                       # seed 0 on rank 0
-        eng.upload_fr(0, scal, False)
+        scal = uniform_fr(n, seed=rank)                       # seed 0 on rank 0; host work first: the GPU
+        eng.gen_srs(TAU, 1, lg, 0, factors=[pow(TAU, rank * n, R_MOD)])   # goes from the table build straight into
+        eng.upload_fr(0, scal, False)                         # the warm-up steps (an idle gap drops its clocks)
         alpha = None
         scaling = "weak"
     elif args.workload == "msm26":
@@ -270,8 +270,8 @@ def main():
         n = n_total // world
         lg = n.bit_length() - 1
         # contiguous SRS segment [rank*n, (rank+1)*n) of the 2^26-point SRS; scalars of the same index range
-        eng.gen_srs(TAU, 1, lg, 0, factors=[pow(TAU, rank * n, R_MOD)])
         scal = uniform_fr(n, seed=1000 + rank)
+        eng.gen_srs(TAU, 1, lg, 0, factors=[pow(TAU, rank * n, R_MOD)])
         eng.upload_fr(0, scal, False)
         alpha = None
         scaling = "strong"
@@ -281,10 +281,10 @@ def main():
         n_total = n * world
         # Pianist segments: worker row `rank`, one per GPU, no exchange (BASELINE.json configs[2] / [4])
         ms = max(0, (world - 1).bit_length())
-        eng.gen_srs(TAU, 0, lg + ms, ms, factors=[lagrange_factor(rank, ms, (TAU * 7 + 1) % R_MOD)])
         scal = uniform_fr(n, seed=rank)
-        eng.upload_fr(0, scal, True)
         alpha = uniform_fr(1, seed=1)
+        eng.gen_srs(TAU, 0, lg + ms, ms, factors=[lagrange_factor(rank, ms, (TAU * 7 + 1) % R_MOD)])
+        eng.upload_fr(0, scal, True)
         scaling = "weak"
     setup_s = time.time() - t_setup
     plan = eng.msm_plan(n)
@@ -345,30 +345,10 @@ def main():
             step_ms.append((now - last) * 1e3)
             last = now
 
-    run_steps(args.warmup, False)
-    results.clear()
-    step_ms.clear()
-    # MSM workloads and short rows (one batched pass): stage spans (HIP events on the library's stream) are recorded inside
-    # the timed region.  Rows above 2^18: the library runs the two MSMs of a commit+open on two lanes unless profiling is
-    # on, so the timed region runs unprofiled and the stage times come from extra profiled (serialised) steps afterwards.
-    profile_in_timed = (is_msm and depth == 1) or (not is_msm and n <= (1 << 18))
-    eng.set_profiling(profile_in_timed)
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps, profile_in_timed)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    n_prof = args.steps
-    timed_step_ms = list(step_ms)
-    if not profile_in_timed:
-        state["depth"] = 1
-        eng.set_profiling(True)
-        n_prof = min(args.steps, 5)
-        run_steps(n_prof, True)
-        state["depth"] = depth
-    eng.set_profiling(False)
     # the same K steps with two requests in flight on two of the library's lanes (MSM i+1's sort/accumulate overlaps the
-    # latency-bound tail of MSM i): reported beside the headline, never mixed into it
+    # latency-bound tail of MSM i): reported beside the headline, never mixed into it.  Measured FIRST: the GPU takes
+    # ~40 ms of sustained load to reach its clocks (scripts/clock_ramp.py: steps 0-15 after an idle gap run 60-2 % slow),
+    # more than W = 5 warm-up steps give it; this way the one-at-a-time region below starts on a warm GPU
     pipelined = None
     if is_msm and depth == 1 and not args.no_pipelined:
         state["depth"], state["gather"] = 2, None
@@ -385,6 +365,29 @@ def main():
             pipe_s = float(t.item())
         pipelined = {"requests_in_flight": 2, "value": n_total * args.steps / pipe_s, "unit": "points/s",
                      "ms_per_step": pipe_s / args.steps * 1e3}
+    run_steps(args.warmup, False)
+    results.clear()
+    step_ms.clear()
+    # The timed region carries HIP events around the dominant kernel only (profiling level 2: two events per
+    # k_msm_accumulate launch, on the stream it is launched on -- the roofline's kernel time is measured live over exactly
+    # these K steps).  A full set of stage spans costs ~0.09 ms per 2^20 MSM (every event is a barrier packet on the
+    # stream) and pins concurrent calls to one lane, so the per-stage table comes from extra, serialised steps afterwards.
+    live_level = 2 if is_msm and depth == 1 else 0
+    eng.set_profiling(live_level)
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(args.steps, live_level == 2)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    acc_live_ms = stage_sum.get("accumulate", 0.0) / args.steps if live_level == 2 else None
+    stage_sum.clear()
+    timed_step_ms = list(step_ms)
+    state["depth"] = 1
+    eng.set_profiling(1)
+    n_prof = min(args.steps, 5)
+    run_steps(n_prof, True)
+    state["depth"] = depth
+    eng.set_profiling(0)
     # single-request latency (one request at a time, result on the host before the next starts)
     lat = []
     for _ in range(min(args.steps, 10)):
@@ -408,7 +411,7 @@ def main():
 
     if rank == 0:
         stages = {k: v / n_prof for k, v in stage_sum.items()}
-        acc_ms = stages.get("accumulate", 0.0)
+        acc_ms = acc_live_ms if acc_live_ms else stages.get("accumulate", 0.0)   # live over the timed region when available
         if is_msm:
             units = n_total * args.steps
             alg_bytes = 128.0 * n                 # 96 B affine point + 32 B scalar, each read once
@@ -475,6 +478,9 @@ def main():
                           if mads and acc_ms else None),
             "result_hex": results[0].hex() if isinstance(results[0], (bytes, bytearray)) else b"".join(results[0]).hex(),
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
+            "stages_ms_source": f"{n_prof} extra steps with every stage bracketed by HIP events, after the timed region; "
+                                "roofline.kernel_ms is measured inside the timed region"
+                                + ("" if acc_live_ms else " of those extra steps (two-lane commit+open: timed unprofiled)"),
             "single_request_latency_ms": round(latency_ms, 4),
             "pipelined": pipelined,
             "step_ms": {"median": round(pctl(timed_step_ms, 0.5), 4), "p10": round(pctl(timed_step_ms, 0.1), 4),

@@ -168,6 +168,8 @@ enum {
     KZG_T_DECODE = 0, KZG_T_NTT, KZG_T_DIGITS, KZG_T_SCAN, KZG_T_SCATTER, KZG_T_ACCUMULATE, KZG_T_FIXUP,
     KZG_T_TREE, KZG_T_FINAL, KZG_T_POLY, KZG_T_TOTAL, KZG_T_COUNT
 };
+/* enable: 0 off; 1 events around every stage (concurrent calls then serialise on one lane so that stage times stay
+   attributable); 2 events around the accumulate kernel only (two per launch; nothing is serialised) */
 int kzg_set_profiling(kzg_ctx* ctx, int enable);
 int kzg_get_timings(kzg_ctx* ctx, float* out_ms, int count); /* accumulated over the last call's MSMs */
 /* fixed-size MSM plan facts for roofline bookkeeping: entries per lane, lanes, buckets, windows */

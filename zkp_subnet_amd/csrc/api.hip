@@ -143,7 +143,7 @@ struct kzg_ctx {
     hipStream_t aux = nullptr;
     DevBuf aux_in, aux_pts, aux_out;
     uint8_t* aux_pin = nullptr;
-    bool profiling = false;
+    int profiling = 0;   // 0 off, 1 every stage (calls serialise on lane 0), 2 the accumulate kernel only (no serialisation)
     bool host_finish = true;
     float tms[KZG_T_COUNT] = {0};  // stage times of the last completed hot-path call
 };
@@ -172,7 +172,7 @@ int fail(kzg_ctx*, int code, const std::string& msg) {
 int lane_acquire(kzg_ctx* ctx, int state, int* out_li) {
     std::unique_lock<std::mutex> lk(ctx->mu);
     for (;;) {
-        const int limit = ctx->profiling ? 1 : N_LANES;
+        const int limit = ctx->profiling == 1 ? 1 : N_LANES;
         bool any_call = false;
         for (int i = 0; i < limit; i++) {
             if (ctx->lane[i].state == LANE_FREE) {
@@ -190,7 +190,7 @@ int lane_acquire(kzg_ctx* ctx, int state, int* out_li) {
 }
 int lane_try_second(kzg_ctx* ctx, int first) {  // a second free lane for the two-lane form of a long commit+open, or -1
     std::lock_guard<std::mutex> lk(ctx->mu);
-    if (ctx->profiling) return -1;
+    if (ctx->profiling == 1) return -1;
     for (int i = 0; i < N_LANES; i++) {
         if (i != first && ctx->lane[i].state == LANE_FREE) {
             ctx->lane[i].state = LANE_CALL;
@@ -278,7 +278,7 @@ struct Span {
     int idx = -1;
     hipStream_t stream;
     Span(kzg_ctx* c, Lane& L, int stage, hipStream_t st = nullptr) : stream(st ? st : L.stream) {
-        if (!c->profiling) return;
+        if (!c->profiling || (c->profiling == 2 && stage != KZG_T_ACCUMULATE)) return;
         lane = &L;
         StageSpan s{stage, prof_event(L), prof_event(L)};
         (void)hipEventRecord(s.a, stream);
@@ -293,13 +293,13 @@ struct Span {
 void prof_begin(kzg_ctx* ctx, Lane& L) {
     L.spans.clear();
     L.ev_used = 0;
-    if (!ctx->profiling) return;
+    if (ctx->profiling != 1) return;
     StageSpan s{KZG_T_TOTAL, prof_event(L), prof_event(L)};
     (void)hipEventRecord(s.a, L.stream);
     L.spans.push_back(s);
 }
 void prof_close(kzg_ctx* ctx, Lane& L) {
-    if (ctx->profiling && !L.spans.empty() && L.spans[0].stage == KZG_T_TOTAL) (void)hipEventRecord(L.spans[0].b, L.stream);
+    if (ctx->profiling == 1 && !L.spans.empty() && L.spans[0].stage == KZG_T_TOTAL) (void)hipEventRecord(L.spans[0].b, L.stream);
 }
 void prof_end(kzg_ctx* ctx, Lane& L) {  // lane stream already synchronised
     if (L.spans.empty()) return;
@@ -1423,7 +1423,7 @@ int kzg_staging_release(kzg_ctx* ctx, int token) {
 int kzg_set_profiling(kzg_ctx* ctx, int enable) {
     if (!ctx) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    ctx->profiling = enable != 0;
+    ctx->profiling = enable == 2 ? 2 : (enable != 0);
     return KZG_OK;
 }
 int kzg_get_timings(kzg_ctx* ctx, float* out_ms, int count) {

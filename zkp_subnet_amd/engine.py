@@ -281,8 +281,10 @@ class HipEngine:
         self._chk(self._lib.kzg_ntt_resident(self._h, slot, n, int(inverse)))
 
     # ------------------------------------------------------------------ measurement
-    def set_profiling(self, enable: bool) -> None:
-        self._chk(self._lib.kzg_set_profiling(self._h, int(enable)))
+    def set_profiling(self, level) -> None:
+        """0 / False: off.  1 / True: HIP events around every stage (calls serialise on one lane).  2: around the
+        accumulate kernel only (two events per launch, no serialisation)."""
+        self._chk(self._lib.kzg_set_profiling(self._h, int(level)))
 
     def timings(self) -> Dict[str, float]:
         arr = (ctypes.c_float * len(_native.TIMING_NAMES))()
