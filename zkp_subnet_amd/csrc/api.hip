@@ -101,6 +101,7 @@ struct Lane {
     uint8_t* tail = nullptr;      // device, TB_SIZE
     uint8_t* pin = nullptr;       // host pinned, 4096
     uint8_t* pin_dev = nullptr;   // the same page as the GPU addresses it
+    bool flags_clean = false;     // the tail record's flag words are zero (left so by the last request's publish)
     bool sort_ws_clean = false;   // the sort's partition counts are zero (left so by every completed sort)
     int skew_hint = 0;            // > 0: the last fast sort overflowed (skewed scalars): go straight to the exact sort
     hipEvent_t ev_sorted = nullptr, ev_done = nullptr, ev_coeffs = nullptr;
@@ -473,15 +474,21 @@ int need_srs(kzg_ctx* ctx) {
     if (!ctx->table.p || !ctx->stride) return fail(ctx, KZG_E_ARG, "no SRS resident: call kzg_load_srs / kzg_gen_srs");
     return KZG_OK;
 }
+// the request's flag words start at zero: left so by the publish that ended the lane's previous request (k_publish
+// clears the two input-error flags it has copied; the fold-depth and overflow words are reset by the sort), by a memset
+// only on a fresh lane or after a request that failed half-way
 int clear_flags(kzg_ctx* ctx, Lane& L) {
-    HIPCHK(ctx, hipMemsetAsync(L.flags(), 0, 16, L.stream));
+    const bool was_clean = L.flags_clean;
+    L.flags_clean = false;
+    if (!was_clean) HIPCHK(ctx, hipMemsetAsync(L.flags(), 0, 16, L.stream));
     return KZG_OK;
 }
 // ends a request: the lane's tail record comes back in ONE copy (result points, eval, flags, GPU-side encodings)
 int finish(kzg_ctx* ctx, Lane& L) {
     prof_close(ctx, L);
-    launch_publish(L.stream, L.tail, L.pin_dev, TB_COPY);
+    launch_publish(L.stream, L.tail, L.pin_dev, TB_COPY, L.flags());
     HIPCHK(ctx, hipStreamSynchronize(L.stream));
+    L.flags_clean = true;
     prof_end(ctx, L);
     const uint32_t* f = reinterpret_cast<const uint32_t*>(L.pin + TB_FLAGS);
     if (f[0]) return fail(ctx, KZG_E_SCALAR, "non-canonical Fr scalar (>= r)");
@@ -606,16 +613,15 @@ int commit_open_dev(kzg_ctx* ctx, LaneHold& H, uint32_t i, const uint32_t* row_d
     if (out_p48) {
         uint32_t* alpha_m = reinterpret_cast<uint32_t*>(A.tail + TB_ALPHA_M);
         uint32_t* y_m = reinterpret_cast<uint32_t*>(A.tail + TB_Y_M);
-        launch_fr_from_host32(so, alpha_be32, alpha_m, 1, A.flags());
         const uint64_t nchunks = (T + 3) / 4;
         HIPCHK(ctx, O.hbuf.ensure((nchunks + (nchunks >> 1) + 64) * 32));
         HIPCHK(ctx, O.hnext.ensure((nchunks + (nchunks >> 1) + 64) * 32));
         HIPCHK(ctx, O.qbuf.ensure(T * 32));
         {
             Span sp(ctx, A, KZG_T_POLY, so);
+            // alpha rides in as an argument of the opening's first kernel, y leaves big-endian from its scan kernel
             launch_poly_open(so, coeffs, T, alpha_m, O.hbuf.as<uint32_t>(), O.hnext.as<uint32_t>(), y_m,
-                             O.qbuf.as<uint32_t>());
-            launch_fr_to_be(so, y_m, A.tail + TB_EVAL, 1, 1);
+                             O.qbuf.as<uint32_t>(), alpha_be32, A.flags(), A.tail + TB_EVAL);
         }
         if (batched) {
             // the quotient has T - 1 coefficients; k_poly_quotient leaves a zero in slot T - 1, so it rides as a second
@@ -1203,9 +1209,8 @@ int kzg_eval(kzg_ctx* ctx, const uint8_t* coeffs_be32, uint64_t n, const uint8_t
     if (rc) return rc;
     uint32_t* x_m = reinterpret_cast<uint32_t*>(L.tail + TB_ALPHA_M);
     uint32_t* y_m = reinterpret_cast<uint32_t*>(L.tail + TB_Y_M);
-    launch_fr_from_host32(L.stream, x_be32, x_m, 1, L.flags());
-    launch_poly_open(L.stream, L.coeffA.as<uint32_t>(), n, x_m, L.hbuf.as<uint32_t>(), L.hnext.as<uint32_t>(), y_m, nullptr);
-    launch_fr_to_be(L.stream, y_m, L.tail + TB_EVAL, 1, 1);
+    launch_poly_open(L.stream, L.coeffA.as<uint32_t>(), n, x_m, L.hbuf.as<uint32_t>(), L.hnext.as<uint32_t>(), y_m, nullptr,
+                     x_be32, L.flags(), L.tail + TB_EVAL);
     rc = finish(ctx, L);
     if (rc) return rc;
     memcpy(out_be32, L.pin + TB_EVAL, 32);
@@ -1293,7 +1298,7 @@ int kzg_msm_submit(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, int 
         if (partial) queue_pack(ctx, L);
         else queue_encode(ctx, L, true, false);
         prof_close(ctx, L);
-        launch_publish(L.stream, L.tail, L.pin_dev, TB_COPY);
+        launch_publish(L.stream, L.tail, L.pin_dev, TB_COPY, L.flags());
         hipError_t e = hipEventRecord(L.ev_done, L.stream);
         if (e == hipSuccess) e = hipGetLastError();
         if (e != hipSuccess) rc = fail(ctx, KZG_E_HIP, std::string("kzg_msm_submit: ") + hipGetErrorString(e));
@@ -1324,6 +1329,7 @@ int kzg_msm_wait(kzg_ctx* ctx, int ticket, uint8_t* out) {
         rc = fail(ctx, KZG_E_HIP, std::string("hipEventSynchronize(ticket): ") + hipGetErrorString(e));
         (void)hipStreamSynchronize(L.stream);
     } else {
+        L.flags_clean = true;
         prof_end(ctx, L);
         if (L.partial) result_partial(ctx, L, out);
         else result_c48(ctx, L, 0, out);

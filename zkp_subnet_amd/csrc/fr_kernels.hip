@@ -259,16 +259,32 @@ KZG_DEV void fr9_pow2k(fr9_t& a, int k) {  // a <- a^(2^k), canonical in and out
     fr9_canon(a, a);
 }
 // h[t] = sum_k f[t*L + k] a^k with a = alpha^(2^sq)  (sq > 0: f is itself an array of chunk values, second level)
+// ARG: alpha comes as the kernel ARGUMENT (its 32 big-endian bytes) instead of from memory: the first kernel of an
+// opening converts it itself -- every lane, it is one product -- and lane 0 leaves the Montgomery form at alpha_out for
+// the kernels behind it (and raises *bad for a value >= r); a 1-lane conversion kernel ahead of it was ~5 us of latency
+template <bool ARG>
 __global__ void __launch_bounds__(256) k_poly_chunk_eval(const uint32_t* __restrict__ f, uint64_t n, int lchunk,
                                                           const uint32_t* __restrict__ alpha_mont, int sq,
-                                                          uint32_t* __restrict__ h) {
+                                                          uint32_t* __restrict__ h, const FrArg arg,
+                                                          uint32_t* __restrict__ alpha_out, uint32_t* __restrict__ bad) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t L = (uint64_t)1 << lchunk;
     uint64_t lo = t * L;
+    fr9_t a, s, c;
+    if constexpr (ARG) {
+        uint32_t w[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = bswap32(arg.w[7 - i]);
+        fr9_from_words(a, w);
+        fr9_to_mont(a, a);
+        if (t == 0) {
+            if (fr_words_ge_r(w)) atomicOr(bad, 1u);
+            fr9_store(alpha_out, a);
+        }
+    }
     if (lo >= n) return;
     uint64_t hi = lo + L < n ? lo + L : n;
-    fr9_t a, s, c;
-    fr9_load(a, alpha_mont);
+    if constexpr (!ARG) fr9_load(a, alpha_mont);
     fr9_pow2k(a, sq);
     fr9_zero(s);
     for (uint64_t j = hi; j-- > lo;) {
@@ -285,7 +301,8 @@ __global__ void __launch_bounds__(256) k_poly_chunk_eval(const uint32_t* __restr
 template <uint32_t NT_>
 __global__ void __launch_bounds__(NT_) k_poly_chunk_scan(const uint32_t* __restrict__ h, uint64_t nchunks, int lchunk,
                                                            const uint32_t* __restrict__ alpha_mont,
-                                                           uint32_t* __restrict__ hnext, uint32_t* __restrict__ y_mont) {
+                                                           uint32_t* __restrict__ hnext, uint32_t* __restrict__ y_mont,
+                                                           uint8_t* __restrict__ y_be_or_null) {
     __shared__ uint32_t sm[9][NT_];
     const uint32_t v = threadIdx.x;
     const uint64_t m = (nchunks + NT_ - 1) / NT_;
@@ -347,6 +364,13 @@ __global__ void __launch_bounds__(NT_) k_poly_chunk_scan(const uint32_t* __restr
     if (v == 0) {
         fr9_reduce(s, s);
         fr9_store(y_mont, s);
+        if (y_be_or_null) {   // the evaluation as the wire carries it (32 bytes big-endian): no separate 1-lane kernel
+            fr9_t yc;
+            fr9_from_mont(yc, s);
+            uint32_t w[8];
+            fr9_to_words(w, yc);
+            limbs_to_be<8>(y_be_or_null, w);
+        }
     }
 }
 // second level back down: hnext2[g] = H_{(g+1) * L2} over groups of L2 = 2^l2 first-level chunks -> hnext[u] = H_{u+1}
@@ -451,9 +475,16 @@ void launch_fr_ntt(hipStream_t s, const uint32_t* in, uint32_t* out, int log_n, 
         s0 += S;
     }
 }
-void launch_poly_open(hipStream_t s, const uint32_t* f_mont, uint64_t n, const uint32_t* alpha_mont, uint32_t* h,
-                      uint32_t* hnext, uint32_t* y_mont, uint32_t* q_canon_or_null) {
-    if (!n) return;
+void launch_poly_open(hipStream_t s, const uint32_t* f_mont, uint64_t n, uint32_t* alpha_mont, uint32_t* h,
+                      uint32_t* hnext, uint32_t* y_mont, uint32_t* q_canon_or_null, const uint8_t* alpha_be32_host,
+                      uint32_t* bad, uint8_t* y_be_or_null) {
+    FrArg arg;
+    memset(&arg, 0, sizeof(arg));
+    if (alpha_be32_host) memcpy(arg.w, alpha_be32_host, 32);
+    if (!n) {
+        if (alpha_be32_host) k_fr_from_arg<<<1, 64, 0, s>>>(arg, alpha_mont, 1, bad);
+        return;
+    }
     // Level 0 folds 2^l0 coefficients per lane, every further level 16 values of the level below, until at most 2048
     // values are left for the single-workgroup scan; then the suffix values H are expanded back down level by
     // level.  Every serial loop is <= 16 long (each step is one dependent Fr product, ~1 us for a lone wave), and
@@ -466,22 +497,27 @@ void launch_poly_open(hipStream_t s, const uint32_t* f_mont, uint64_t n, const u
     int K = 1;
     lv_l[0] = l0; lv_sq[0] = 0; lv_n[0] = n; lv_off[0] = 0;           // level 0 = f itself (offset unused)
     lv_n[1] = (n + ((uint64_t)1 << l0) - 1) >> l0; lv_sq[1] = l0; lv_off[1] = 0;
-    k_poly_chunk_eval<<<nblk(lv_n[1], 256), 256, 0, s>>>(f_mont, n, l0, alpha_mont, 0, h);
+    if (alpha_be32_host)
+        k_poly_chunk_eval<true><<<nblk(lv_n[1], 256), 256, 0, s>>>(f_mont, n, l0, alpha_mont, 0, h, arg, alpha_mont, bad);
+    else
+        k_poly_chunk_eval<false><<<nblk(lv_n[1], 256), 256, 0, s>>>(f_mont, n, l0, alpha_mont, 0, h, arg, nullptr, nullptr);
     while (lv_n[K] > 2048 && K < 14) {
         lv_l[K] = lup;
         lv_n[K + 1] = (lv_n[K] + ((uint64_t)1 << lup) - 1) >> lup;
         lv_sq[K + 1] = lv_sq[K] + lup;
         lv_off[K + 1] = lv_off[K] + lv_n[K];
-        k_poly_chunk_eval<<<nblk(lv_n[K + 1], 256), 256, 0, s>>>(h + 8 * lv_off[K], lv_n[K], lup, alpha_mont, lv_sq[K],
-                                                                 h + 8 * lv_off[K + 1]);
+        k_poly_chunk_eval<false><<<nblk(lv_n[K + 1], 256), 256, 0, s>>>(h + 8 * lv_off[K], lv_n[K], lup, alpha_mont, lv_sq[K],
+                                                                        h + 8 * lv_off[K + 1], arg, nullptr, nullptr);
         K++;
     }
     // the scan is one workgroup of dependent Fr products: 256 lanes (one wave per SIMD, <= 8 values each) run the chain
     // at a lone wave's issue rate; 1024 lanes (four waves per SIMD) only when there is more than that to fold
     if (lv_n[K] <= 1024)
-        k_poly_chunk_scan<256><<<1, 256, 0, s>>>(h + 8 * lv_off[K], lv_n[K], lv_sq[K], alpha_mont, hnext + 8 * lv_off[K], y_mont);
+        k_poly_chunk_scan<256><<<1, 256, 0, s>>>(h + 8 * lv_off[K], lv_n[K], lv_sq[K], alpha_mont, hnext + 8 * lv_off[K], y_mont,
+                                                 y_be_or_null);
     else
-        k_poly_chunk_scan<1024><<<1, 1024, 0, s>>>(h + 8 * lv_off[K], lv_n[K], lv_sq[K], alpha_mont, hnext + 8 * lv_off[K], y_mont);
+        k_poly_chunk_scan<1024><<<1, 1024, 0, s>>>(h + 8 * lv_off[K], lv_n[K], lv_sq[K], alpha_mont, hnext + 8 * lv_off[K], y_mont,
+                                                   y_be_or_null);
     for (int k = K - 1; k >= 1; k--)
         k_poly_chunk_expand<<<nblk(lv_n[k + 1], 256), 256, 0, s>>>(h + 8 * lv_off[k], lv_n[k], lv_l[k], alpha_mont,
                                                                    lv_sq[k], hnext + 8 * lv_off[k + 1],

@@ -15,5 +15,9 @@ void launch_fr_ntt(hipStream_t s, const uint32_t* in, uint32_t* out, int log_n, 
                    const uint32_t* scale_or_null);
 // y = f(alpha) (Montgomery) and, if q is given, the n-1 canonical coefficients of (f - y)/(X - alpha)
 // h, hnext: ceil(n/4) * 3/2 + 64 Fr scratch each (level arrays stacked; the chunk length shrinks to 4 for small rows)
-void launch_poly_open(hipStream_t s, const uint32_t* f_mont, uint64_t n, const uint32_t* alpha_mont, uint32_t* h,
-                      uint32_t* hnext, uint32_t* y_mont, uint32_t* q_canon_or_null);
+// alpha_be32_host given: alpha arrives as 32 big-endian HOST bytes (a kernel argument of the first kernel), its
+// Montgomery form is left at alpha_mont, *bad is raised if it is >= r; otherwise alpha_mont is read.
+// y_be_or_null: also write y as 32 big-endian bytes (device pointer)
+void launch_poly_open(hipStream_t s, const uint32_t* f_mont, uint64_t n, uint32_t* alpha_mont, uint32_t* h,
+                      uint32_t* hnext, uint32_t* y_mont, uint32_t* q_canon_or_null,
+                      const uint8_t* alpha_be32_host = nullptr, uint32_t* bad = nullptr, uint8_t* y_be_or_null = nullptr);
