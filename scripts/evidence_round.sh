@@ -1,0 +1,12 @@
+#!/bin/bash
+# Everything the round's profiles/ are refreshed from, in one GPU-box call: bench lines, rocprofv3 kernel stats, PMC
+# passes, short-row profiles, end-to-end latency from text, concurrency, fuzz.  Outputs under gpurun_out/.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+bash scripts/profile_round.sh
+bash scripts/pmc_round.sh
+bash scripts/rows_profile.sh
+python scripts/e2e_latency.py > gpurun_out/prof/e2e_latency.json 2> gpurun_out/prof/e2e_latency.err
+python scripts/concurrency_throughput.py > gpurun_out/prof/concurrency.json 2> gpurun_out/prof/concurrency.err
+python tests/fuzz_gpu.py ${FUZZ_S:-300} ${FUZZ_SEED:-20261007} > gpurun_out/prof/fuzz.log 2>&1
+tail -2 gpurun_out/prof/fuzz.log
