@@ -124,6 +124,16 @@ int kzg_g1_sum_compressed(kzg_ctx* ctx, const uint8_t* points_c48, uint32_t coun
  * completed the collective (stream synchronised) before kzg_g1_sum_dev. */
 int kzg_msm_partial_resident_dev(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, void* dev_out_xyzz192);
 int kzg_g1_sum_dev(kzg_ctx* ctx, const void* dev_partials_xyzz192, uint32_t count, uint8_t out48[48]);
+/* The same step chained through streams, one host synchronisation per MSM.  _begin queues the MSM of this rank's SRS
+ * segment on a free lane, writes its 192-byte partial to dev_out_xyzz192 and makes `consumer_stream` (a hipStream_t: the
+ * stream the collective is enqueued on, e.g. torch's current stream) wait for it ON THE DEVICE; it returns a ticket
+ * without blocking.  After the all_gather has been enqueued on that stream, _finish makes the lane wait for
+ * `producer_stream` in turn, sums the `count` gathered partials on the lane and returns the compressed point.
+ * (the exchange is 192 B per rank, latency-bound -- host round trips around it are what it costs.) */
+int kzg_msm_sharded_begin(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, void* dev_out_xyzz192,
+                          void* consumer_stream, int* out_ticket);
+int kzg_msm_sharded_finish(kzg_ctx* ctx, int ticket, const void* dev_partials_xyzz192, uint32_t count,
+                           void* producer_stream, uint8_t out48[48]);
 
 /* ---- device-resident inputs (what a serving loop and bench.py use: inputs already in HBM when timing starts).
  *      slot in [0, 4).  to_mont=1 stores Montgomery form (rows for commit/open), 0 canonical (MSM scalars). */

@@ -534,6 +534,22 @@ def test_two_processes_sharded_msm_on_one_gpu(hip):
     eng.close()
 
 
+def test_stream_chained_collective_step_one_rank_rccl(hip):
+    """kzg_msm_sharded_begin / _finish (the engine's lane, torch's stream with RCCL behind it, and the lane again chained
+    by events: one host synchronisation per MSM) against the blocking pair and the plain MSM, in a fresh process holding
+    a one-rank RCCL group (N > 1 ranks cannot share this box's single GPU)."""
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_rccl_onerank.py"), "29551"], capture_output=True,
+                         text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])   # RCCL prints its banner after it
+    assert set(rec) == {"6", "12", "16"}
+    for lg, r in rec.items():
+        assert r["chained_equal"] and r["blocking_equal"] and r["segment_equal"] and len(r["plain"]) == 96, (lg, r)
+
+
 def test_g1_sum_of_k_partials_any_count(hip):
     """kzg_g1_sum over k = 1..40 partial sums (the lane-parallel tree for 2..32, the one-lane form beyond), including
     infinities (empty ranges) and repeated points (P + P inside the tree): equals the MSM over the union."""

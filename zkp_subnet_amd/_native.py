@@ -46,6 +46,8 @@ SYMBOLS = {
     "kzg_g1_sum": (_I, [_P, _B, _U32, _B]),
     "kzg_msm_partial_resident_dev": (_I, [_P, _I, _U64, _U64, _P]),
     "kzg_g1_sum_dev": (_I, [_P, _P, _U32, _B]),
+    "kzg_msm_sharded_begin": (_I, [_P, _I, _U64, _U64, _P, _P, ctypes.POINTER(_I)]),
+    "kzg_msm_sharded_finish": (_I, [_P, _I, _P, _U32, _P, _B]),
     "kzg_upload_fr": (_I, [_P, _I, _B, _U64, _I]),
     "kzg_msm_resident": (_I, [_P, _I, _U64, _U64, _B]),
     "kzg_msm_partial_resident": (_I, [_P, _I, _U64, _U64, _B]),

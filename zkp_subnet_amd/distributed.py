@@ -55,6 +55,15 @@ class DeviceGather:
         torch.cuda.synchronize()
 
     def msm(self, slot: int, n: int, srs_offset: int = 0) -> bytes:
+        """partial -> all_gather -> sum, chained on the device: the engine's lane, torch's current stream (RCCL behind it)
+        and the lane again hand over through events; the host blocks once, for the result."""
+        stream = self.torch.cuda.current_stream().cuda_stream
+        ticket = self.engine.msm_sharded_begin(slot, n, srs_offset, self.src.data_ptr(), stream)
+        self.dist.all_gather_into_tensor(self.out, self.src, group=self.group)
+        return self.engine.msm_sharded_finish(ticket, self.out.data_ptr(), self.world, stream)
+
+    def msm_blocking(self, slot: int, n: int, srs_offset: int = 0) -> bytes:
+        """The same step through the blocking entry points (three host synchronisations)."""
         self.engine.msm_partial_resident_dev(slot, n, srs_offset, self.src.data_ptr())   # complete on return
         self.dist.all_gather_into_tensor(self.out, self.src, group=self.group)
         self.torch.cuda.current_stream().synchronize()                                   # RCCL done before the sum reads

@@ -271,6 +271,21 @@ class HipEngine:
         self._chk(self._lib.kzg_g1_sum_dev(self._h, ctypes.c_void_p(dev_ptr), count, out))
         return out.raw
 
+    def msm_sharded_begin(self, slot: int, n: int, srs_offset: int, dev_ptr: int, consumer_stream: int) -> int:
+        """Queue this rank's partial MSM; its 192 bytes land at `dev_ptr` and `consumer_stream` (a raw hipStream_t, e.g.
+        `torch.cuda.current_stream().cuda_stream`) waits for them on the device.  Returns a ticket; nothing blocks."""
+        t = ctypes.c_int(-1)
+        self._chk(self._lib.kzg_msm_sharded_begin(self._h, slot, n, srs_offset, ctypes.c_void_p(dev_ptr),
+                                                  ctypes.c_void_p(consumer_stream), ctypes.byref(t)))
+        return t.value
+
+    def msm_sharded_finish(self, ticket: int, dev_ptr: int, count: int, producer_stream: int) -> bytes:
+        """Sum the `count` gathered partials at `dev_ptr` once `producer_stream` has reached this point -> 48 bytes."""
+        out = ctypes.create_string_buffer(48)
+        self._chk(self._lib.kzg_msm_sharded_finish(self._h, ticket, ctypes.c_void_p(dev_ptr), count,
+                                                   ctypes.c_void_p(producer_stream), out))
+        return out.raw
+
     def commit_open_resident(self, i: int, slot: int, T: int, alpha_be32: bytes,
                              evaluation_form: bool = True) -> Tuple[bytes, bytes, bytes]:
         c, ev, pf = ctypes.create_string_buffer(48), ctypes.create_string_buffer(32), ctypes.create_string_buffer(48)
