@@ -178,6 +178,26 @@ def test_msm_matches_c_oracle(hip, lg, window):
     assert eng.msm(sc[: 32 * m], off) == oc.msm(srs[96 * off:96 * (off + m)], sc[: 32 * m], threads=8)
 
 
+def test_widest_window_24_msm_and_batched_commit_open(hip):
+    """c = 24 (what 2^26-point slices get: 11 windows, 2^23 buckets) on a small input, where it is cheap to check against
+    the oracle: the plain MSM, and a batched commit+open, whose sort key carries one more bit (24 in all: the widest the
+    sort's 12 + 12 split takes)."""
+    lg, n = 10, 1 << 10
+    eng = hip(24)
+    tx = 0x24C0DE
+    eng.gen_srs(tx, 1, lg, 0)
+    assert eng.window == 24
+    sc = rand_scalars_bytes(n, 24)
+    assert eng.msm(sc, 0) == oc.g1_mul_gen(o.poly_eval(ints(sc), tx).to_bytes(32, "big"))
+    srs = eng.srs_read(0, n)
+    alpha = (0xA1FA << 100) + 7
+    row = rand_scalars_bytes(n, 25)
+    c, ev, pf = eng.commit_open(0, row, alpha.to_bytes(32, "big"), True)
+    ec = oc.commit(srs, row, True, threads=8)
+    ee, ep = oc.open_(srs, row, alpha.to_bytes(32, "big"), True, threads=8)
+    assert (c, ev, pf) == (ec, ee, ep)
+
+
 @pytest.mark.parametrize("dist", ["all_equal", "small_32bit", "all_r_minus_1", "one_hot", "two_values"])
 def test_msm_adversarial_scalar_distributions(hip, dist):
     """Structured scalars pile every digit on a few buckets: the chunked accumulate + log-depth fold must stay
