@@ -614,7 +614,7 @@ __global__ void __launch_bounds__(256) k_fold_heads(const uint32_t* __restrict__
     g1_xyzz_t a, b, r;
     load_xyzz(a, &buckets[key]);
     load_xyzz(b, &carries[t]);
-    g1_add(r, a, b);
+    g1_add<true>(r, a, b);   // one full addition per lane, throughput-bound like the wide tree levels: inlined products
     store_xyzz(&buckets[key], r);
 }
 
