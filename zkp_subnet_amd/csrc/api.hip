@@ -97,6 +97,7 @@ struct Lane {
     int index = 0;
     hipStream_t stream = nullptr;
     DevBuf rank, sorted, hist, offsets, bufA, bufB, bufC, carries, carry_key;      // MSM workspace
+    DevBuf ntt_mid;               // the vector between the passes of an NTT (9 words per element)
     DevBuf in_be, scal, coeffA, coeffB, qbuf, hbuf, hnext, out_be;                 // request buffers
     uint8_t* tail = nullptr;      // device, TB_SIZE
     uint8_t* pin = nullptr;       // host pinned, 4096
@@ -523,7 +524,7 @@ int ensure_twiddles(kzg_ctx* ctx, Lane& L, int log_n, int inverse, uint32_t** tw
     bool built = false;
     if (log_n >= 1 && !m.count(log_n)) {
         DevBuf b;
-        HIPCHK(ctx, b.ensure(((size_t)1 << (log_n - 1)) * 32));
+        HIPCHK(ctx, b.ensure(((size_t)1 << (log_n - 1)) * 48));   // nine 29-bit limbs per twiddle in a 48-byte slot
         launch_fr_twiddles(L.stream, b.as<uint32_t>(), log_n, inverse);
         m[log_n] = std::move(b);
         built = true;
@@ -554,8 +555,9 @@ int row_to_coeffs(kzg_ctx* ctx, Lane& L, const uint32_t* row_dev, uint64_t T, in
     int rc = ensure_twiddles(ctx, L, lg, 1, &tw, &invn);
     if (rc) return rc;
     HIPCHK(ctx, L.coeffB.ensure(T * 32));
+    HIPCHK(ctx, L.ntt_mid.ensure(T * 48));
     Span sp(ctx, L, KZG_T_NTT);
-    launch_fr_ntt(L.stream, row_dev, L.coeffB.as<uint32_t>(), lg, tw, invn);
+    launch_fr_ntt(L.stream, row_dev, L.coeffB.as<uint32_t>(), lg, tw, invn, L.ntt_mid.as<uint32_t>());
     *coeffs = L.coeffB.as<uint32_t>();
     return KZG_OK;
 }
@@ -870,7 +872,7 @@ void kzg_destroy(kzg_ctx* ctx) {
     for (Lane& L : ctx->lane) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         for (DevBuf* b : {&L.rank, &L.sorted, &L.hist, &L.offsets, &L.bufA, &L.bufB, &L.bufC, &L.carries, &L.carry_key,
-                          &L.in_be, &L.scal, &L.coeffA, &L.coeffB, &L.qbuf, &L.hbuf, &L.hnext, &L.out_be})
+                          &L.in_be, &L.scal, &L.coeffA, &L.coeffB, &L.qbuf, &L.hbuf, &L.hnext, &L.out_be, &L.ntt_mid})
             b->release();
         for (hipEvent_t e : L.ev_pool) (void)hipEventDestroy(e);
         for (hipEvent_t e : {L.ev_sorted, L.ev_done, L.ev_coeffs, L.ev_ext})
@@ -1160,9 +1162,10 @@ static int ntt_dev(kzg_ctx* ctx, Lane& L, uint32_t* data, uint64_t n, int invers
     int rc = ensure_twiddles(ctx, L, lg, inverse, &tw, inverse ? &invn : nullptr);
     if (rc) return rc;
     HIPCHK(ctx, L.coeffB.ensure(n * 32));
+    HIPCHK(ctx, L.ntt_mid.ensure(n * 48));
     {
         Span sp(ctx, L, KZG_T_NTT);
-        launch_fr_ntt(L.stream, data, L.coeffB.as<uint32_t>(), lg, tw, inverse ? invn : nullptr);
+        launch_fr_ntt(L.stream, data, L.coeffB.as<uint32_t>(), lg, tw, inverse ? invn : nullptr, L.ntt_mid.as<uint32_t>());
         HIPCHK(ctx, hipMemcpyAsync(data, L.coeffB.p, n * 32, hipMemcpyDeviceToDevice, L.stream));
     }
     return KZG_OK;

@@ -75,7 +75,9 @@ KZG_DEV void fr_root_2_32(fr9_t& w, int inverse) {
     fr9_from_words(w, t);
     fr9_to_mont(w, w);
 }
-// tw[k] = w_n^(+-k), k < n/2, Montgomery form; 64 consecutive k per lane
+// tw = w_n^(+-k), k < n/2, Montgomery form, canonical, as the NINE 29-bit limbs the butterflies multiply by, in a 48-byte
+// slot each: a butterfly reads its twiddle with three 16-byte loads and no conversion.
+// 64 consecutive k per lane
 __global__ void __launch_bounds__(256) k_fr_twiddles(uint32_t* __restrict__ tw, int log_n, int inverse) {
     const uint64_t half = (uint64_t)1 << (log_n - 1);
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -94,7 +96,12 @@ __global__ void __launch_bounds__(256) k_fr_twiddles(uint32_t* __restrict__ tw, 
     for (uint64_t k = k0; k < k0 + 64 && k < half; k++) {
         fr9_t c;
         fr9_canon(c, cur);
-        fr9_store(tw + 8 * k, c);
+        {
+            uint4* q = reinterpret_cast<uint4*>(tw + 12 * k);
+            q[0] = make_uint4(c.l[0], c.l[1], c.l[2], c.l[3]);
+            q[1] = make_uint4(c.l[4], c.l[5], c.l[6], c.l[7]);
+            q[2] = make_uint4(c.l[8], 0u, 0u, 0u);
+        }
         fr9_mul(cur, cur, w);
     }
 }
@@ -144,14 +151,39 @@ KZG_DEV void tile_put(NttTile& sm, uint32_t e, const fr9_t& v) {
 #pragma unroll
     for (int i = 0; i < 9; i++) sm.l[i][e] = v.l[i];
 }
-template <uint32_t NT_>
+// Between the passes of a transform the vector is kept in `mid`, the nine 29-bit limbs of an element in a 48-byte slot,
+// values partially reduced (< 2r, fr9_reduce_approx): a pass that is not the last stores without
+// the canonicalising product (27 % of the products of a three-pass transform), a pass that is not the first loads without
+// unpacking.  LAST: this pass writes `out` (8-word canonical elements, 1/n applied).  The first pass reads `in`.
+// nine limbs in a 48-byte slot (three 16-byte accesses; element-major, so a tile row stays C x 48 contiguous bytes)
+KZG_DEV void limbs12_get(fr9_t& v, const uint32_t* __restrict__ base, uint64_t e) {
+    const uint4* q = reinterpret_cast<const uint4*>(base + 12 * e);
+    const uint4 a = q[0], b = q[1], c = q[2];
+    v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w;
+    v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
+    v.l[8] = c.x;
+}
+KZG_DEV void limbs12_put(uint32_t* __restrict__ base, uint64_t e, const fr9_t& v) {
+    uint4* q = reinterpret_cast<uint4*>(base + 12 * e);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    q[2] = make_uint4(v.l[8], 0u, 0u, 0u);
+}
+KZG_DEV void mid_get(fr9_t& v, const uint32_t* __restrict__ mid, uint64_t, uint64_t e) { limbs12_get(v, mid, e); }
+KZG_DEV void mid_put(uint32_t* __restrict__ mid, uint64_t, uint64_t e, const fr9_t& v_norm) {
+    fr9_t t;
+    fr9_reduce_approx(t, v_norm);
+    limbs12_put(mid, e, t);
+}
+template <uint32_t NT_, bool LAST>
 __global__ void __launch_bounds__(NT_) k_fr_ntt_pass(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                      int log_n, int s0, int S, int logC,
+                                                      uint32_t* __restrict__ mid, int log_n, int s0, int S, int logC,
                                                       const uint32_t* __restrict__ tw,
                                                       const uint32_t* __restrict__ scale_or_null) {
     __shared__ NttTile sm;
     const uint32_t R = 1u << S, C = 1u << logC, E = R << logC;
     const bool first = s0 == 0;
+    const uint64_t n = (uint64_t)1 << log_n;
     const int log_nt = log_n - S;  // first pass: tiles
     // ---- load
     if (first) {
@@ -170,7 +202,7 @@ __global__ void __launch_bounds__(NT_) k_fr_ntt_pass(const uint32_t* __restrict_
         for (uint32_t e = threadIdx.x; e < E; e += NT_) {
             const uint32_t r = e >> logC, c = e & (C - 1);
             fr9_t v;
-            fr9_load(v, out + 8 * (base + ((uint64_t)r << s0) + c));
+            mid_get(v, mid, n, base + ((uint64_t)r << s0) + c);
             tile_put(sm, e, v);                              // LDS layout [row][column]
         }
     }
@@ -181,6 +213,7 @@ __global__ void __launch_bounds__(NT_) k_fr_ntt_pass(const uint32_t* __restrict_
     for (int l = 0; l < S; l++) {
         const uint32_t half = 1u << l;
         const int s = s0 + l;
+        const bool renorm = ((S - 1 - l) & 1) == 0;
         for (uint32_t b = threadIdx.x; b < E / 2; b += NT_) {
             uint32_t ei, ej;
             uint64_t k;
@@ -202,21 +235,26 @@ __global__ void __launch_bounds__(NT_) k_fr_ntt_pass(const uint32_t* __restrict_
             fr9_t u, v, w, t;
             tile_get(u, sm, ei);
             tile_get(v, sm, ej);
-            fr9_load(w, tw + 8 * (k << (log_n - s - 1)));
+            limbs12_get(w, tw, k << (log_n - s - 1));
             fr9_mul(t, v, w);
             fr9_add(v, u, t);
             fr9_sub4(w, u, t);
-            fr9_norm(v, v);
-            fr9_norm(w, w);
+            if (renorm) {   // every second stage, and always the last: in between the limbs stay below 2^31 (header of fr29.hip.h)
+                fr9_norm(v, v);
+                fr9_norm(w, w);
+            }
             tile_put(sm, ei, v);
             tile_put(sm, ej, w);
         }
         __syncthreads();
     }
-    // ---- store: canonical again; the same product applies the 1/n on the last pass of an inverse transform
+    // ---- store.  Last pass: canonical 8-word elements; the same product applies the 1/n of an inverse transform.
+    // Earlier passes: the nine limbs, partially reduced, to `mid`.
     fr9_t f;
-    if (scale_or_null) fr9_load(f, scale_or_null);
-    else fr9_one(f);
+    if constexpr (LAST) {
+        if (scale_or_null) fr9_load(f, scale_or_null);
+        else fr9_one(f);
+    }
     if (first) {
         const uint32_t u = blockIdx.x;
         const uint64_t tiles_per_c = ((uint64_t)1 << log_nt) >> logC;
@@ -226,9 +264,13 @@ __global__ void __launch_bounds__(NT_) k_fr_ntt_pass(const uint32_t* __restrict_
             const uint64_t t = (uint64_t)brev_bits(c, logC) * tiles_per_c + t_low;
             fr9_t v;
             tile_get(v, sm, e);
-            fr9_mul(v, v, f);
-            fr9_canon(v, v);
-            fr9_store(out + 8 * ((t << S) + r), v);
+            if constexpr (LAST) {
+                fr9_mul(v, v, f);
+                fr9_canon(v, v);
+                fr9_store(out + 8 * ((t << S) + r), v);
+            } else {
+                mid_put(mid, n, (t << S) + r, v);
+            }
         }
     } else {
         const uint64_t groups = ((uint64_t)1 << s0) >> logC;
@@ -238,9 +280,13 @@ __global__ void __launch_bounds__(NT_) k_fr_ntt_pass(const uint32_t* __restrict_
             const uint32_t r = e >> logC, c = e & (C - 1);
             fr9_t v;
             tile_get(v, sm, e);
-            fr9_mul(v, v, f);
-            fr9_canon(v, v);
-            fr9_store(out + 8 * (base + ((uint64_t)r << s0) + c), v);
+            if constexpr (LAST) {
+                fr9_mul(v, v, f);
+                fr9_canon(v, v);
+                fr9_store(out + 8 * (base + ((uint64_t)r << s0) + c), v);
+            } else {
+                mid_put(mid, n, base + ((uint64_t)r << s0) + c, v);
+            }
         }
     }
 }
@@ -446,7 +492,7 @@ void launch_fr_twiddles(hipStream_t s, uint32_t* tw, int log_n, int inverse) {
 }
 void launch_fr_inv_pow2(hipStream_t s, uint32_t* out, int log_n) { k_fr_inv_pow2<<<1, 64, 0, s>>>(out, log_n); }
 void launch_fr_ntt(hipStream_t s, const uint32_t* in, uint32_t* out, int log_n, const uint32_t* tw,
-                   const uint32_t* scale_or_null) {
+                   const uint32_t* scale_or_null, uint32_t* mid) {
     const uint64_t n = (uint64_t)1 << log_n;
     if (log_n == 0) {  // length 1: the transform is the identity (1/1 = 1)
         (void)hipMemcpyAsync(out, in, 32, hipMemcpyDeviceToDevice, s);
@@ -462,16 +508,16 @@ void launch_fr_ntt(hipStream_t s, const uint32_t* in, uint32_t* out, int log_n, 
         const int avail = p == 0 ? log_n - S : s0;
         if (logC > avail) logC = avail;
         if (p == 0 && logC > 2) logC = 2;  // first pass: 4 tiles (128 B source rows) keep the tiles' stores long
-        const uint64_t blocks = n >> (S + logC);
+        const uint32_t blocks = (uint32_t)(n >> (S + logC));
+        const bool last = p == passes - 1;
         // one butterfly per thread and stage when the tile allows it (512 threads for a full 1024-element tile): a stage
         // is then ONE dependent Fr product deep instead of two -- what counts for short rows (2^16: two passes on 64
         // workgroups, pure latency) -- and long rows just run more waves per CU
-        if ((1u << (S + logC)) >= 1024)
-            k_fr_ntt_pass<512><<<(uint32_t)blocks, 512, 0, s>>>(in, out, log_n, s0, S, logC, tw,
-                                                                p == passes - 1 ? scale_or_null : nullptr);
-        else
-            k_fr_ntt_pass<256><<<(uint32_t)blocks, 256, 0, s>>>(in, out, log_n, s0, S, logC, tw,
-                                                                p == passes - 1 ? scale_or_null : nullptr);
+        const bool big = (1u << (S + logC)) >= 1024;
+        if (big && last) k_fr_ntt_pass<512, true><<<blocks, 512, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, scale_or_null);
+        else if (big) k_fr_ntt_pass<512, false><<<blocks, 512, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, nullptr);
+        else if (last) k_fr_ntt_pass<256, true><<<blocks, 256, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, scale_or_null);
+        else k_fr_ntt_pass<256, false><<<blocks, 256, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, nullptr);
         s0 += S;
     }
 }

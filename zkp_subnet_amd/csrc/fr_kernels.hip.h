@@ -7,12 +7,14 @@ void launch_fr_from_be(hipStream_t s, const uint8_t* be, uint32_t* out, uint64_t
 void launch_fr_from_host32(hipStream_t s, const uint8_t be32[32], uint32_t* out, int to_mont, uint32_t* bad);
 void launch_fr_to_be(hipStream_t s, const uint32_t* in, uint8_t* be, uint64_t n, int from_mont);
 void launch_fr_from_mont(hipStream_t s, const uint32_t* in, uint32_t* out, uint64_t n);
-// tw: 2^(log_n-1) Montgomery-form powers of w_n (inverse: of w_n^-1)
+// tw: 2^(log_n-1) Montgomery-form powers of w_n (inverse: of w_n^-1), 12 words each (nine limbs + padding)
 void launch_fr_twiddles(hipStream_t s, uint32_t* tw, int log_n, int inverse);
 void launch_fr_inv_pow2(hipStream_t s, uint32_t* out, int log_n);
 // out-of-place natural-order NTT of 2^log_n Montgomery-form elements; scale (1/n, Montgomery) applied if given
+// tw: the table launch_fr_twiddles fills (n/2 twiddles, nine 29-bit limbs in a 48-byte slot each).  mid: 12 * n words of
+// scratch (the vector between passes, same slot format); unused when log_n <= 8 (one pass)
 void launch_fr_ntt(hipStream_t s, const uint32_t* in, uint32_t* out, int log_n, const uint32_t* tw,
-                   const uint32_t* scale_or_null);
+                   const uint32_t* scale_or_null, uint32_t* mid);
 // y = f(alpha) (Montgomery) and, if q is given, the n-1 canonical coefficients of (f - y)/(X - alpha)
 // h, hnext: ceil(n/4) * 3/2 + 64 Fr scratch each (level arrays stacked; the chunk length shrinks to 4 for small rows)
 // alpha_be32_host given: alpha arrives as 32 big-endian HOST bytes (a kernel argument of the first kernel), its
