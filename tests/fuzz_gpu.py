@@ -32,15 +32,21 @@ def scalars(n, kind):
         return b"".join(rnd.choice(pool).to_bytes(32, "big") for _ in range(n))
     if kind == "equal":
         return rnd.randrange(1, o.R).to_bytes(32, "big") * n
+    if kind == "clustered":   # low digits spread over a few adjacent buckets: oversized sort partitions without a dominant bucket
+        base = rnd.randrange(o.R >> 1) & ~((1 << 40) - 1)
+        spread = rnd.choice((4, 6, 9, 12))
+        return b"".join((base + rnd.randrange(1 << spread)).to_bytes(32, "big") for _ in range(n))
     few = [rnd.randrange(o.R) for _ in range(3)]
     return b"".join(rnd.choice(few).to_bytes(32, "big") for _ in range(n))
 
 
 while time.time() < t_end:
     # ---- one engine / SRS per round
-    lg = rnd.choice((3, 5, 8, 10, 11, 12, 13, 14, 15, 16, 16, 17, 18))
+    lg = rnd.choice((3, 5, 8, 10, 11, 12, 13, 14, 15, 16, 16, 17, 18)) if rnd.random() < 0.93 else rnd.choice((19, 20))
     ms = rnd.choice((0, 0, 1, 2)) if lg >= 4 else 0
     window = rnd.choice((0, 0, 0, 4, 5, 7, 8, 9, 11, 12, 13, 15, 16, 17, 18))
+    if lg <= 14 and rnd.random() < 0.15:
+        window = rnd.choice((19, 20, 22, 24))       # the widest windows (what 2^20 .. 2^26 slices use) on small inputs
     tx, ty = rnd.randrange(2, o.R), rnd.randrange(2, o.R)
     eng = HipEngine(0, window=window)
     i = rnd.randrange(1 << ms)
@@ -51,7 +57,7 @@ while time.time() < t_end:
     for _ in range(3):
         n = rnd.choice((T, T, rnd.randrange(1, T + 1)))
         off = rnd.randrange(0, T - n + 1)
-        kind = rnd.choice(("uniform", "uniform", "small", "edge", "equal", "few"))
+        kind = rnd.choice(("uniform", "uniform", "small", "edge", "equal", "few", "clustered"))
         sc = scalars(n, kind)
         want = oc.msm(srs[96 * off:96 * (off + n)], sc)
         assert eng.msm(sc, off) == want, ("msm", lg, ms, window, n, off, kind)
