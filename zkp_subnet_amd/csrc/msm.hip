@@ -876,6 +876,20 @@ __global__ void __launch_bounds__(256) k_fold_heads_coop(const uint32_t* __restr
     coop_add(sm, dst, dst, &carries[active ? t : 0], active);
 }
 
+// the late fold steps of a short row: few pairs are left (about nchunks / 2d), so one WAVE per carry -- the inactive ones
+// leave at once -- runs each addition lane-parallel (~6 us a step against ~13 for the cooperative form)
+__global__ void __launch_bounds__(64) k_fold_step_lp(const uint32_t* __restrict__ offsets,
+                                                      const uint32_t* __restrict__ carry_key, uint32_t chunk,
+                                                      uint32_t d, g1_xyzz_t* __restrict__ carries) {
+    tail_priority();
+    __shared__ LpScratch sm;
+    const uint32_t t = blockIdx.x;
+    uint32_t key, i, len;
+    if (!carry_pos(offsets, carry_key, chunk, t, key, i, len)) return;
+    if ((i & (2u * d - 1u)) || i + d >= len) return;
+    lp_add(sm, &carries[t], &carries[t], &carries[t + d], lp_lane());
+}
+
 // same merge as k_msm_tree_level, 64 operations per 256-thread workgroup, for the narrow (latency-bound) levels
 __global__ void __launch_bounds__(256) k_msm_tree_level_coop(const g1_xyzz_t* __restrict__ in,
                                                               const g1_xyzz_t* __restrict__ prev,
@@ -1532,6 +1546,9 @@ void launch_fold_maxlen(hipStream_t s, const uint32_t* offsets, uint32_t nbucket
 }
 // cooperative fold kernels (4 waves per 64 carries) up to this many chunks, one lane per carry above (A/B: 2^16 batched
 // commit+open, 65536 chunks: fixup 0.090 -> 0.054 ms; no gain at 131072 chunks)
+#ifndef KZG_FOLD_LP_MAX
+#define KZG_FOLD_LP_MAX LP_MAX_OPS
+#endif
 #ifndef KZG_FOLD_COOP_MAX
 #define KZG_FOLD_COOP_MAX 65536
 #endif
@@ -1539,6 +1556,9 @@ void launch_fold_step(hipStream_t s, const uint32_t* offsets, const uint32_t* ca
                       uint32_t nchunks, uint32_t d, g1_xyzz_t* carries) {
     if (!nchunks) return;
     if (nchunks > KZG_FOLD_COOP_MAX) k_fold_step<<<nblk(nchunks, 256), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, d, carries);
+#if !defined(KZG_NO_LP) && !defined(KZG_NO_FOLD_LP)
+    else if (nchunks / (2 * d) <= KZG_FOLD_LP_MAX) k_fold_step_lp<<<nchunks, 64, 0, s>>>(offsets, carry_key, chunk, d, carries);
+#endif
     else k_fold_step_coop<<<nblk(nchunks, 64), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, d, carries);
 }
 void launch_fold_heads(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
