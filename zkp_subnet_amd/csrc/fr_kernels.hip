@@ -251,9 +251,9 @@ __global__ void __launch_bounds__(NT_) k_fr_ntt_pass(const uint32_t* __restrict_
     // ---- store.  Last pass: canonical 8-word elements; the same product applies the 1/n of an inverse transform.
     // Earlier passes: the nine limbs, partially reduced, to `mid`.
     fr9_t f;
+    fr9_zero(f);
     if constexpr (LAST) {
         if (scale_or_null) fr9_load(f, scale_or_null);
-        else fr9_one(f);
     }
     if (first) {
         const uint32_t u = blockIdx.x;
@@ -265,8 +265,8 @@ __global__ void __launch_bounds__(NT_) k_fr_ntt_pass(const uint32_t* __restrict_
             fr9_t v;
             tile_get(v, sm, e);
             if constexpr (LAST) {
-                fr9_mul(v, v, f);
-                fr9_canon(v, v);
+                if (scale_or_null) { fr9_mul(v, v, f); fr9_canon(v, v); }
+                else fr9_reduce(v, v);          // forward transform: nothing to multiply by
                 fr9_store(out + 8 * ((t << S) + r), v);
             } else {
                 mid_put(mid, n, (t << S) + r, v);
@@ -281,8 +281,8 @@ __global__ void __launch_bounds__(NT_) k_fr_ntt_pass(const uint32_t* __restrict_
             fr9_t v;
             tile_get(v, sm, e);
             if constexpr (LAST) {
-                fr9_mul(v, v, f);
-                fr9_canon(v, v);
+                if (scale_or_null) { fr9_mul(v, v, f); fr9_canon(v, v); }
+                else fr9_reduce(v, v);
                 fr9_store(out + 8 * (base + ((uint64_t)r << s0) + c), v);
             } else {
                 mid_put(mid, n, base + ((uint64_t)r << s0) + c, v);
