@@ -722,6 +722,23 @@ __global__ void __launch_bounds__(256) k_test_fr(int op, const uint8_t* a_be, co
     if (op == 0) fr9_mul(r, a, b);
     else if (op == 1) fr9_add(r, a, b);
     else if (op == 2) fr9_sub4(r, a, b);
+    else if (op == 5 || op == 6) {
+        // k (a + b) summed lazily, k = 1 + (a mod 29) <= 29: a value up to 58 r with limbs up to 2^30.9, then the
+        // product-free reductions: 5 = fr9_reduce (canonical), 6 = fr9_reduce_approx alone (< 2r)
+        const uint32_t k = 1u + (uint32_t)((((uint64_t)wa[1] << 32) | wa[0]) % 29u);   // test side: (a mod 2^64) mod 29
+        fr9_t s;
+        fr9_add(s, a, b);
+        r = s;
+        for (uint32_t i = 1; i < k; i++) {
+            fr9_add(r, r, s);
+            if ((i & 1) == 0) fr9_norm(r, r);        // limbs stay below 2^31
+        }
+        if (op == 5) fr9_reduce(r, r);
+        else {
+            fr9_norm(r, r);
+            fr9_reduce_approx(r, r);
+        }
+    }
     else fr9_mul(r, a, a);
     fr9_from_mont(r, r);
     fr9_to_words(wr, r);
