@@ -9,6 +9,8 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <atomic>
+#include <chrono>
 #include <string>
 #include <utility>
 #include <vector>
@@ -93,6 +95,8 @@ enum {
     TB_ALPHA_M = 832, TB_Y_M = 864, TB_ALPHA_BE = 896, TB_SIZE = 1024
 };
 #define PIN_MAXLEN 1024           // offset of the fold-depth read-back inside the lane's pinned page
+#define PIN_SEQ 2048              // sequence word of the last published record (polled by finish())
+#define PIN_SEQ_SORT 2052         // sequence word of the last published fold-depth / overflow pair (polled by msm_core)
 struct Lane {
     int index = 0;
     hipStream_t stream = nullptr;
@@ -102,6 +106,9 @@ struct Lane {
     uint8_t* tail = nullptr;      // device, TB_SIZE
     uint8_t* pin = nullptr;       // host pinned, 4096
     uint8_t* pin_dev = nullptr;   // the same page as the GPU addresses it
+    uint32_t pub_seq = 0;         // sequence number of the last record publish on this lane
+    uint32_t sort_seq = 0;        // ... and of the last fold-depth publish
+    bool expect_short = false;    // the request in flight is a short one (set by msm_core): finish() may poll for its record
     bool flags_clean = false;     // the tail record's flag words are zero (left so by the last request's publish)
     bool sort_ws_clean = false;   // the sort's partition counts are zero (left so by every completed sort)
     int skew_hint = 0;            // > 0: the last fast sort overflowed (skewed scalars): go straight to the exact sort
@@ -128,6 +135,7 @@ struct kzg_ctx {
     std::mutex mu;                 // guards lane states, the staging pool, the twiddle caches, config and timings
     std::condition_variable cv;    // a lane or a staging buffer was released
     int c_user = 0, c = 0, nwin = 0;
+    int poll_timeout_ms = 200;   // finish(): how long the pinned page is polled before falling back to the stream
     WinLayout lay;
     uint32_t nbuckets = 0;
     // resident SRS + window tables: table[w*stride + j] = 2^off[w] P_j   (read-only while any lane is busy)
@@ -371,6 +379,20 @@ int ilog2_exact(uint64_t n) {
 // set b is sorted into bucket set b, the sort / accumulate / fold / tree kernels simply see twice the buckets, the
 // tree stops at two roots and out_xyzz[0..1] receive the two sums.  One kernel sequence, one latency-bound tail.
 // The only host wait inside is on the 4-byte fold-depth read-back; the calling thread holds no lock meanwhile.
+// waits until the pinned word at `off` shows `seq` (a k_publish has landed); false if it does not within the budget
+static bool poll_pinned(const kzg_ctx* ctx, const Lane& L, uint32_t off, uint32_t seq) {
+    const volatile uint32_t* w = reinterpret_cast<const volatile uint32_t*>(L.pin + off);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spin = 0;; spin++) {
+        if (*w == seq) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return true;
+        }
+        if ((spin & 0xfff) == 0xfff &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(ctx->poll_timeout_ms)) return false;
+        __builtin_ia32_pause();
+    }
+}
 int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t n, uint64_t srs_offset,
              g1_xyzz_t* out_xyzz, const uint32_t* scalars2 = nullptr, int mont2 = 0) {
     hipStream_t s = L.stream;
@@ -388,6 +410,7 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
     sh.srs_offset = srs_offset; sh.srs_stride = ctx->stride; sh.chunk = pick_chunk(entries);
     const uint32_t nchunks = (uint32_t)((entries + sh.chunk - 1) / sh.chunk);
     const size_t B = sh.nbuckets;
+    L.expect_short = entries <= ((uint64_t)1 << 23);   // up to ~2 ms of GPU time
     // Sort mode.  Fast: no count pass, fixed-capacity partition regions -- right for well-spread scalars (field elements
     // of a polynomial), wrong for skewed ones, where a region overflows: that is detected on the device, costs one wasted
     // sort (the queued accumulate sees an empty MSM), and is remembered for the lane's next few calls.
@@ -413,7 +436,8 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
         // the longest run of carries decides how many fold steps are launched; it depends on the offsets only, so
         // its read-back (with the sort's overflow word) completes while the accumulate kernel runs and costs no bubble
         launch_fold_maxlen(s, L.offsets.as<uint32_t>(), sh.nbuckets, (uint32_t)sh.chunk, max_len_d, L.bufA.as<g1_xyzz_t>());
-        launch_publish(s, max_len_d, L.pin_dev + PIN_MAXLEN, 8);
+        launch_publish(s, max_len_d, L.pin_dev + PIN_MAXLEN, 8, nullptr,
+                       reinterpret_cast<uint32_t*>(L.pin_dev + PIN_SEQ_SORT), ++L.sort_seq);
         HIPCHK(ctx, hipEventRecord(L.ev_sorted, s));
     }
     {
@@ -421,7 +445,15 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
         launch_msm_accumulate(s, sh, ctx->table.as<g1_affine_t>(), L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(),
                               L.bufA.as<g1_xyzz_t>(), L.carries.as<g1_xyzz_t>(), L.carry_key.as<uint32_t>(), nchunks);
     }
-    HIPCHK(ctx, hipEventSynchronize(L.ev_sorted));
+    // short rows: the tail's ~20 launches must be queued while the (short) accumulate runs -- poll for the two words
+    // instead of sleeping on the event
+    auto wait_sorted = [&]() -> hipError_t {
+#ifndef KZG_NO_POLL
+        if (!ctx->profiling && L.expect_short && poll_pinned(ctx, L, PIN_SEQ_SORT, L.sort_seq)) return hipSuccess;
+#endif
+        return hipEventSynchronize(L.ev_sorted);
+    };
+    HIPCHK(ctx, wait_sorted());
     if (fast && max_len_h[1]) {   // a region overflowed: skewed scalars.  Exact sort + accumulate once more.
         L.skew_hint = 16;
         {
@@ -429,7 +461,8 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
             launch_msm_sort(s, sh, scalars, mont, scalars2, mont2, L.hist.as<uint32_t>(), true, L.rank.as<uint2>(),
                             L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(), max_len_d, false, max_len_d + 1);
             launch_fold_maxlen(s, L.offsets.as<uint32_t>(), sh.nbuckets, (uint32_t)sh.chunk, max_len_d, L.bufA.as<g1_xyzz_t>());
-            launch_publish(s, max_len_d, L.pin_dev + PIN_MAXLEN, 8);
+            launch_publish(s, max_len_d, L.pin_dev + PIN_MAXLEN, 8, nullptr,
+                           reinterpret_cast<uint32_t*>(L.pin_dev + PIN_SEQ_SORT), ++L.sort_seq);
             HIPCHK(ctx, hipEventRecord(L.ev_sorted, s));
         }
         {
@@ -437,7 +470,7 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
             launch_msm_accumulate(s, sh, ctx->table.as<g1_affine_t>(), L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(),
                                   L.bufA.as<g1_xyzz_t>(), L.carries.as<g1_xyzz_t>(), L.carry_key.as<uint32_t>(), nchunks);
         }
-        HIPCHK(ctx, hipEventSynchronize(L.ev_sorted));
+        HIPCHK(ctx, wait_sorted());
     }
     {
         Span sp(ctx, L, KZG_T_FIXUP);
@@ -481,14 +514,25 @@ int need_srs(kzg_ctx* ctx) {
 int clear_flags(kzg_ctx* ctx, Lane& L) {
     const bool was_clean = L.flags_clean;
     L.flags_clean = false;
+    L.expect_short = false;
     if (!was_clean) HIPCHK(ctx, hipMemsetAsync(L.flags(), 0, 16, L.stream));
     return KZG_OK;
 }
 // ends a request: the lane's tail record comes back in ONE copy (result points, eval, flags, GPU-side encodings)
 int finish(kzg_ctx* ctx, Lane& L) {
     prof_close(ctx, L);
-    launch_publish(L.stream, L.tail, L.pin_dev, TB_COPY, L.flags());
-    HIPCHK(ctx, hipStreamSynchronize(L.stream));
+    const uint32_t seq = ++L.pub_seq;
+    launch_publish(L.stream, L.tail, L.pin_dev, TB_COPY, L.flags(), reinterpret_cast<uint32_t*>(L.pin_dev + PIN_SEQ), seq);
+    // The record is complete when its sequence word arrives: poll the pinned page (the kernel's completion signal and the
+    // runtime's wake-up come several microseconds later).  Whatever follows on this lane is stream-ordered behind the
+    // publish anyway.  With stage events to read (profiling), on a HIP error, or if nothing arrives: the stream.
+    bool seen = false;
+#ifndef KZG_NO_POLL
+    // only for requests expected to take well under the polling budget (short rows: that is where a few us count); a long
+    // MSM waits in the runtime, which may sleep
+    if (!ctx->profiling && L.expect_short) seen = poll_pinned(ctx, L, PIN_SEQ, seq);
+#endif
+    if (!seen) HIPCHK(ctx, hipStreamSynchronize(L.stream));
     L.flags_clean = true;
     prof_end(ctx, L);
     const uint32_t* f = reinterpret_cast<const uint32_t*>(L.pin + TB_FLAGS);

@@ -1117,12 +1117,18 @@ __global__ void __launch_bounds__(64) k_g1_compress_pair(const g1_xyzz_t* __rest
 // transfer (~16 us on this stack for 832 bytes); the stream synchronisation that follows makes it visible to the host
 // clear2 != null: the two input-error flags of the record are zeroed once copied, so the lane's next request finds them
 // clean without a memset at its start
+// seq_word != null: once every word is out (system-scope fence), the host page's sequence word is set to `seq` -- the
+// host polls it instead of waiting for the stream's completion signal (kernel end + signal + wake-up: several us)
 __global__ void __launch_bounds__(256) k_publish(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst_host, uint32_t words,
-                                                 uint32_t* __restrict__ clear2) {
+                                                 uint32_t* __restrict__ clear2, uint32_t* __restrict__ seq_word, uint32_t seq) {
     for (uint32_t i = threadIdx.x; i < words; i += 256) dst_host[i] = src[i];
-    if (clear2) {
+    if (clear2 || seq_word) {
+        __threadfence_system();
         __syncthreads();
-        if (threadIdx.x < 2) clear2[threadIdx.x] = 0;
+        if (clear2 && threadIdx.x < 2) clear2[threadIdx.x] = 0;
+        if (seq_word && threadIdx.x == 0) {
+            __hip_atomic_store(seq_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 // XYZZ working form <-> the 192-byte partial-sum format of the C-ABI (4 x 12 u32: canonical Montgomery residues)
@@ -1606,9 +1612,10 @@ void launch_g1_compress(hipStream_t s, const g1_xyzz_t* in, uint8_t* out48) {
 void launch_g1_compress_pair(hipStream_t s, const g1_xyzz_t* in0, const g1_xyzz_t* in1, uint8_t* out0, uint8_t* out1) {
     k_g1_compress_pair<<<1, 64, 0, s>>>(in0, in1, out0, out1);
 }
-void launch_publish(hipStream_t s, const void* src_dev, void* dst_host_devptr, uint32_t bytes, uint32_t* clear2) {
+void launch_publish(hipStream_t s, const void* src_dev, void* dst_host_devptr, uint32_t bytes, uint32_t* clear2,
+                    uint32_t* seq_word_devptr, uint32_t seq) {
     k_publish<<<1, 256, 0, s>>>(reinterpret_cast<const uint32_t*>(src_dev), reinterpret_cast<uint32_t*>(dst_host_devptr), bytes / 4,
-                                clear2);
+                                clear2, seq_word_devptr, seq);
 }
 void launch_xyzz_pack(hipStream_t s, const g1_xyzz_t* in, uint32_t* out48w, uint32_t count) {
     if (count) k_xyzz_pack<<<nblk(count, 64), 64, 0, s>>>(in, out48w, count);

@@ -48,7 +48,9 @@ bool msm_sort_fast_ok(const MsmShape& sh);
 uint64_t msm_sort_parted_entries(const MsmShape& sh, bool fast);
 // bytes (multiple of 4) from device memory to a device-visible host pointer, by a kernel
 // clear2: two device words zeroed after the copy (the record's input-error flags), or null
-void launch_publish(hipStream_t s, const void* src_dev, void* dst_host_devptr, uint32_t bytes, uint32_t* clear2 = nullptr);
+// seq_word_devptr: a word of the host page set to `seq` after everything else has landed (the host may poll it)
+void launch_publish(hipStream_t s, const void* src_dev, void* dst_host_devptr, uint32_t bytes, uint32_t* clear2 = nullptr,
+                    uint32_t* seq_word_devptr = nullptr, uint32_t seq = 0);
 void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t* table, const uint32_t* offsets,
                            const uint32_t* sorted, g1_xyzz_t* buckets, g1_xyzz_t* carries, uint32_t* carry_key,
                            uint32_t nchunks);
