@@ -410,7 +410,7 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
     sh.srs_offset = srs_offset; sh.srs_stride = ctx->stride; sh.chunk = pick_chunk(entries);
     const uint32_t nchunks = (uint32_t)((entries + sh.chunk - 1) / sh.chunk);
     const size_t B = sh.nbuckets;
-    L.expect_short = entries <= ((uint64_t)1 << 23);   // up to ~2 ms of GPU time
+    L.expect_short = entries <= ((uint64_t)1 << 24);   // up to ~3 ms of GPU time (a 2^20-point MSM)
     // Sort mode.  Fast: no count pass, fixed-capacity partition regions -- right for well-spread scalars (field elements
     // of a polynomial), wrong for skewed ones, where a region overflows: that is detected on the device, costs one wasted
     // sort (the queued accumulate sees an empty MSM), and is remembered for the lane's next few calls.
