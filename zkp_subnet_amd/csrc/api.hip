@@ -1433,7 +1433,8 @@ int kzg_msm_submit(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, int 
         if (partial) queue_pack(ctx, L);
         else queue_encode(ctx, L, true, false);
         prof_close(ctx, L);
-        launch_publish(L.stream, L.tail, L.pin_dev, TB_COPY, L.flags());
+        launch_publish(L.stream, L.tail, L.pin_dev, TB_COPY, L.flags(), reinterpret_cast<uint32_t*>(L.pin_dev + PIN_SEQ),
+                       ++L.pub_seq);
         hipError_t e = hipEventRecord(L.ev_done, L.stream);
         if (e == hipSuccess) e = hipGetLastError();
         if (e != hipSuccess) rc = fail(ctx, KZG_E_HIP, std::string("kzg_msm_submit: ") + hipGetErrorString(e));
@@ -1458,7 +1459,11 @@ int kzg_msm_wait(kzg_ctx* ctx, int ticket, uint8_t* out) {
         L.state = LANE_WAITING;
     }
     (void)hipSetDevice(ctx->device);
-    hipError_t e = hipEventSynchronize(L.ev_done);  // not under the lock: other threads submit / run meanwhile
+    hipError_t e = hipSuccess;  // not under the lock: other threads submit / run meanwhile
+#ifndef KZG_NO_POLL
+    if (ctx->profiling || !L.expect_short || !poll_pinned(ctx, L, PIN_SEQ, L.pub_seq))
+#endif
+        e = hipEventSynchronize(L.ev_done);
     int rc = KZG_OK;
     if (e != hipSuccess) {
         rc = fail(ctx, KZG_E_HIP, std::string("hipEventSynchronize(ticket): ") + hipGetErrorString(e));
