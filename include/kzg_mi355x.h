@@ -116,7 +116,8 @@ int kzg_msm_partial(kzg_ctx* ctx, const uint8_t* scalars_be32, uint64_t n, uint6
 int kzg_g1_sum(kzg_ctx* ctx, const uint8_t* partials_xyzz192, uint32_t count, uint8_t out48[48]);
 /* Pianist master aggregation: sum of `count` 48-byte compressed G1 points (the worker rows' commitments,
  * sum_i commit_i = commitment of the bivariate polynomial; reference neurons/validator.py:196-198, README.md:38).
- * Inputs are decompressed on the GPU (one Fp square root each); malformed / off-curve input -> KZG_E_POINT. */
+ * Inputs are decompressed on the GPU (one Fp square root each) and checked for membership in G1 (the prime-order
+ * subgroup: they come from untrusted miners); malformed / off-curve / out-of-subgroup input -> KZG_E_POINT. */
 int kzg_g1_sum_compressed(kzg_ctx* ctx, const uint8_t* points_c48, uint32_t count, uint8_t out48[48]);
 /* Device-pointer forms for the collective path: the partial is written into / the gathered partials are read from the
  * CALLER's device memory (the tensors of an RCCL all_gather), so a step makes no host round trip for them.
@@ -148,6 +149,9 @@ int kzg_msm_partial_resident(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_of
  * need the whole context (SRS load, kzg_upload_fr, kzg_ntt_resident) fail with KZG_E_BUSY while any ticket is out. */
 int kzg_msm_submit(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, int partial, int* out_ticket);
 int kzg_msm_wait(kzg_ctx* ctx, int ticket, uint8_t* out);
+/* Gives up a ticket of kzg_msm_submit / kzg_msm_sharded_begin whose result will not be collected (the collective
+ * between _begin and _finish raised, a peer died): drains the lane and frees it.  Without it the lane would stay parked. */
+int kzg_msm_cancel(kzg_ctx* ctx, int ticket);
 int kzg_commit_open_resident(kzg_ctx* ctx, uint32_t i, int slot, uint64_t T, int evaluation_form,
                              const uint8_t alpha_be32[32], uint8_t out_commitment48[48], uint8_t out_eval32[32],
                              uint8_t out_proof48[48]);
@@ -196,11 +200,6 @@ int kzg_test_field(kzg_ctx* ctx, int field /*0 Fp,1 Fr*/, int op /*0 mul,1 add,2
 int kzg_test_g1(kzg_ctx* ctx, int op /*0 a+b mixed,1 2a+b full,2 2a,3 4a,4 a+20a+20b chain; lane-parallel forms: 5 2a+b,
                                          6 4a, 7 ten rounds r <- 2r+b from a*/, const uint8_t* a_be96,
                 const uint8_t* b_be96, uint8_t* out_be96, uint64_t n);
-
-/* ---- prototype measurement hook (zkp_subnet_amd/csrc/baff_proto.hip, scripts/proto_baff.py): times k_msm_accumulate and
- *      three batched-affine pairwise-addition rounds on the same sorted entries.  Not part of the serving surface. */
-int kzg_proto_baff(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint32_t lanes, float out_ms[8],
-                   uint32_t out_counts[8]);
 
 #ifdef __cplusplus
 }

@@ -3,7 +3,9 @@ k_msm_accumulate, from the gfx950 ISA hipcc emits for csrc/msm.hip (no GPU neede
 [loop header .. the `g1_madd_checked` exit label]; the rare doubling branch (equal x coordinates: g1_dbl_aff inlined,
 the block between the second-level `s_cbranch_execz` pair) is excluded.  Writes profiles/isa_counts.json.
 
-    python scripts/count_mads.py"""
+    python scripts/count_mads.py            # rewrite profiles/isa_counts.json
+    python scripts/count_mads.py --check    # exit 1 if the committed file no longer matches the current source
+(bench.py quotes `mad_issue.wave_mads_per_launch` from that file; tests/test_host_logic.py runs --check so it cannot go stale)"""
 import json
 import os
 import re
@@ -45,5 +47,12 @@ valu = sum(1 for i, l in enumerate(body) if re.match(r"\s*v_", l) and not (best[
 out = {"kernel": "k_msm_accumulate", "mads_per_mixed_add": common, "mads_in_rare_doubling_branch": rare,
        "valu_per_loop_iteration_static": valu,
        "source": "hipcc --offload-arch=gfx950 -O3 -save-temps of zkp_subnet_amd/csrc/msm.hip (scripts/count_mads.py)"}
-json.dump(out, open(os.path.join(ROOT, "profiles", "isa_counts.json"), "w"), indent=1)
+path = os.path.join(ROOT, "profiles", "isa_counts.json")
+if "--check" in sys.argv:
+    have = json.load(open(path))
+    keys = ("kernel", "mads_per_mixed_add", "mads_in_rare_doubling_branch")
+    diff = {k: (have.get(k), out[k]) for k in keys if have.get(k) != out[k]}
+    print(json.dumps({"committed": have, "current": out, "stale": diff}))
+    sys.exit(1 if diff else 0)
+json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out))

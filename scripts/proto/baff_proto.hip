@@ -11,7 +11,7 @@
 // a real MSM (pairs of consecutive entries); later rounds read the previous round's output in order.
 // Pairs with equal x (doubling / cancellation) are only counted: the prototype measures cost, it does not replace the
 // accumulate kernel.  Checked against the XYZZ formulas by k_baff_check.
-#include "msm.hip.h"
+#include "../../zkp_subnet_amd/csrc/msm.hip.h"
 
 KZG_DEV void baff_load_x(fp_t& x, const g1_affine_t* row) {
     const uint4* q = reinterpret_cast<const uint4*>(row);

@@ -1,5 +1,5 @@
 """A/B of the batched-affine prototype (csrc/baff_proto.hip) against k_msm_accumulate on the same sorted entries
-(dev tool; needs the GPU).  Prints one JSON line per (size, lanes).   python scripts/proto_baff.py [log2_n ...]"""
+(dev tool; needs the GPU and a library built with `KZG_WITH_PROTO=1 python -m zkp_subnet_amd.build`).  Prints one JSON line per (size, lanes).   python scripts/proto_baff.py [log2_n ...]"""
 import ctypes
 import json
 import os
@@ -9,9 +9,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import TAU, uniform_fr                              # noqa: E402
 from zkp_subnet_amd import HipEngine                           # noqa: E402
 
+_U32, _F = ctypes.c_uint32, ctypes.c_float
 for lg in [int(a) for a in sys.argv[1:]] or [20, 22]:
     n = 1 << lg
     eng = HipEngine(0)
+    eng._lib.kzg_proto_baff.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, _U32,
+                                        ctypes.POINTER(_F), ctypes.POINTER(_U32)]
     eng.gen_srs(TAU, 1, lg, 0)
     eng.upload_fr(0, uniform_fr(n, 0), False)
     for lanes in (65536, 131072, 262144):

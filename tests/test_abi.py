@@ -224,3 +224,22 @@ def test_wire_decoder_every_byte_in_every_position_both_paths():
         assert out.returncode == 0, out.stderr[-2000:]
         seen.add(out.stdout.strip().splitlines()[-1])
     assert "simd 0" in seen          # the scalar path was exercised; "simd 2" too wherever the CPU has AVX2
+
+
+def test_isa_counts_file_matches_current_source():
+    """bench.py's `mad_issue` figure quotes profiles/isa_counts.json (mads per mixed addition of k_msm_accumulate): the
+    committed file must be what scripts/count_mads.py derives from the CURRENT csrc/msm.hip (hipcc -save-temps, no GPU)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "count_mads.py"), "--check"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, "profiles/isa_counts.json is stale: rerun scripts/count_mads.py\n" + r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_shipped_library_carries_no_prototype_hooks(lib):
+    """The batched-affine prototype lives under scripts/proto/ and is linked only by KZG_WITH_PROTO=1 builds."""
+    assert not hasattr(lib, "kzg_proto_baff")
+    hdr = open(os.path.join(ROOT, "include", "kzg_mi355x.h")).read()
+    assert "kzg_proto" not in hdr and "baff" not in hdr

@@ -336,6 +336,29 @@ def test_msm_tickets_pipeline_matches_blocking_calls(hip):
     eng.close()
 
 
+def test_msm_ticket_cancel_frees_the_lane(hip):
+    """kzg_msm_cancel: a ticket whose result will never be collected (the collective between _begin and _finish raised)
+    must not park its lane forever -- afterwards exclusive calls (kzg_upload_fr) work again and results are unchanged."""
+    from zkp_subnet_amd import KzgError
+
+    eng = hip()
+    n = 1 << 12
+    eng.gen_srs(0xCA11CE1, 1, 12, 0)
+    sc = rand_scalars_bytes(n, 4242)
+    eng.upload_fr(0, sc, False)
+    want = eng.msm_resident(0, n)
+    tickets = [eng.msm_submit(0, n) for _ in range(4)]          # all four lanes parked
+    with pytest.raises(KzgError):
+        eng.upload_fr(1, sc, False)                             # E_BUSY: a ticket is outstanding
+    for t in tickets[:3]:
+        eng.msm_cancel(t)
+    assert eng.msm_wait(tickets[3]) == want
+    with pytest.raises(KzgError):
+        eng.msm_cancel(tickets[0])                              # already released
+    eng.upload_fr(1, sc, False)                                 # exclusive call goes through again
+    assert eng.msm_resident(1, n) == want == oc.msm(eng.srs_read(0, n), sc)
+
+
 def test_msm_2_24_large_size_trapdoor(hip):
     """2^24 points on one GPU (12 window tables = 26 GB resident; 2^26: test_cfg4_msm_2_26_in_eight_srs_segments):
     bit-exact against [f(tau)]G."""
@@ -658,6 +681,17 @@ def test_aggregate_commitments_and_api_commit_on_hip_engine(hip):
         assert base64.b64decode(r.json()["commitment"]) == b"\xc0" + bytes(47)
     bad_x = bytes([0x9F]) + b"\xff" * 47                  # x >= p
     assert miner.client.aggregate_commitments([base64.b64encode(bad_x).decode()]).status_code == 400
+    # ON the curve but OUTSIDE the prime-order subgroup (E(Fp) has a 2^126 cofactor): x = 5.  An untrusted miner could
+    # send it as a "commitment"; the GPU membership test ([z^2]P == -sigma(P)) refuses it, alone or among valid points
+    y5 = o.fp_sqrt((5 ** 3 + 4) % o.P)
+    rogue = base64.b64encode(o.g1_compress((5, y5))).decode()
+    assert o.is_on_curve((5, y5))
+    r = miner.client.aggregate_commitments([rogue])
+    assert r.status_code == 400 and "subgroup" in r.json()["error"]
+    assert miner.client.aggregate_commitments(comms + [rogue]).status_code == 400
+    inf = base64.b64encode(b"\xc0" + bytes(47)).decode()  # the identity IS a member
+    with miner.client.aggregate_commitments([comms[1], inf]) as r:
+        assert r.status_code == 200 and r.json()["commitment"] == comms[1]
     assert commit([o.fr_to_b64(1)] * T, [], index=0) == ""
     assert commit(["@@"], axons, index=0) == ""            # the miner's commit handler failed: request echoed, no string
     miner.stop()

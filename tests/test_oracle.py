@@ -174,3 +174,35 @@ def test_c_oracle_trapdoor_midsize(oracle_cpu):
     coeffs = [rnd.randrange(o.R) for _ in range(1 << 12)]
     got = oracle_cpu.commit(srs, o.fr_to_be32(coeffs), evaluation_form=False, threads=4)
     assert got == o.g1_compress(o.trapdoor_commit(tx, ty, 0, 0, coeffs))
+
+
+def test_endomorphism_subgroup_criterion_constants():
+    """The G1 membership test of csrc/msm.hip (k_g1_subgroup_check_lp): sigma(x, y) = (beta x, y) acts on G1 as -z^2,
+    and z^4 - z^2 + 1 = r is the degree of sigma + z^2, so [z^2]P == -sigma(P) holds exactly on G1.  Checks the
+    constants the kernel hard-codes, on the generator and on an on-curve point outside the subgroup."""
+    z = abs(o.BLS_X)
+    assert z == 0xD201000000010000 and z ** 4 - z ** 2 + 1 == o.R
+    beta = 0x5F19672FDF76CE51BA69C6076A0F77EADDB3A93BE6F89688DE17D813620A00022E01FFFFFFFEFFFE
+    assert beta != 1 and pow(beta, 3, o.P) == 1
+    src = open(__import__("os").path.join(__import__("os").path.dirname(__file__), "..", "zkp_subnet_amd", "csrc", "msm.hip")).read()
+    bm = beta * pow(2, 392, o.P) % o.P            # Montgomery residue, 14 limbs of 28 bits, as the kernel stores it
+    for i in range(14):
+        assert "0x%08xu" % ((bm >> (28 * i)) & 0xFFFFFFF) in src
+
+    def mul(pt, k):                               # no reduction of k mod r: the point may lie outside G1
+        acc, base = o.JAC_INF, o.to_jac(pt)
+        while k:
+            if k & 1:
+                acc = o.jac_add(acc, base)
+            base = o.jac_double(base)
+            k >>= 1
+        return o.to_affine(acc)
+
+    g = o.G1
+    q = o.g1_neg(mul(g, z * z))
+    assert (beta * g[0] % o.P, g[1]) == (q[0], q[1])
+    x = 5                                          # (5, sqrt(129)) is on the curve, order not dividing r
+    y = o.fp_sqrt((x ** 3 + 4) % o.P)
+    assert y is not None and o.is_on_curve((x, y)) and mul((x, y), o.R) is not None
+    q = o.g1_neg(mul((x, y), z * z))
+    assert (beta * x % o.P, y) != (q[0], q[1])

@@ -53,6 +53,7 @@ SYMBOLS = {
     "kzg_msm_partial_resident": (_I, [_P, _I, _U64, _U64, _B]),
     "kzg_msm_submit": (_I, [_P, _I, _U64, _U64, _I, ctypes.POINTER(_I)]),
     "kzg_msm_wait": (_I, [_P, _I, _B]),
+    "kzg_msm_cancel": (_I, [_P, _I]),
     "kzg_commit_open_resident": (_I, [_P, _U32, _I, _U64, _I, _B, _B, _B, _B]),
     "kzg_ntt_resident": (_I, [_P, _I, _U64, _I]),
     "kzg_staging_acquire": (_I, [_P, _U64, ctypes.POINTER(_P), ctypes.POINTER(_I)]),
@@ -65,7 +66,6 @@ SYMBOLS = {
     "kzg_set_profiling": (_I, [_P, _I]),
     "kzg_get_timings": (_I, [_P, ctypes.POINTER(ctypes.c_float), _I]),
     "kzg_msm_plan": (_I, [_P, _U64, ctypes.POINTER(ctypes.c_int32)]),
-    "kzg_proto_baff": (_I, [_P, _I, _U64, _U64, _U32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_U32)]),
     "kzg_b64_decode_fr": (_I, [_B, _U64, _B]),
     "kzg_b64_encode_fr": (_I, [_B, _U64, _B]),
     "kzg_test_field": (_I, [_P, _I, _I, _B, _B, _B, _U64]),

@@ -14,8 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libkzg_mi355x.so")
-SOURCES = ["msm.hip", "fr_kernels.hip", "api.hip", "baff_proto.hip", "pairing_host.cpp", "finish_host.cpp"]
-HEADERS = ["bigint.hip.h", "field.hip.h", "fp28.hip.h", "g1.hip.h", "msm.hip.h", "fr_kernels.hip.h", "fp_lp.hip.h", "fp_host.h",
+SOURCES = ["msm.hip", "fr_kernels.hip", "api.hip", "pairing_host.cpp", "finish_host.cpp"]
+# dev-only prototypes (scripts/proto/), linked only when KZG_WITH_PROTO=1: never part of the shipped library
+PROTO_SOURCES = ["../../scripts/proto/baff_proto.hip"]
+HEADERS = ["bigint.hip.h", "field.hip.h", "fp28.hip.h", "fr29.hip.h", "g1.hip.h", "msm.hip.h", "fr_kernels.hip.h", "fp_lp.hip.h", "fp_host.h",
            "../../include/kzg_mi355x.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 
@@ -58,9 +60,14 @@ def build(force: bool = False, extra_flags=()) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     jobs = []
-    for src in SOURCES:
+    sources = list(SOURCES)
+    if os.environ.get("KZG_WITH_PROTO") == "1":
+        sources += PROTO_SOURCES
+        extra_flags += ("-DKZG_WITH_PROTO",)
+        force = True
+    for src in sources:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        o = os.path.join(OBJ, os.path.splitext(os.path.basename(src))[0] + ".o")
         if force or _stale(o, [s] + hdrs):
             jobs.append([hipcc, *FLAGS, *extra_flags, "-c", s, "-o", o])
     if jobs:
@@ -68,7 +75,7 @@ def build(force: bool = False, extra_flags=()) -> str:
             for res in ex.map(lambda cmd: subprocess.run(cmd, capture_output=True, text=True), jobs):
                 if res.returncode != 0:
                     raise RuntimeError("hipcc failed:\n" + " ".join(res.args) + "\n" + res.stderr[-4000:])
-    objs = [os.path.join(OBJ, os.path.splitext(s)[0] + ".o") for s in SOURCES]
+    objs = [os.path.join(OBJ, os.path.splitext(os.path.basename(s))[0] + ".o") for s in sources]
     if force or jobs or _stale(LIB, objs):
         res = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs],
                              capture_output=True, text=True)

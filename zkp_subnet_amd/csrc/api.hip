@@ -12,6 +12,8 @@
 #include <atomic>
 #include <chrono>
 #include <string>
+#include <thread>
+#include <algorithm>
 #include <utility>
 #include <vector>
 
@@ -24,6 +26,7 @@
 #define N_SLOTS 4
 #define N_LANES 4
 #define N_STAGE 4
+#define KZG_MAX_GATHER 4096   // partials one kzg_msm_sharded_finish can sum (ranks of a job)
 
 namespace kzg_host {  // finish_host.cpp
 void xyzz_to_c48(const uint32_t* xyzz, uint8_t out48[48]);
@@ -102,6 +105,7 @@ struct Lane {
     hipStream_t stream = nullptr;
     DevBuf rank, sorted, hist, offsets, bufA, bufB, bufC, carries, carry_key;      // MSM workspace
     DevBuf ntt_mid;               // the vector between the passes of an NTT (9 words per element)
+    DevBuf gather;                // kzg_msm_sharded_finish: the gathered partials, unpacked (own buffer: the MSM may still run)
     DevBuf in_be, scal, coeffA, coeffB, qbuf, hbuf, hnext, out_be;                 // request buffers
     uint8_t* tail = nullptr;      // device, TB_SIZE
     uint8_t* pin = nullptr;       // host pinned, 4096
@@ -109,6 +113,7 @@ struct Lane {
     uint32_t pub_seq = 0;         // sequence number of the last record publish on this lane
     uint32_t sort_seq = 0;        // ... and of the last fold-depth publish
     bool expect_short = false;    // the request in flight is a short one (set by msm_core): finish() may poll for its record
+    uint32_t expect_us = 0;       // ... and roughly how long its GPU work takes (bounds the polling)
     bool flags_clean = false;     // the tail record's flag words are zero (left so by the last request's publish)
     bool sort_ws_clean = false;   // the sort's partition counts are zero (left so by every completed sort)
     int skew_hint = 0;            // > 0: the last fast sort overflowed (skewed scalars): go straight to the exact sort
@@ -316,7 +321,13 @@ void prof_end(kzg_ctx* ctx, Lane& L) {  // lane stream already synchronised
     float t[KZG_T_COUNT] = {0};
     for (auto& s : L.spans) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) t[s.stage] += ms;
+        hipError_t e = hipEventElapsedTime(&ms, s.a, s.b);
+        if (e == hipErrorNotReady) {   // the host saw the published record before the runtime retired the event
+            (void)hipGetLastError();
+            (void)hipEventSynchronize(s.b);
+            e = hipEventElapsedTime(&ms, s.a, s.b);
+        }
+        if (e == hipSuccess) t[s.stage] += ms;
     }
     L.spans.clear();
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -381,16 +392,26 @@ int ilog2_exact(uint64_t n) {
 // The only host wait inside is on the 4-byte fold-depth read-back; the calling thread holds no lock meanwhile.
 // waits until the pinned word at `off` shows `seq` (a k_publish has landed); false if it does not within the budget
 static bool poll_pinned(const kzg_ctx* ctx, const Lane& L, uint32_t off, uint32_t seq) {
+    // The budget is the request's own expected duration (set by msm_core from its entry count), not a fixed 200 ms: a
+    // request that overruns it is waited for in the runtime (which sleeps) instead of burning a host core.  After the
+    // first ~50 us the loop yields between probes, so four axon threads waiting at once do not pin four cores.
     const volatile uint32_t* w = reinterpret_cast<const volatile uint32_t*>(L.pin + off);
     const auto t0 = std::chrono::steady_clock::now();
+    const auto budget = std::chrono::microseconds(
+        std::min<uint64_t>((uint64_t)ctx->poll_timeout_ms * 1000, 2 * (uint64_t)L.expect_us + 500));
+    bool yielding = false;
     for (uint32_t spin = 0;; spin++) {
         if (*w == seq) {
             std::atomic_thread_fence(std::memory_order_acquire);
             return true;
         }
-        if ((spin & 0xfff) == 0xfff &&
-            std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(ctx->poll_timeout_ms)) return false;
-        __builtin_ia32_pause();
+        if ((spin & 0xff) == 0xff) {
+            const auto dt = std::chrono::steady_clock::now() - t0;
+            if (dt > budget) return false;
+            yielding = dt > std::chrono::microseconds(50);
+        }
+        if (yielding) std::this_thread::yield();
+        else __builtin_ia32_pause();
     }
 }
 int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t n, uint64_t srs_offset,
@@ -411,6 +432,7 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
     const uint32_t nchunks = (uint32_t)((entries + sh.chunk - 1) / sh.chunk);
     const size_t B = sh.nbuckets;
     L.expect_short = entries <= ((uint64_t)1 << 24);   // up to ~3 ms of GPU time (a 2^20-point MSM)
+    L.expect_us += 400 + (uint32_t)(entries / 4096);     // ~0.2 ns per sorted entry + the latency-bound tail
     // Sort mode.  Fast: no count pass, fixed-capacity partition regions -- right for well-spread scalars (field elements
     // of a polynomial), wrong for skewed ones, where a region overflows: that is detected on the device, costs one wasted
     // sort (the queued accumulate sees an empty MSM), and is remembered for the lane's next few calls.
@@ -449,7 +471,7 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
     // instead of sleeping on the event
     auto wait_sorted = [&]() -> hipError_t {
 #ifndef KZG_NO_POLL
-        if (!ctx->profiling && L.expect_short && poll_pinned(ctx, L, PIN_SEQ_SORT, L.sort_seq)) return hipSuccess;
+        if (ctx->profiling != 1 && L.expect_short && poll_pinned(ctx, L, PIN_SEQ_SORT, L.sort_seq)) return hipSuccess;
 #endif
         return hipEventSynchronize(L.ev_sorted);
     };
@@ -515,11 +537,12 @@ int clear_flags(kzg_ctx* ctx, Lane& L) {
     const bool was_clean = L.flags_clean;
     L.flags_clean = false;
     L.expect_short = false;
+    L.expect_us = 0;
     if (!was_clean) HIPCHK(ctx, hipMemsetAsync(L.flags(), 0, 16, L.stream));
     return KZG_OK;
 }
 // ends a request: the lane's tail record comes back in ONE copy (result points, eval, flags, GPU-side encodings)
-int finish(kzg_ctx* ctx, Lane& L) {
+int finish(kzg_ctx* ctx, Lane& L, bool allow_poll = true) {
     prof_close(ctx, L);
     const uint32_t seq = ++L.pub_seq;
     launch_publish(L.stream, L.tail, L.pin_dev, TB_COPY, L.flags(), reinterpret_cast<uint32_t*>(L.pin_dev + PIN_SEQ), seq);
@@ -530,7 +553,8 @@ int finish(kzg_ctx* ctx, Lane& L) {
 #ifndef KZG_NO_POLL
     // only for requests expected to take well under the polling budget (short rows: that is where a few us count); a long
     // MSM waits in the runtime, which may sleep
-    if (!ctx->profiling && L.expect_short) seen = poll_pinned(ctx, L, PIN_SEQ, seq);
+    // (level-2 profiling keeps polling: its two events per accumulate launch precede the publish in stream order)
+    if (allow_poll && ctx->profiling != 1 && L.expect_short) seen = poll_pinned(ctx, L, PIN_SEQ, seq);
 #endif
     if (!seen) HIPCHK(ctx, hipStreamSynchronize(L.stream));
     L.flags_clean = true;
@@ -914,6 +938,9 @@ int kzg_create(int device_id, kzg_ctx** out) {
              // coherent (fine-grained) and mapped: k_publish stores results straight into this page
              hipHostMalloc((void**)&L.pin, 4096, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
              hipHostGetDevicePointer((void**)&L.pin_dev, L.pin, 0) == hipSuccess &&
+             // the host trusts this page on the sole basis of its sequence words (PIN_SEQ / PIN_SEQ_SORT == the lane's
+             // counters, which start at 1): recycled host memory must not carry a stale equal word
+             (memset(L.pin, 0, 4096), true) &&
              hipEventCreateWithFlags(&L.ev_sorted, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&L.ev_coeffs, hipEventDisableTiming) == hipSuccess &&
@@ -933,7 +960,7 @@ void kzg_destroy(kzg_ctx* ctx) {
     for (Lane& L : ctx->lane) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         for (DevBuf* b : {&L.rank, &L.sorted, &L.hist, &L.offsets, &L.bufA, &L.bufB, &L.bufC, &L.carries, &L.carry_key,
-                          &L.in_be, &L.scal, &L.coeffA, &L.coeffB, &L.qbuf, &L.hbuf, &L.hnext, &L.out_be, &L.ntt_mid})
+                          &L.in_be, &L.scal, &L.coeffA, &L.coeffB, &L.qbuf, &L.hbuf, &L.hnext, &L.out_be, &L.ntt_mid, &L.gather})
             b->release();
         for (hipEvent_t e : L.ev_pool) (void)hipEventDestroy(e);
         for (hipEvent_t e : {L.ev_sorted, L.ev_done, L.ev_coeffs, L.ev_ext})
@@ -1145,6 +1172,8 @@ static int g1_sum_common(kzg_ctx* ctx, const uint8_t* in, uint32_t count, uint8_
         if (count) HIPCHK(ctx, hipMemcpyAsync(ctx->aux_in.p, in, (size_t)count * 48, hipMemcpyHostToDevice, s));
         g1_affine_t* aff = reinterpret_cast<g1_affine_t*>(pts + 1);
         launch_srs_from_c48(s, ctx->aux_in.as<uint8_t>(), aff, count, bad);
+        // these are UNTRUSTED points (miners' commitments): on the curve is not enough, E(Fp) has a 2^126 cofactor
+        launch_g1_subgroup_check(s, aff, count, bad);
         launch_g1_sum_affine(s, aff, count, pts);
     } else {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(in);
@@ -1165,8 +1194,9 @@ static int g1_sum_common(kzg_ctx* ctx, const uint8_t* in, uint32_t count, uint8_
     HIPCHK(ctx, hipMemcpyAsync(pin + 224, bad, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
     HIPCHK(ctx, hipGetLastError());
-    if (*reinterpret_cast<const uint32_t*>(pin + 224))
-        return fail(ctx, KZG_E_POINT, "compressed G1 input malformed, not reduced or not on the curve");
+    if (const uint32_t b = *reinterpret_cast<const uint32_t*>(pin + 224))
+        return fail(ctx, KZG_E_POINT, (b & 3u) ? "compressed G1 input malformed, not reduced or not on the curve"
+                                                : "G1 input on the curve but outside the prime-order subgroup");
     if (ctx->host_finish) kzg_host::xyzz_to_c48(reinterpret_cast<const uint32_t*>(pin), out48);
     else memcpy(out48, pin, 48);
     return KZG_OK;
@@ -1352,15 +1382,23 @@ int kzg_msm_sharded_begin(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offse
                           void* consumer_stream, int* out_ticket) {
     if (!ctx || !out_ticket || !dev_out_xyzz192 || slot < 0 || slot >= N_SLOTS) return KZG_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    int rc = need_srs(ctx);
-    if (rc) return rc;
-    if (n > ctx->slot_n[slot]) return fail(ctx, KZG_E_ARG, "slot holds fewer scalars than requested");
     int li = -1;
-    rc = lane_acquire(ctx, LANE_TICKET, &li);
+    int rc = lane_acquire(ctx, LANE_TICKET, &li);
     if (rc) return rc;
     Lane& L = ctx->lane[li];
+    // checked while the lane is held: an exclusive operation (SRS reload, kzg_upload_fr) cannot slip in between
+    rc = need_srs(ctx);
+    if (!rc && n > ctx->slot_n[slot]) rc = fail(ctx, KZG_E_ARG, "slot holds fewer scalars than requested");
+    if (rc) {
+        lane_release(ctx, li);
+        return rc;
+    }
     prof_begin(ctx, L);
     rc = clear_flags(ctx, L);
+    // the gathered partials get their own buffer, allocated BEFORE anything is queued: _finish must not (re)allocate
+    // while the lane's MSM may still be running (hipFree synchronises the whole device)
+    if (!rc && L.gather.ensure((size_t)(KZG_MAX_GATHER + 2) * sizeof(g1_xyzz_t)) != hipSuccess)
+        rc = fail(ctx, KZG_E_NOMEM, "gather buffer");
     if (!rc) rc = msm_core(ctx, L, ctx->slot[slot].as<uint32_t>(), ctx->slot_mont[slot], n, srs_offset, L.res());
     if (!rc) {
         launch_xyzz_pack(L.stream, L.res(), reinterpret_cast<uint32_t*>(dev_out_xyzz192), 1);
@@ -1381,7 +1419,7 @@ int kzg_msm_sharded_begin(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offse
 }
 int kzg_msm_sharded_finish(kzg_ctx* ctx, int ticket, const void* dev_partials_xyzz192, uint32_t count,
                            void* producer_stream, uint8_t out48[48]) {
-    if (!ctx || !out48 || !dev_partials_xyzz192 || !count || count > 4096 || ticket < 0 || ticket >= N_LANES) return KZG_E_ARG;
+    if (!ctx || !out48 || !dev_partials_xyzz192 || !count || count > KZG_MAX_GATHER || ticket < 0 || ticket >= N_LANES) return KZG_E_ARG;
     Lane& L = ctx->lane[ticket];
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
@@ -1390,15 +1428,15 @@ int kzg_msm_sharded_finish(kzg_ctx* ctx, int ticket, const void* dev_partials_xy
     }
     (void)hipSetDevice(ctx->device);
     int rc = KZG_OK;
-    hipError_t e = L.carries.ensure(((size_t)count + 2) * sizeof(g1_xyzz_t));
-    if (e == hipSuccess) e = hipEventRecord(L.ev_ext, reinterpret_cast<hipStream_t>(producer_stream));
+    hipError_t e = hipEventRecord(L.ev_ext, reinterpret_cast<hipStream_t>(producer_stream));
     if (e == hipSuccess) e = hipStreamWaitEvent(L.stream, L.ev_ext, 0);
     if (e == hipSuccess) {
-        g1_xyzz_t* pts = L.carries.as<g1_xyzz_t>();   // free again: the MSM's tail is behind us on this stream
+        g1_xyzz_t* pts = L.gather.as<g1_xyzz_t>();    // sized by _begin
         launch_xyzz_unpack(L.stream, reinterpret_cast<const uint32_t*>(dev_partials_xyzz192), pts, count);
         launch_g1_sum(L.stream, pts, count, L.res());
         queue_encode(ctx, L, true, false);
-        rc = finish(ctx, L);
+        // no polling: the lane waits on an external producer (the collective of ALL ranks), whose time is not ours to bound
+        rc = finish(ctx, L, false);
         if (!rc) result_c48(ctx, L, 0, out48);
     } else {
         rc = fail(ctx, KZG_E_HIP, std::string("kzg_msm_sharded_finish: ") + hipGetErrorString(e));
@@ -1418,13 +1456,17 @@ int kzg_msm_sharded_finish(kzg_ctx* ctx, int ticket, const void* dev_partials_xy
 int kzg_msm_submit(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, int partial, int* out_ticket) {
     if (!ctx || !out_ticket || slot < 0 || slot >= N_SLOTS) return KZG_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    int rc = need_srs(ctx);
-    if (rc) return rc;
-    if (n > ctx->slot_n[slot]) return fail(ctx, KZG_E_ARG, "slot holds fewer scalars than requested");
     int li = -1;
-    rc = lane_acquire(ctx, LANE_TICKET, &li);
+    int rc = lane_acquire(ctx, LANE_TICKET, &li);
     if (rc) return rc;
     Lane& L = ctx->lane[li];
+    // checked while the lane is held: an exclusive operation (SRS reload, kzg_upload_fr) cannot slip in between
+    rc = need_srs(ctx);
+    if (!rc && n > ctx->slot_n[slot]) rc = fail(ctx, KZG_E_ARG, "slot holds fewer scalars than requested");
+    if (rc) {
+        lane_release(ctx, li);
+        return rc;
+    }
     prof_begin(ctx, L);
     rc = clear_flags(ctx, L);
     if (!rc) rc = msm_core(ctx, L, ctx->slot[slot].as<uint32_t>(), ctx->slot_mont[slot], n, srs_offset, L.res());
@@ -1461,7 +1503,7 @@ int kzg_msm_wait(kzg_ctx* ctx, int ticket, uint8_t* out) {
     (void)hipSetDevice(ctx->device);
     hipError_t e = hipSuccess;  // not under the lock: other threads submit / run meanwhile
 #ifndef KZG_NO_POLL
-    if (ctx->profiling || !L.expect_short || !poll_pinned(ctx, L, PIN_SEQ, L.pub_seq))
+    if (ctx->profiling == 1 || !L.expect_short || !poll_pinned(ctx, L, PIN_SEQ, L.pub_seq))
 #endif
         e = hipEventSynchronize(L.ev_done);
     int rc = KZG_OK;
@@ -1476,6 +1518,26 @@ int kzg_msm_wait(kzg_ctx* ctx, int ticket, uint8_t* out) {
     }
     lane_release(ctx, ticket);
     return rc;
+}
+
+// gives up an outstanding ticket (kzg_msm_submit / kzg_msm_sharded_begin) whose result will never be collected -- e.g. the
+// collective between _begin and _finish raised: drains the lane and frees it
+int kzg_msm_cancel(kzg_ctx* ctx, int ticket) {
+    if (!ctx || ticket < 0 || ticket >= N_LANES) return KZG_E_ARG;
+    Lane& L = ctx->lane[ticket];
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (L.state != LANE_TICKET) return fail(ctx, KZG_E_ARG, "no outstanding MSM on this ticket (or it is already being waited for)");
+        L.state = LANE_WAITING;
+    }
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(L.stream);
+    (void)hipGetLastError();
+    L.spans.clear();
+    L.flags_clean = false;     // its publish may not have run: the next request clears the flag words itself
+    L.sort_ws_clean = false;
+    lane_release(ctx, ticket);
+    return KZG_OK;
 }
 
 int kzg_commit_open_resident(kzg_ctx* ctx, uint32_t i, int slot, uint64_t T, int evaluation_form,
@@ -1588,81 +1650,11 @@ int kzg_msm_plan(kzg_ctx* ctx, uint64_t n, int32_t out[4]) {
     out[3] = ctx->nwin;
     return KZG_OK;
 }
-// ---- PROTOTYPE measurement hook (csrc/baff_proto.hip; not part of the serving surface): sorts the digits of the slot's
-// scalars exactly as an MSM does, then times (HIP events) k_msm_accumulate and three batched-affine pairwise rounds on
-// the SAME sorted entries.  out_ms: [0] sort, [1] k_msm_accumulate, [2..4] batched-affine rounds 1..3;
-// out_counts: [0] entries, [1..3] pairs per round, [4..6] mismatches against the XYZZ formulas (sampled), [7] pairs
-// with equal x (skipped by the prototype).
-int kzg_proto_baff(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint32_t lanes, float out_ms[8],
-                   uint32_t out_counts[8]) {
-    if (!ctx || !out_ms || !out_counts || slot < 0 || slot >= N_SLOTS || !lanes) return KZG_E_ARG;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    LaneHold H(ctx);
-    if (int rc = H.take()) return rc;
-    Lane& L = H.L();
-    int rc = need_srs(ctx);
-    if (rc) return rc;
-    if (n > ctx->slot_n[slot] || srs_offset + n > ctx->stride) return fail(ctx, KZG_E_ARG, "range");
-    hipStream_t s = L.stream;
-    const uint64_t entries_max = n * (uint64_t)ctx->nwin;
-    MsmShape sh;
-    sh.c = ctx->c; sh.nwin = ctx->nwin; sh.lay = ctx->lay; sh.nbuckets = ctx->nbuckets; sh.n = n; sh.nbatch = 1;
-    sh.srs_offset = srs_offset; sh.srs_stride = ctx->stride; sh.chunk = pick_chunk(entries_max);
-    const uint32_t nchunks = (uint32_t)((entries_max + sh.chunk - 1) / sh.chunk);
-    const size_t B = sh.nbuckets;
-    HIPCHK(ctx, L.rank.ensure(entries_max * 8));
-    HIPCHK(ctx, L.sorted.ensure(entries_max * 4 + 64));
-    HIPCHK(ctx, L.hist.ensure(16384 * 4));
-    HIPCHK(ctx, L.offsets.ensure((B + 1) * 4));
-    HIPCHK(ctx, L.bufA.ensure(B * sizeof(g1_xyzz_t) + 16384));
-    HIPCHK(ctx, L.carries.ensure((size_t)nchunks * sizeof(g1_xyzz_t)));
-    HIPCHK(ctx, L.carry_key.ensure((size_t)nchunks * 4));
-    DevBuf prefix, o1, o2, o3, cnt;
-    HIPCHK(ctx, prefix.ensure((entries_max / 2 + 1) * 64));
-    HIPCHK(ctx, o1.ensure((entries_max / 2 + 1) * sizeof(g1_affine_t)));
-    HIPCHK(ctx, o2.ensure((entries_max / 4 + 1) * sizeof(g1_affine_t)));
-    HIPCHK(ctx, o3.ensure((entries_max / 8 + 1) * sizeof(g1_affine_t)));
-    HIPCHK(ctx, cnt.ensure(64));
-    HIPCHK(ctx, hipMemsetAsync(cnt.p, 0, 64, s));
-    hipEvent_t ev[8];
-    for (auto& e : ev) HIPCHK(ctx, hipEventCreate(&e));
-    HIPCHK(ctx, hipMemsetAsync(L.bufA.p, 0, B * sizeof(g1_xyzz_t), s));
-    HIPCHK(ctx, hipEventRecord(ev[0], s));
-    launch_msm_sort(s, sh, ctx->slot[slot].as<uint32_t>(), ctx->slot_mont[slot], nullptr, 0, L.hist.as<uint32_t>(), false,
-                    L.rank.as<uint2>(), L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(), L.flags() + 2, false, L.flags() + 3);
-    HIPCHK(ctx, hipEventRecord(ev[1], s));
-    uint32_t entries = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&entries, L.offsets.as<uint32_t>() + B, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(ctx, hipStreamSynchronize(s));
-    HIPCHK(ctx, hipEventRecord(ev[2], s));
-    launch_msm_accumulate(s, sh, ctx->table.as<g1_affine_t>(), L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(),
-                          L.bufA.as<g1_xyzz_t>(), L.carries.as<g1_xyzz_t>(), L.carry_key.as<uint32_t>(), nchunks);
-    HIPCHK(ctx, hipEventRecord(ev[3], s));
-    const uint32_t np1 = entries / 2, np2 = np1 / 2, np3 = np2 / 2;
-    uint32_t* c = cnt.as<uint32_t>();
-    launch_baff_round(s, ctx->table.as<g1_affine_t>(), L.sorted.as<uint32_t>(), np1, lanes, prefix.p, o1.as<g1_affine_t>(), c + 7);
-    HIPCHK(ctx, hipEventRecord(ev[4], s));
-    launch_baff_round(s, o1.as<g1_affine_t>(), nullptr, np2, lanes, prefix.p, o2.as<g1_affine_t>(), c + 7);
-    HIPCHK(ctx, hipEventRecord(ev[5], s));
-    launch_baff_round(s, o2.as<g1_affine_t>(), nullptr, np3, lanes, prefix.p, o3.as<g1_affine_t>(), c + 7);
-    HIPCHK(ctx, hipEventRecord(ev[6], s));
-    launch_baff_check(s, ctx->table.as<g1_affine_t>(), L.sorted.as<uint32_t>(), np1, 997, o1.as<g1_affine_t>(), c + 4);
-    launch_baff_check(s, o1.as<g1_affine_t>(), nullptr, np2, 499, o2.as<g1_affine_t>(), c + 5);
-    launch_baff_check(s, o2.as<g1_affine_t>(), nullptr, np3, 251, o3.as<g1_affine_t>(), c + 6);
-    HIPCHK(ctx, hipMemcpyAsync(out_counts, c, 32, hipMemcpyDeviceToHost, s));
-    HIPCHK(ctx, hipStreamSynchronize(s));
-    HIPCHK(ctx, hipGetLastError());
-    for (int i = 0; i < 8; i++) out_ms[i] = 0.f;
-    (void)hipEventElapsedTime(&out_ms[0], ev[0], ev[1]);
-    (void)hipEventElapsedTime(&out_ms[1], ev[2], ev[3]);
-    (void)hipEventElapsedTime(&out_ms[2], ev[3], ev[4]);
-    (void)hipEventElapsedTime(&out_ms[3], ev[4], ev[5]);
-    (void)hipEventElapsedTime(&out_ms[4], ev[5], ev[6]);
-    for (auto& e : ev) (void)hipEventDestroy(e);
-    out_counts[0] = entries; out_counts[1] = np1; out_counts[2] = np2; out_counts[3] = np3;
-    H.clean = true;
-    return KZG_OK;
-}
+// dev-only prototype hooks (scripts/proto/): compiled in only by `KZG_WITH_PROTO=1 python -m zkp_subnet_amd.build`;
+// the shipped library and include/kzg_mi355x.h do not carry them
+#ifdef KZG_WITH_PROTO
+#include "../../scripts/proto/baff_hook.inc"
+#endif
 
 // test hooks for the host-side encoder (finish_host.cpp): no GPU involved
 int kzg_host_xyzz_to_c48(const uint32_t xyzz_limbs28[56], uint8_t out48[48]) {

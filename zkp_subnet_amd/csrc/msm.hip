@@ -1071,6 +1071,69 @@ __global__ void __launch_bounds__(64) k_g1_sum_affine(const g1_affine_t* __restr
     if (tid == 0) store_xyzz(out, acc);
 }
 
+// ---- G1 membership of untrusted points (the miners' commitments entering the master aggregation): on the curve is not
+// enough -- E(Fp) has cofactor h = (z-1)^2/3 ~ 2^126.  With sigma(x, y) = (beta x, y), beta a primitive cube root of unity,
+// the endomorphism sigma + z^2 (z = |BLS parameter| = 0xd201000000010000) has degree N(sigma + z^2) = z^4 - z^2 + 1 = r,
+// is separable, and kills G1 (sigma acts there as -z^2 mod r): its kernel IS G1.  So P is in G1 exactly when
+// [z^2] P == -sigma(P), two multiplications by the 64-bit, weight-6 z: 126 doublings + 10 additions instead of the
+// 255 + ~127 of [r]P.  One wave per point (lane-parallel point operations, ~1.5 us each): ~0.2 ms for any count up to
+// the number of SIMDs.  beta below satisfies sigma(G) = -[z^2]G for the generator (checked in tests/test_oracle.py).
+FP28_TABLE(g1_beta_mont, 0x0a75929au, 0x0681b798u, 0x022a3e9du, 0x0abc02bfu, 0x04e5bb45u, 0x055e6e7eu, 0x04814117u,
+           0x06d04f1bu, 0x0ae3387du, 0x054acb0cu, 0x00a4c74bu, 0x056138b5u, 0x0b64e066u, 0x000076f2u)
+#define BLS_Z 0xd201000000010000ull
+__global__ void __launch_bounds__(64) k_g1_subgroup_check_lp(const g1_affine_t* __restrict__ in, uint32_t count,
+                                                              uint32_t* __restrict__ bad) {
+    tail_priority();
+    __shared__ LpScratch sm;
+    __shared__ g1_xyzz_t base, acc;
+    const LpLane k = lp_lane();
+    const uint32_t j = blockIdx.x;
+    if (j >= count) return;
+    if (threadIdx.x == 0) {
+        g1_aff28 a;
+        g1_load_aff(a, &in[j]);
+        g1_xyzz_t t;
+        g1_from_aff(t, a);
+        store_xyzz(&base, t);
+        store_xyzz(&acc, t);
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 2; pass++) {           // acc <- [z] base, most significant bit first; then base <- acc
+        for (int b = 62; b >= 0; b--) {
+            lp_dbl(sm, &acc, &acc, k);
+            __syncthreads();
+            if ((BLS_Z >> b) & 1ull) {
+                lp_add(sm, &acc, &acc, &base, k);
+                __syncthreads();
+            }
+        }
+        if (threadIdx.x < 56) reinterpret_cast<uint32_t*>(&base)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&acc)[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    g1_aff28 a;
+    g1_load_aff(a, &in[j]);
+    if (g1_aff_is_inf(a)) return;                    // the identity is a member
+    g1_xyzz_t q;
+    load_xyzz(q, &acc);
+    if (g1_is_inf(q)) { atomicOr(bad, 4u); return; } // order divides z^2: not in G1
+    // [z^2]P = (X/ZZ, Y/ZZZ) == (beta x, -y)  <=>  beta x ZZ - X == 0  and  y ZZZ + Y == 0
+    fp_t beta, one, t, d, chk;
+#pragma unroll
+    for (int i = 0; i < 14; i++) beta.l[i] = g1_beta_mont(i);
+    fp_one(one);
+    fp_mul(t, beta, a.x);
+    fp_mul(t, t, q.zz);
+    fp_sub16(d, t, q.x);                             // X: normalised, < 14p
+    fp_mul(chk, d, one);
+    bool ok = fp_is_zero_n(chk);
+    fp_mul(t, a.y, q.zzz);
+    fp_add(d, t, q.y);                               // Y: normalised, < 6p
+    fp_mul(chk, d, one);
+    ok &= fp_is_zero_n(chk);
+    if (!ok) atomicOr(bad, 4u);
+}
+
 __global__ void __launch_bounds__(64) k_g1_compress(const g1_xyzz_t* __restrict__ in, uint8_t* __restrict__ out48) {
     tail_priority();
     if (threadIdx.x != 0) return;
@@ -1605,6 +1668,9 @@ void launch_g1_sum(hipStream_t s, const g1_xyzz_t* in, uint32_t count, g1_xyzz_t
 }
 void launch_g1_sum_affine(hipStream_t s, const g1_affine_t* in, uint32_t count, g1_xyzz_t* out_xyzz) {
     k_g1_sum_affine<<<1, 64, 0, s>>>(in, count, out_xyzz);
+}
+void launch_g1_subgroup_check(hipStream_t s, const g1_affine_t* in, uint32_t count, uint32_t* bad_flag) {
+    if (count) k_g1_subgroup_check_lp<<<count, 64, 0, s>>>(in, count, bad_flag);
 }
 void launch_g1_compress(hipStream_t s, const g1_xyzz_t* in, uint8_t* out48) {
     k_g1_compress<<<1, 64, 0, s>>>(in, out48);

@@ -79,6 +79,8 @@ void launch_msm_final(hipStream_t s, const g1_xyzz_t* node, const g1_xyzz_t* pre
 void launch_g1_sum(hipStream_t s, const g1_xyzz_t* in, uint32_t count, g1_xyzz_t* out_xyzz);
 // sum `count` affine table-format points into out_xyzz[0]
 void launch_g1_sum_affine(hipStream_t s, const g1_affine_t* in, uint32_t count, g1_xyzz_t* out_xyzz);
+// G1 membership (prime-order subgroup) of `count` affine table-format points, one wave each: *bad_flag |= 4 on a failure
+void launch_g1_subgroup_check(hipStream_t s, const g1_affine_t* in, uint32_t count, uint32_t* bad_flag);
 // affine + ZCash compression of one point
 void launch_g1_compress(hipStream_t s, const g1_xyzz_t* in, uint8_t* out48);
 // two points, one shared inversion
@@ -99,9 +101,3 @@ void launch_srs_precompute(hipStream_t s, g1_affine_t* table, uint64_t stride, u
 // (global index j_base + j); gtab: 32*255 affine scratch (built when build_gtab); tmp: count XYZZ + count*32 B
 void launch_srs_generate(hipStream_t s, g1_affine_t* out, uint64_t count, uint64_t j_base, const uint32_t* tau_mont,
                          const uint32_t* s0_mont, g1_affine_t* gtab, g1_xyzz_t* tmp, bool build_gtab);
-
-// PROTOTYPE (csrc/baff_proto.hip): batched-affine pairwise addition rounds, measured against k_msm_accumulate
-void launch_baff_round(hipStream_t s, const g1_affine_t* table, const uint32_t* idx, uint32_t npairs, uint32_t lanes,
-                       void* prefix, g1_affine_t* out, uint32_t* n_equal_x);
-void launch_baff_check(hipStream_t s, const g1_affine_t* table, const uint32_t* idx, uint32_t npairs, uint32_t stride,
-                       const g1_affine_t* out, uint32_t* bad);

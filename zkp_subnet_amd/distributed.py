@@ -59,7 +59,13 @@ class DeviceGather:
         and the lane again hand over through events; the host blocks once, for the result."""
         stream = self.torch.cuda.current_stream().cuda_stream
         ticket = self.engine.msm_sharded_begin(slot, n, srs_offset, self.src.data_ptr(), stream)
-        self.dist.all_gather_into_tensor(self.out, self.src, group=self.group)
+        try:
+            self.dist.all_gather_into_tensor(self.out, self.src, group=self.group)
+        except BaseException:
+            # the collective raised (RCCL timeout, peer death): nobody will call _finish -- free the lane, or it stays
+            # parked under the ticket and every exclusive call returns E_BUSY from then on
+            self.engine.msm_cancel(ticket)
+            raise
         return self.engine.msm_sharded_finish(ticket, self.out.data_ptr(), self.world, stream)
 
     def msm_blocking(self, slot: int, n: int, srs_offset: int = 0) -> bytes:

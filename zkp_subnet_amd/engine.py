@@ -261,6 +261,10 @@ class HipEngine:
         self._chk(self._lib.kzg_msm_wait(self._h, ticket[0], out))
         return out.raw
 
+    def msm_cancel(self, ticket) -> None:
+        """Give up an outstanding ticket (msm_submit / msm_sharded_begin): drains its lane and frees it."""
+        self._chk(self._lib.kzg_msm_cancel(self._h, ticket[0] if isinstance(ticket, tuple) else ticket))
+
     def msm_partial_resident_dev(self, slot: int, n: int, srs_offset: int, dev_ptr: int) -> None:
         """The 192-byte partial goes to device address `dev_ptr` (e.g. `tensor.data_ptr()`); complete on return."""
         self._chk(self._lib.kzg_msm_partial_resident_dev(self._h, slot, n, srs_offset, ctypes.c_void_p(dev_ptr)))
