@@ -61,6 +61,15 @@ int kzg_load_srs(kzg_ctx* ctx, const uint8_t* g1_affine_be96, uint64_t n_points,
  * The y coordinates are recovered on the GPU (one Fp square root per point); a non-residue, x >= p or malformed flags
  * fail the load with KZG_E_POINT. */
 int kzg_load_srs_compressed(kzg_ctx* ctx, const uint8_t* g1_c48, uint64_t n_points, int scale, int machines_scale);
+/* The reference's own start path: Client(setup_path=...).start(scale, machines_scale) gives the prover a FILE
+ * (base/miner.py:75-84; Makefile:63-74 starts mainnet from setup_24_8.uncompressed: 2^24 points, 1.6 GB).  The file
+ * (96-byte records, or 48-byte compressed ones with compressed=1) is memory-mapped and streamed through two pinned
+ * tiles: host copy, upload and GPU decode overlap.  All three loaders build the new tables aside and swap them in only
+ * when the whole load has succeeded: after a failure (bad point, I/O, memory) the previously loaded SRS keeps serving. */
+int kzg_load_srs_file(kzg_ctx* ctx, const char* path, int compressed, int scale, int machines_scale);
+/* seconds spent by the last successful load: [0] host copies into the pinned tiles, [1] host waiting for upload + decode
+ * (decompression), [2] window-table build, [3] whole call */
+int kzg_get_load_stats(kzg_ctx* ctx, double out_s[4]);
 
 /* synthetic SRS with known discrete logs (tests / benches; stands in for `fourier setup --generate-setup`,
  * reference tests/conftest.py:50-65): slice k, point j = [s0_k * tau^j] G.  s0_be32: n_slices x 32 bytes. */

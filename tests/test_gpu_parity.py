@@ -697,15 +697,26 @@ def test_aggregate_commitments_and_api_commit_on_hip_engine(hip):
     miner.stop()
 
 
-def test_mainnet_configuration_scale_24_machines_scale_8(hip):
-    """The reference's mainnet prover flags (Makefile:63-74: --scale 24 --machines_scale 8): the whole 2^24-point SRS
-    resident as 256 worker slices of T = 2^16 (16 window tables: 34 GB), commit+open of full-length rows for several
-    worker indices, each bit-exact against the trapdoor identities with L_i(tau_y) of ITS slice."""
-    scale, ms = 24, 8
+def test_mainnet_configuration_scale_24_machines_scale_8(hip, tmp_path):
+    """The reference's MAINNET prover start (Makefile:63-74: --scale 24 --machines_scale 8 from setup_24_8.uncompressed,
+    2^24 points = 1.6 GB) through the production path: the setup file is written once, then `Client(setup_path).start(24,
+    8)` maps and streams it (64 pinned tiles), builds the 16 window tables (34 GB); commit+open of full-length rows for
+    several worker indices, each bit-exact against the trapdoor identities with L_i(tau_y) of ITS slice, verified with
+    the .vk.  The start-up time is printed (and kept in profiles/ by scripts/start_time.py)."""
+    import time
+
+    from zkp_subnet_amd.client import Client, derive_taus
+
+    scale, ms, seed = 24, 8, 2424
     T = 1 << (scale - ms)
-    eng = hip()
-    tx, ty = 0x24242424DEADBEEF2424, 0x80808080CAFE
-    eng.gen_srs(tx, ty, scale, ms)
+    path = _write_setup(tmp_path, "setup_24_8.uncompressed", scale, ms, seed)
+    tx, ty = derive_taus(seed)
+    cl = Client(setup_path=path)
+    t0 = time.perf_counter()
+    cl.start(scale, ms)
+    start_s = time.perf_counter() - t0
+    eng = cl.engine
+    print("mainnet start from file: %.2f s" % start_s, eng.load_stats())
     assert eng.srs_points == 1 << 24 and eng.window == 16
     alpha_b = rand_scalars_bytes(1, 2408)
     alpha = int.from_bytes(alpha_b, "big")
@@ -722,11 +733,13 @@ def test_mainnet_configuration_scale_24_machines_scale_8(hip):
         qt = (ft - int.from_bytes(y, "big")) * o.fr_inv(tx - alpha) % o.R
         assert pf == oc.g1_mul_gen((li * qt % o.R).to_bytes(32, "big")), i
         assert eng.verify(i, pf, alpha_b, ev, c)
+        assert not eng.verify((i + 7) % 256, pf, alpha_b, ev, c)
     # spot-check resident points of the last slice against the oracle's fixed-base multiplication
     for j in (0, T - 1):
         want = o.g1_table().mul(pow(tx, j, o.R) * o.lagrange_at(255, 1 << ms, ty) % o.R)
         assert eng.srs_read(255 * T + j, 1) == o.g1_to_be96(want)
-    eng.close()
+    cl.stop()
+    os.remove(path)
 
 
 def test_client_and_miner_on_hip_engine(hip, fr_kat):
@@ -905,6 +918,120 @@ def test_setup_cli_file_roundtrip_through_client(hip, tmp_path, fr_kat):
     from_c.stop()
     from_file.stop()
     in_memory.stop()
+
+
+def _write_setup(tmp_path, name, scale, ms, seed, compressed=False):
+    from zkp_subnet_amd import setup_cli
+
+    path = str(tmp_path / name)
+    args = ["setup", "--setup-path", path, "--scale", str(scale), "--machines-scale", str(ms), "--generate-setup",
+            "--overwrite", "--seed", str(seed)] + (["--compressed"] if compressed else [])
+    assert setup_cli.main(args) == 0
+    assert os.path.getsize(path) == (48 if compressed else 96) << scale
+    assert os.path.getsize(path + ".vk") == 192 + 96 * (1 << ms)
+    return path
+
+
+def test_production_start_testnet_20_8_from_setup_files(hip, tmp_path):
+    """The reference's TESTNET start path (Makefile:89-101: --scale 20 --machines_scale 8) as the reference runs it:
+    `Client(setup_path=...).start(20, 8)` from a setup FILE (base/miner.py:75-84) -- not gen_srs -- uncompressed and with
+    uncompressed=False, with its .vk; commit / open / fused commit+open for workers 0, 137, 255 == the C oracle on that
+    worker's slice; worker_verify true, false for another worker."""
+    from zkp_subnet_amd.client import Client, derive_taus
+
+    scale, ms, seed = 20, 8, 2008
+    T = 1 << (scale - ms)
+    tx, ty = derive_taus(seed)
+    txb, tyb = tx.to_bytes(32, "big"), ty.to_bytes(32, "big")
+    paths = [(_write_setup(tmp_path, "setup_20_8.uncompressed", scale, ms, seed), True),
+             (_write_setup(tmp_path, "setup_20_8.compressed", scale, ms, seed, compressed=True), False)]
+    rnd = random.Random(208)
+    alpha = rnd.randrange(o.R)
+    alpha_s, alpha_b = o.fr_to_b64(alpha), alpha.to_bytes(32, "big")
+    seen = {}
+    for path, unc in paths:
+        cl = Client(setup_path=path, uncompressed=unc)
+        cl.start(scale, ms)
+        assert cl.engine.srs_points == 1 << scale and cl.engine.window == 12
+        st = cl.engine.load_stats()
+        assert st["total_s"] > 0 and st["tables_s"] > 0
+        for i in (0, 137, 255):
+            row = [random.Random(1000 + i).randrange(o.R) for _ in range(T)]
+            poly, row_b = [o.fr_to_b64(v) for v in row], o.fr_to_be32(row)
+            srs = oc.srs_gen(txb, tyb, scale, ms, i)
+            assert cl.engine.srs_read(i * T, T) == srs
+            want_c = oc.commit(srs, row_b, True)
+            want_e, want_p = oc.open_(srs, row_b, alpha_b, True)
+            with cl.worker_commit(i, poly) as r:
+                assert r.status_code == 200 and base64.b64decode(r.json()["commitment"]) == want_c
+            with cl.worker_open(i, poly, alpha_s) as r:
+                assert o.fr_from_b64(r.json()["eval"]) == int.from_bytes(want_e, "big")
+                assert base64.b64decode(r.json()["proof"]) == want_p
+            with cl.worker_commit_and_open(i, poly, alpha_s) as r:
+                body = r.json()
+                assert base64.b64decode(body["commitment"]) == want_c and base64.b64decode(body["proof"]) == want_p
+            with cl.worker_verify(i, body["proof"], alpha_s, body["eval"], body["commitment"]) as r:
+                assert r.json()["valid"] is True
+            with cl.worker_verify((i + 1) % 256, body["proof"], alpha_s, body["eval"], body["commitment"]) as r:
+                assert r.json()["valid"] is False
+            assert seen.setdefault(i, body) == body          # compressed and uncompressed files: identical answers
+        cl.stop()
+
+
+def test_multi_tile_setup_file_2_22_boundaries_and_rollback(hip, tmp_path):
+    """A 2^22-point setup file is streamed through 16 pinned tiles of 2^18 points: the resident table equals a gen_srs
+    engine's at every tile boundary (window 0 and the highest window), for the uncompressed AND the compressed file; ONE
+    bad point in tile 3 fails the reload with KZG_E_POINT and the previously loaded SRS keeps serving (tables are built
+    aside and swapped in only on success)."""
+    from zkp_subnet_amd._native import KzgError, KZG_E_POINT
+    from zkp_subnet_amd.client import derive_taus
+
+    scale, ms, seed = 22, 8, 2208
+    T, tile = 1 << (scale - ms), 1 << 18
+    tx, ty = derive_taus(seed)
+    path = _write_setup(tmp_path, "setup_22_8.uncompressed", scale, ms, seed)
+    cpath = _write_setup(tmp_path, "setup_22_8.compressed", scale, ms, seed, compressed=True)
+    ref = hip()
+    ref.gen_srs(tx, ty, scale, ms)
+    wtop = len(ref.window_offsets) - 2
+    probes = sorted({max(0, k * tile + d) for k in range(17) for d in (-2, -1, 0, 1)} & set(range(1 << scale)))
+    want = {(w, j): ref.srs_read(j, 1, window=w) for w in (0, wtop) for j in probes}
+    eng = hip()
+    for pth, comp in ((path, False), (cpath, True)):
+        eng.load_srs_file(pth, scale, ms, compressed=comp)
+        assert eng.srs_points == 1 << scale
+        for (w, j), v in want.items():
+            assert eng.srs_read(j, 1, window=w) == v, (comp, w, j)
+    row = rand_scalars_bytes(T, 2209)
+    alpha_b = rand_scalars_bytes(1, 2210)
+    before = eng.commit_open(200, row, alpha_b, True)
+    assert before == ref.commit_open(200, row, alpha_b, True)
+    # one bad point in tile 3: y off the curve (uncompressed) / an x with no point above it (compressed)
+    bad_at = 3 * tile + 5
+    with open(path, "r+b") as f:
+        f.seek(96 * bad_at + 95)
+        last = f.read(1)
+        f.seek(96 * bad_at + 95)
+        f.write(bytes([last[0] ^ 1]))
+    x = 1
+    while o.fp_sqrt((x ** 3 + 4) % o.P) is not None:
+        x += 1
+    no_point = bytearray(x.to_bytes(48, "big"))
+    no_point[0] |= 0x80
+    with open(cpath, "r+b") as f:
+        f.seek(48 * bad_at)
+        f.write(bytes(no_point))
+    for pth, comp in ((path, False), (cpath, True)):
+        with pytest.raises(KzgError) as ei:
+            eng.load_srs_file(pth, scale, ms, compressed=comp)
+        assert ei.value.code == KZG_E_POINT
+        assert eng.srs_points == 1 << scale                      # rollback: the previous table still serves
+        assert eng.commit_open(200, row, alpha_b, True) == before
+    with pytest.raises(KzgError):
+        eng.load_srs_file(str(tmp_path / "absent"), scale, ms)
+    assert eng.commit_open(200, row, alpha_b, True) == before
+    ref.close()
+    eng.close()
 
 
 def test_bench_contract_line(hip):

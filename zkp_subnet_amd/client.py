@@ -97,13 +97,16 @@ class Client:
 
             self.engine = HipEngine(self.device)
         if self.setup_path and os.path.exists(self.setup_path):
-            with open(self.setup_path, "rb") as f:
-                data = f.read()
             rec = 96 if self.uncompressed else 48      # the reference's `uncompressed` flag (base/miner.py:77)
-            if len(data) % rec:
+            if os.path.getsize(self.setup_path) % rec:
                 raise ValueError(f"setup file must be a whole number of {rec}-byte G1 points "
                                  f"(uncompressed={self.uncompressed})")
-            self.engine.load_srs(data, scale, machines_scale, compressed=not self.uncompressed)
+            load_file = getattr(self.engine, "load_srs_file", None)
+            if load_file is not None:                  # HipEngine: the library maps the file and streams it itself
+                load_file(self.setup_path, scale, machines_scale, compressed=not self.uncompressed)
+            else:                                      # an injected engine without a file loader (tests)
+                with open(self.setup_path, "rb") as f:
+                    self.engine.load_srs(f.read(), scale, machines_scale, compressed=not self.uncompressed)
             self._slice_of = None
             vk_path = self.setup_path + ".vk"   # 192 B [tau_x]_2 (uncompressed) + one 96 B [L_i(tau_y)]_1 per slice
             if os.path.exists(vk_path) and hasattr(self.engine, "set_verifier_key"):

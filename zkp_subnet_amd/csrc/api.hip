@@ -4,6 +4,12 @@
 // No CPU arithmetic fallback exists here: if HIP fails, the call fails.
 #include <hip/hip_runtime.h>
 
+#include <errno.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -161,6 +167,7 @@ struct kzg_ctx {
     int profiling = 0;   // 0 off, 1 every stage (calls serialise on lane 0), 2 the accumulate kernel only (no serialisation)
     bool host_finish = true;
     float tms[KZG_T_COUNT] = {0};  // stage times of the last completed hot-path call
+    double load_stats[4] = {0, 0, 0, 0};   // kzg_get_load_stats
 };
 
 namespace {
@@ -349,17 +356,26 @@ int choose_window(uint64_t T) {
     return 24;   // 2^26: 11 windows, 2^23 buckets -- 132.2 -> 128.4 ms (the tree grows 1.2 -> 4.4 ms, the accumulate drops 8 %)
 }
 // nwin = ceil(256/c) windows of width base or base+1 (256 = nwin*base + extra): the widest is <= c bits
-void set_window(kzg_ctx* ctx, int c) {
+// Everything that describes one resident table.  A (re)load builds table + spec ASIDE and installs both only when the
+// whole load has succeeded: a failed reload leaves the previous SRS serving.
+struct TableSpec {
+    int c = 0, nwin = 0;
+    WinLayout lay;
+    uint32_t nbuckets = 0;
+    uint64_t stride = 0, T = 0;
+    int scale = 0, mscale = 0;
+};
+void spec_window(TableSpec& sp, int c) {
     const int nwin = (256 + c - 1) / c, base = 256 / nwin, extra = 256 % nwin;
-    ctx->nwin = ctx->lay.nwin = nwin;
+    sp.nwin = sp.lay.nwin = nwin;
     int off = 0;
     for (int w = 0; w < nwin; w++) {
-        ctx->lay.off[w] = (uint16_t)off;
+        sp.lay.off[w] = (uint16_t)off;
         off += base + (w < extra ? 1 : 0);
     }
-    ctx->lay.off[nwin] = 256;
-    ctx->c = base + (extra ? 1 : 0);
-    ctx->nbuckets = 1u << (ctx->c - 1);
+    sp.lay.off[nwin] = 256;
+    sp.c = base + (extra ? 1 : 0);
+    sp.nbuckets = 1u << (sp.c - 1);
 }
 // sorted entries per accumulate lane.  Large MSMs (throughput-bound): the grid is a whole number of "rounds" of 131072
 // lanes (2 waves per SIMD on 256 CUs: the second wave hides the point loads) so that the last round is not a partially
@@ -721,40 +737,64 @@ int commit_open_dev(kzg_ctx* ctx, LaneHold& H, uint32_t i, const uint32_t* row_d
     return KZG_OK;
 }
 
-// a failed (re)load must not leave a half-built table behind: need_srs() would pass and MSMs would return garbage
-struct TableRollback {
-    kzg_ctx* ctx;
-    bool armed = false;
-    ~TableRollback() {
-        if (!armed) return;
-        (void)hipStreamSynchronize(ctx->lane[0].stream);
-        ctx->table.release();
-        ctx->stride = 0;
-        ctx->T = 0;
-    }
-};
-int alloc_table(kzg_ctx* ctx, uint64_t n_points, int scale, int mscale) {
+// A (re)load never touches the serving table until it has succeeded: the new table is built in its own allocation and
+// swapped in at the end (288 GB of HBM hold both: mainnet's 34 GB twice is nothing).  Only when the second allocation does
+// not fit is the old table given up first -- then, and only then, a failure leaves the context without an SRS.
+int plan_table(kzg_ctx* ctx, uint64_t n_points, int scale, int mscale, TableSpec& sp) {
     if (mscale < 0 || scale < mscale || scale - mscale > 30) return fail(ctx, KZG_E_ARG, "bad scale / machines_scale");
     const uint64_t T = (uint64_t)1 << (scale - mscale);
     if (n_points == 0 || n_points % T) return fail(ctx, KZG_E_ARG, "SRS length must be a whole number of worker slices");
-    set_window(ctx, ctx->c_user ? ctx->c_user : choose_window(T));
-    if ((uint64_t)ctx->nwin * n_points >= ((uint64_t)1 << 31))
+    spec_window(sp, ctx->c_user ? ctx->c_user : choose_window(T));
+    if ((uint64_t)sp.nwin * n_points >= ((uint64_t)1 << 31))
         return fail(ctx, KZG_E_ARG, "SRS x windows exceeds 2^31 table entries");
+    sp.stride = n_points; sp.T = T; sp.scale = scale; sp.mscale = mscale;
+    return KZG_OK;
+}
+void drop_table(kzg_ctx* ctx) {
     ctx->table.release();
     ctx->stride = 0;
     ctx->T = 0;
-    HIPCHK(ctx, ctx->table.ensure((size_t)ctx->nwin * n_points * sizeof(g1_affine_t)));
-    ctx->stride = n_points; ctx->T = T; ctx->scale = scale; ctx->mscale = mscale;
+}
+int alloc_new_table(kzg_ctx* ctx, const TableSpec& sp, DevBuf& nt) {
+    const size_t bytes = (size_t)sp.nwin * sp.stride * sizeof(g1_affine_t);
+    hipError_t e = hipMalloc(&nt.p, bytes);
+    if (e != hipSuccess && ctx->table.p) {      // both do not fit: give the old one up first
+        (void)hipGetLastError();
+        drop_table(ctx);
+        e = hipMalloc(&nt.p, bytes);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        nt.p = nullptr;
+        return fail(ctx, KZG_E_NOMEM, std::string("hipMalloc(window tables): ") + hipGetErrorString(e));
+    }
+    nt.cap = bytes;
     return KZG_OK;
 }
-int precompute_tables(kzg_ctx* ctx) {
+void install_table(kzg_ctx* ctx, const TableSpec& sp, DevBuf& nt) {
+    ctx->table = std::move(nt);   // frees the previous table
+    ctx->c = sp.c; ctx->nwin = sp.nwin; ctx->lay = sp.lay; ctx->nbuckets = sp.nbuckets;
+    ctx->stride = sp.stride; ctx->T = sp.T; ctx->scale = sp.scale; ctx->mscale = sp.mscale;
+}
+// drains a stream at scope exit unless disarmed: the new table (declared before it) must not be freed under queued kernels
+struct DrainGuard {
+    hipStream_t s;
+    bool armed = true;
+    ~DrainGuard() {
+        if (armed) {
+            (void)hipStreamSynchronize(s);
+            (void)hipGetLastError();
+        }
+    }
+};
+int precompute_tables(kzg_ctx* ctx, const TableSpec& sp, g1_affine_t* table) {
     hipStream_t s = ctx->lane[0].stream;
-    const uint64_t tile = ctx->stride < ((uint64_t)1 << 20) ? ctx->stride : ((uint64_t)1 << 20);
+    const uint64_t tile = sp.stride < ((uint64_t)1 << 20) ? sp.stride : ((uint64_t)1 << 20);
     DevBuf tmp;
-    HIPCHK(ctx, tmp.ensure((size_t)(ctx->nwin - 1) * tile * sizeof(g1_xyzz_t) + 256));
-    for (uint64_t first = 0; first < ctx->stride; first += tile) {
-        uint64_t cnt = ctx->stride - first < tile ? ctx->stride - first : tile;
-        launch_srs_precompute(s, ctx->table.as<g1_affine_t>(), ctx->stride, first, cnt, ctx->lay, tmp.as<g1_xyzz_t>());
+    HIPCHK(ctx, tmp.ensure((size_t)(sp.nwin - 1) * tile * sizeof(g1_xyzz_t) + 256));
+    for (uint64_t first = 0; first < sp.stride; first += tile) {
+        uint64_t cnt = sp.stride - first < tile ? sp.stride - first : tile;
+        launch_srs_precompute(s, table, sp.stride, first, cnt, sp.lay, tmp.as<g1_xyzz_t>());
     }
     HIPCHK(ctx, hipStreamSynchronize(s));
     HIPCHK(ctx, hipGetLastError());
@@ -1004,36 +1044,112 @@ int kzg_set_host_finish(kzg_ctx* ctx, int enable) {
     return KZG_OK;
 }
 
+// copies [src, src + bytes) with up to four threads: a setup file in the page cache is read at memory speed, not at one
+// core's memcpy speed
+static void copy_parallel(uint8_t* dst, const uint8_t* src, size_t bytes) {
+    const size_t min_piece = (size_t)4 << 20;
+    const unsigned parts = (unsigned)std::min<size_t>(4, std::max<size_t>(1, bytes / min_piece));
+    if (parts <= 1) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t piece = ((bytes / parts) + 4095) & ~(size_t)4095;
+    for (unsigned t = 1; t < parts; t++) {
+        const size_t off = (size_t)t * piece;
+        if (off >= bytes) break;
+        const size_t len = std::min(piece, bytes - off);
+        th.emplace_back([=] { memcpy(dst + off, src + off, len); });
+    }
+    memcpy(dst, src, std::min(piece, bytes));
+    for (auto& t : th) t.join();
+}
+// The points of a setup file / caller buffer -> a NEW window-0 table, tile by tile through two pinned staging buffers: the
+// host fills buffer b (from the mmapped file or the caller's memory) while the GPU still copies and decodes buffer 1 - b;
+// the only host waits are for a buffer to come free.  Then the window tables; then the swap.
 static int load_srs_common(kzg_ctx* ctx, const uint8_t* data, uint64_t n_points, int scale, int machines_scale,
                            bool compressed) {
     if (!ctx || !data) return KZG_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    using clk = std::chrono::steady_clock;
+    const auto t_begin = clk::now();
+    double host_copy_s = 0, wait_s = 0;
     LaneHold H(ctx);
     if (int rc = H.take_all()) return rc;
     Lane& L = H.L();
-    TableRollback rollback{ctx};
-    int rc = alloc_table(ctx, n_points, scale, machines_scale);
+    TableSpec sp;
+    int rc = plan_table(ctx, n_points, scale, machines_scale, sp);
     if (rc) return rc;
-    rollback.armed = true;
+    DevBuf nt;
+    rc = alloc_new_table(ctx, sp, nt);
+    if (rc) return rc;
+    DrainGuard drain{L.stream};
     rc = clear_flags(ctx, L);
     if (rc) return rc;
-    const uint64_t tile = (uint64_t)1 << 20;
+    const uint64_t tile = (uint64_t)1 << 18;
     const size_t rec = compressed ? 48 : 96;
-    HIPCHK(ctx, L.in_be.ensure((n_points < tile ? n_points : tile) * rec));
-    for (uint64_t first = 0; first < n_points; first += tile) {
-        uint64_t cnt = n_points - first < tile ? n_points - first : tile;
-        HIPCHK(ctx, hipMemcpyAsync(L.in_be.p, data + rec * first, cnt * rec, hipMemcpyHostToDevice, L.stream));
-        if (compressed)
-            launch_srs_from_c48(L.stream, L.in_be.as<uint8_t>(), ctx->table.as<g1_affine_t>() + first, cnt, L.flags() + 1);
-        else
-            launch_srs_from_be96(L.stream, L.in_be.as<uint8_t>(), ctx->table.as<g1_affine_t>() + first, cnt, L.flags() + 1);
-        HIPCHK(ctx, hipStreamSynchronize(L.stream));
+    const uint64_t tile_pts = n_points < tile ? n_points : tile;
+    struct PinPair {
+        uint8_t* p[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        bool used[2] = {false, false};
+        ~PinPair() {
+            for (int b = 0; b < 2; b++) {
+                if (ev[b]) (void)hipEventDestroy(ev[b]);
+                if (p[b]) (void)hipHostFree(p[b]);
+            }
+        }
+    } pin;   // (dies before `drain` runs: every path below that leaves with copies in flight drains the stream itself first)
+    const int nbuf = n_points > tile ? 2 : 1;
+    for (int b = 0; b < nbuf; b++) {
+        HIPCHK(ctx, hipHostMalloc((void**)&pin.p[b], tile_pts * rec, hipHostMallocDefault));
+        HIPCHK(ctx, hipEventCreateWithFlags(&pin.ev[b], hipEventDisableTiming));
     }
-    rc = finish(ctx, L);
+    DevBuf dev_in[2];
+    for (int b = 0; b < nbuf; b++) HIPCHK(ctx, dev_in[b].ensure(tile_pts * rec));
+    g1_affine_t* table = nt.as<g1_affine_t>();
+    hipError_t err = hipSuccess;
+    uint64_t t_idx = 0;
+    for (uint64_t first = 0; first < n_points && err == hipSuccess; first += tile, t_idx++) {
+        const int b = (int)(t_idx & 1) % nbuf;
+        const uint64_t cnt = n_points - first < tile ? n_points - first : tile;
+        if (pin.used[b]) {
+            const auto w0 = clk::now();
+            err = hipEventSynchronize(pin.ev[b]);     // the H2D copy that last read this buffer has completed
+            wait_s += std::chrono::duration<double>(clk::now() - w0).count();
+            if (err != hipSuccess) break;
+        }
+        const auto c0 = clk::now();
+        copy_parallel(pin.p[b], data + rec * first, cnt * rec);
+        host_copy_s += std::chrono::duration<double>(clk::now() - c0).count();
+        err = hipMemcpyAsync(dev_in[b].p, pin.p[b], cnt * rec, hipMemcpyHostToDevice, L.stream);
+        if (err != hipSuccess) break;
+        err = hipEventRecord(pin.ev[b], L.stream);
+        pin.used[b] = true;
+        if (compressed) launch_srs_from_c48(L.stream, dev_in[b].as<uint8_t>(), table + first, cnt, L.flags() + 1);
+        else launch_srs_from_be96(L.stream, dev_in[b].as<uint8_t>(), table + first, cnt, L.flags() + 1);
+    }
+    if (err != hipSuccess) {
+        (void)hipStreamSynchronize(L.stream);
+        return fail(ctx, KZG_E_HIP, std::string("SRS upload: ") + hipGetErrorString(err));
+    }
+    const auto w0 = clk::now();
+    rc = finish(ctx, L);        // drains the stream; a bad point in ANY tile has raised the flag by now
+    wait_s += std::chrono::duration<double>(clk::now() - w0).count();
+    if (rc) return rc;          // the previous table (if any) keeps serving
+    const auto p0 = clk::now();
+    rc = precompute_tables(ctx, sp, table);
     if (rc) return rc;
-    rc = precompute_tables(ctx);
-    if (rc) return rc;
-    rollback.armed = false;
+    const double tables_s = std::chrono::duration<double>(clk::now() - p0).count();
+    drain.armed = false;
+    install_table(ctx, sp, nt);
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        ctx->load_stats[0] = host_copy_s;
+        ctx->load_stats[1] = wait_s;
+        ctx->load_stats[2] = tables_s;
+        ctx->load_stats[3] = std::chrono::duration<double>(clk::now() - t_begin).count();
+    }
     H.clean = true;
     return KZG_OK;
 }
@@ -1042,6 +1158,41 @@ int kzg_load_srs(kzg_ctx* ctx, const uint8_t* g1_affine_be96, uint64_t n_points,
 }
 int kzg_load_srs_compressed(kzg_ctx* ctx, const uint8_t* g1_c48, uint64_t n_points, int scale, int machines_scale) {
     return load_srs_common(ctx, g1_c48, n_points, scale, machines_scale, true);
+}
+// The reference's start path: `Client(setup_path=...).start(scale, machines_scale)` hands the prover a FILE
+// (base/miner.py:75-84, Makefile:63-74: setup_24_8.uncompressed = 2^24 points, 1.6 GB).  The file is mapped, not read:
+// its pages go from the page cache into the pinned tiles and nowhere else.
+int kzg_load_srs_file(kzg_ctx* ctx, const char* path, int compressed, int scale, int machines_scale) {
+    if (!ctx || !path) return KZG_E_ARG;
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return fail(ctx, KZG_E_ARG, std::string("cannot open setup file ") + path + ": " + strerror(errno));
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size <= 0) {
+        close(fd);
+        return fail(ctx, KZG_E_ARG, std::string("setup file ") + path + " is empty or unreadable");
+    }
+    const size_t rec = compressed ? 48 : 96;
+    if ((size_t)st.st_size % rec) {
+        close(fd);
+        return fail(ctx, KZG_E_ARG, "setup file must be a whole number of " + std::to_string(rec) + "-byte G1 points");
+    }
+    void* map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) return fail(ctx, KZG_E_NOMEM, std::string("mmap(setup file): ") + strerror(errno));
+    (void)madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL);
+    (void)madvise(map, (size_t)st.st_size, MADV_WILLNEED);
+    const int rc = load_srs_common(ctx, static_cast<const uint8_t*>(map), (uint64_t)st.st_size / rec, scale, machines_scale,
+                                   compressed != 0);
+    munmap(map, (size_t)st.st_size);
+    return rc;
+}
+// seconds of the last successful kzg_load_srs*: [0] host copies file/buffer -> pinned tiles, [1] host waits for the GPU
+// (upload + decode / decompression), [2] window-table build, [3] the whole call
+int kzg_get_load_stats(kzg_ctx* ctx, double out_s[4]) {
+    if (!ctx || !out_s) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (int i = 0; i < 4; i++) out_s[i] = ctx->load_stats[i];
+    return KZG_OK;
 }
 
 int kzg_gen_srs(kzg_ctx* ctx, const uint8_t tau_be32[32], const uint8_t* s0_be32, uint32_t n_slices, int scale,
@@ -1054,10 +1205,13 @@ int kzg_gen_srs(kzg_ctx* ctx, const uint8_t tau_be32[32], const uint8_t* s0_be32
     if (int rc = H.take_all()) return rc;
     Lane& L = H.L();
     const uint64_t T = (uint64_t)1 << (scale - machines_scale);
-    TableRollback rollback{ctx};
-    int rc = alloc_table(ctx, (uint64_t)n_slices * T, scale, machines_scale);
+    TableSpec sp;
+    int rc = plan_table(ctx, (uint64_t)n_slices * T, scale, machines_scale, sp);
     if (rc) return rc;
-    rollback.armed = true;
+    DevBuf nt;
+    rc = alloc_new_table(ctx, sp, nt);
+    if (rc) return rc;
+    DrainGuard drain{L.stream};
     rc = clear_flags(ctx, L);
     if (rc) return rc;
     DevBuf gtab, tmp, sc;
@@ -1074,7 +1228,7 @@ int kzg_gen_srs(kzg_ctx* ctx, const uint8_t tau_be32[32], const uint8_t* s0_be32
     for (uint32_t k = 0; k < n_slices; k++) {
         for (uint64_t first = 0; first < T; first += tile) {
             uint64_t cnt = T - first < tile ? T - first : tile;
-            launch_srs_generate(L.stream, ctx->table.as<g1_affine_t>() + (uint64_t)k * T + first, cnt, first, tau_m,
+            launch_srs_generate(L.stream, nt.as<g1_affine_t>() + (uint64_t)k * T + first, cnt, first, tau_m,
                                 tau_m + 8 * (1 + (uint64_t)k), gtab.as<g1_affine_t>(), tmp.as<g1_xyzz_t>(),
                                 k == 0 && first == 0);
         }
@@ -1082,9 +1236,10 @@ int kzg_gen_srs(kzg_ctx* ctx, const uint8_t tau_be32[32], const uint8_t* s0_be32
     rc = finish(ctx, L);  // synchronises: gtab / tmp / sc are idle when they go out of scope
     if (rc) return rc;
     HIPCHK(ctx, hipGetLastError());
-    rc = precompute_tables(ctx);
+    rc = precompute_tables(ctx, sp, nt.as<g1_affine_t>());
     if (rc) return rc;
-    rollback.armed = false;
+    drain.armed = false;
+    install_table(ctx, sp, nt);
     H.clean = true;
     return KZG_OK;
 }

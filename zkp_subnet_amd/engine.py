@@ -6,6 +6,7 @@ methods to exercise the host logic on machines without a GPU."""
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 from . import _native
@@ -92,6 +93,19 @@ class HipEngine:
             self._chk(self._lib.kzg_load_srs(self._h, points, len(points) // 96, scale, machines_scale))
         self.scale, self.machines_scale = scale, machines_scale
         self.verifier = None
+
+    def load_srs_file(self, path: str, scale: int, machines_scale: int, compressed: bool = False) -> None:
+        """The setup FILE the reference prover is started with (base/miner.py:75-84): mapped and streamed by the library
+        (pinned double-buffered tiles), never read into Python memory."""
+        self._chk(self._lib.kzg_load_srs_file(self._h, os.fsencode(path), int(compressed), scale, machines_scale))
+        self.scale, self.machines_scale = scale, machines_scale
+        self.verifier = None
+
+    def load_stats(self) -> Dict[str, float]:
+        """Seconds of the last successful SRS load: host copies, waits for upload + decode, window tables, total."""
+        arr = (ctypes.c_double * 4)()
+        self._chk(self._lib.kzg_get_load_stats(self._h, arr))
+        return {"host_copy_s": arr[0], "gpu_wait_s": arr[1], "tables_s": arr[2], "total_s": arr[3]}
 
     def set_verifier_key(self, tau_g2_be192: bytes, li_g1_be96: bytes) -> None:
         """Verification key of a loaded SRS: [tau_x]_2 (uncompressed G2, 192 B) and [L_i(tau_y)]_1 per resident slice."""
