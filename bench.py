@@ -14,6 +14,11 @@ per-GPU work fixed).  `value` = points of all ranks / wall time of the K timed s
 one per rank (N = 1: all 2^26 points and 103 GB of window tables on one GPU); strong scaling, same collective.
 `--workload kzg22` is configs[2] / [4]: one degree-2^22 commit+open per GPU (N > 1: Pianist rows, no exchange).
 
+With a process group (N > 1, the driver's SCALE runs) and no --workload, the SAME launch also measures configs[3] and
+configs[4] after the headline region and adds them to the line as `msm26` (one 2^26-point MSM over N SRS segments,
+strong scaling) and `pianist_kzg22` (one 2^22 commit+open per rank): a flag-less multi-GPU run yields every BASELINE
+multi-GPU number.  Every rank's MSM result is checked against rank 0's.
+
 Extra objects on the JSON line:
   roofline         dominant kernel (k_msm_accumulate): duration from HIP events on the library's own stream inside the
                    timed region, denominators from SURVEY.md 8d (128 B per point)
@@ -196,6 +201,114 @@ def kzg_rows_report(HipEngine, lagrange_factor, device, logs, cpu_threads, with_
     return rows
 
 
+def dist_extra_workloads(args, torch, dist, HipEngine, lagrange_factor, rank, local_rank, world):
+    """With a process group and no --workload: the OTHER multi-GPU configurations of BASELINE.json, measured in the same
+    launch so that a driver SCALE run (which passes no flags) yields every multi-GPU number:
+      msm26          configs[3]: ONE 2^26-point MSM, SRS split into `world` contiguous segments, one per rank, partials
+                     all_gathered over RCCL and summed on every rank (strong scaling: total work fixed)
+      pianist_kzg22  configs[4]: one degree-2^22 commit+open per rank (Pianist worker row `rank`), no exchange (weak)
+    Same timing discipline as the headline: W warm-up steps, K steps between barrier + synchronize, MAX over ranks.
+    Every rank's MSM result must equal rank 0's."""
+    from zkp_subnet_amd.distributed import DeviceGather
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_bytes(b):
+        src = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+        out = torch.empty(world * len(b), dtype=torch.uint8, device="cuda")
+        dist.all_gather_into_tensor(out, src)
+        raw = out.cpu().numpy().tobytes()
+        return [raw[i * len(b):(i + 1) * len(b)] for i in range(world)]
+
+    res = {}
+    steps, warm = max(1, min(args.steps, 10)), max(1, min(args.warmup, 3))
+    # ---- msm26
+    lg_total = args.msm26_log
+    if not (world & (world - 1)) and (1 << lg_total) >= world:
+        n_total = 1 << lg_total
+        n = n_total // world
+        lg = n.bit_length() - 1
+        eng = HipEngine(local_rank, window=args.window)
+        t0 = time.time()
+        scal = uniform_fr(n, seed=1000 + rank)
+        eng.gen_srs(TAU, 1, lg, 0, factors=[pow(TAU, rank * n, R_MOD)])
+        eng.upload_fr(0, scal, False)
+        setup_s = time.time() - t0
+        g = DeviceGather(eng)
+        for _ in range(warm):
+            ref = g.msm(0, n, 0)
+        eng.set_profiling(2)
+        barrier()
+        t0 = time.perf_counter()
+        acc = 0.0
+        for _ in range(steps):
+            r = g.msm(0, n, 0)
+            acc += eng.timings().get("accumulate", 0.0)
+            assert r == ref, "non-deterministic sharded MSM"
+        barrier()
+        el = max_over_ranks(time.perf_counter() - t0)
+        eng.set_profiling(0)
+        allr = gather_bytes(ref)
+        assert all(x == allr[0] for x in allr), "ranks disagree on the sharded MSM result"
+        kernel_ms = acc / steps
+        ach = 128.0 * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None
+        res["msm26"] = {
+            "metric": f"BLS12-381 G1 MSM points/sec at 2^{lg_total} (SRS-sharded)", "value": n_total * steps / el,
+            "unit": "points/s", "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warm, "scaling": "strong",
+            "n_gpus": world, "points_per_gpu": n, "window_bits": eng.window, "result_hex": ref.hex(),
+            "all_ranks_equal": True, "setup_s": round(setup_s, 2),
+            "workload": f"2^{lg_total}-point G1 MSM, SRS split into {world} contiguous segment(s) of 2^{lg} points, "
+                        "partials all_gathered (192 B per rank) over RCCL, summed on every rank",
+            "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS if ach else None, "kernel_ms": kernel_ms,
+                         "algorithmic_bytes": 128.0 * n, "traffic": None}}
+        del g
+        eng.close()
+        torch.cuda.empty_cache()
+    # ---- pianist_kzg22: worker row `rank` on this GPU, full commit+open, no data-path collective
+    lg = args.kzg22_log
+    T = 1 << lg
+    ms = max(0, (world - 1).bit_length())
+    eng = HipEngine(local_rank, window=args.window)
+    t0 = time.time()
+    row = uniform_fr(T, seed=rank)
+    alpha = uniform_fr(1, seed=1)
+    tau_y = (TAU * 7 + 1) % R_MOD
+    eng.gen_srs(TAU, 0, lg + ms, ms, factors=[lagrange_factor(rank, ms, tau_y)])
+    eng.upload_fr(0, row, True)
+    setup_s = time.time() - t0
+    for _ in range(warm):
+        ref = eng.commit_open_resident(0, 0, T, alpha, True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        assert eng.commit_open_resident(0, 0, T, alpha, True) == ref, "non-deterministic commit+open"
+    barrier()
+    el = max_over_ranks(time.perf_counter() - t0)
+    rows = gather_bytes(b"".join(ref))               # 48 + 32 + 48 bytes per rank
+    agg = eng.g1_sum_compressed(b"".join(r[:48] for r in rows))     # master aggregation: sum_i commit_i
+    alg = 384.0 * T
+    res["pianist_kzg22"] = {
+        "metric": f"KZG commit+open coefficients/sec at 2^{lg} per segment", "value": T * world * steps / el,
+        "unit": "coefficients/s", "ms_per_step": el / steps * 1e3, "per_segment_latency_ms": el / steps * 1e3,
+        "steps": steps, "warmup": warm, "scaling": "weak", "n_gpus": world, "window_bits": eng.window,
+        "workload": f"Pianist segments: {world} worker row(s) of 2^{lg} evaluation-form coefficients, one per GPU, full "
+                    "commit+open (INTT + 2 MSM + quotient) per segment, no exchange on the data path",
+        "results_hex_by_rank": [r.hex() for r in rows], "aggregate_commitment_hex": agg.hex(), "setup_s": round(setup_s, 2),
+        "roofline": {"bound": "hbm", "achieved": alg / (el / steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg / (el / steps) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg, "per": "whole commit+open call",
+                     "traffic": None}}
+    eng.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,12 +329,16 @@ def main():
     ap.add_argument("--kzg-rows", default="22,16,12", help="log2 row lengths of `kzg_commit_open`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adversarial", action="store_true", help="skip the separately reported adversarial inputs")
+    ap.add_argument("--no-dist-extra", action="store_true",
+                    help="with a process group and the default workload: skip the msm26 / pianist_kzg22 objects")
+    ap.add_argument("--msm26-log", type=int, default=26, help="log2(total points) of the `msm26` object")
+    ap.add_argument("--kzg22-log", type=int, default=22, help="log2(row length) of the `pianist_kzg22` object")
     ap.add_argument("--headline-only", action="store_true",
                     help="timed region only (profiling runs: every k_msm_accumulate launch is then an uncontended launch "
                          "of the headline size, so rocprofv3's average matches `roofline.kernel_ms`)")
     args = ap.parse_args()
     if args.headline_only:
-        args.no_pipelined = args.no_kzg_rows = args.no_cpu_baseline = args.no_adversarial = True
+        args.no_pipelined = args.no_kzg_rows = args.no_cpu_baseline = args.no_adversarial = args.no_dist_extra = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -411,6 +528,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert all(r == results[0] for r in results), "non-deterministic result across steps"
+    window_bits = eng.window
+    dist_extra = None
+    rccl_version = None
+    if use_dist:
+        try:
+            rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:                      # noqa: BLE001 -- informational only
+            rccl_version = "unknown"
+        if is_msm:                             # every rank computed the same sum: check it, do not assume it
+            src = torch.frombuffer(bytearray(results[0]), dtype=torch.uint8).cuda()
+            allr = torch.empty(world * 48, dtype=torch.uint8, device="cuda")
+            dist.all_gather_into_tensor(allr, src)
+            allr = allr.cpu().numpy().tobytes()
+            assert all(allr[48 * i:48 * i + 48] == results[0] for i in range(world)), "ranks disagree on the MSM result"
+    if use_dist and args.workload == "msm20" and not args.no_dist_extra:
+        # free this workload's tables first (2^26 / world points per rank come next); rank 0 needs nothing more from `eng`
+        eng.close()
+        eng = None
+        torch.cuda.empty_cache()
+        dist_extra = dist_extra_workloads(args, torch, dist, HipEngine, lagrange_factor, rank, local_rank, world)
 
     if rank == 0:
         stages = {k: v / n_prof for k, v in stage_sum.items()}
@@ -443,7 +580,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pmc = json.load(f)
-            if (pmc["workload"], pmc["points_per_gpu"], pmc["window_bits"]) == ("msm20" if is_msm else args.workload, n, eng.window):
+            if (pmc["workload"], pmc["points_per_gpu"], pmc["window_bits"]) == ("msm20" if is_msm else args.workload, n, window_bits):
                 traffic = pmc["traffic_bytes_per_launch"]
                 valu_insts = pmc.get("sq_insts_valu_per_launch")
                 mads = pmc.get("wave_mads_per_launch")
@@ -454,9 +591,10 @@ def main():
             "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": wl, "points_per_gpu": n, "window_bits": eng.window, "windows": plan["windows"],
+            "config": {"workload": wl, "points_per_gpu": n, "window_bits": window_bits, "windows": plan["windows"],
                        "buckets": plan["buckets"], "entries_per_lane": plan["chunk"], "lanes": plan["lanes"],
-                       "requests_in_flight": depth,
+                       "requests_in_flight": depth, "world_size": dist.get_world_size() if use_dist else 1,
+                       "rccl_version": rccl_version,
                        "parallelism": "single GPU" if world == 1 else
                        (f"SRS-sharded x{world}, all_gather of 192 B partials over RCCL" if is_msm
                         else f"Pianist segments x{world}, no exchange")},
@@ -498,7 +636,7 @@ def main():
                     assert eng.commit_open(0, scal, alpha, True) == results[0]
                 out["pcie_inclusive_latency_ms"] = round((time.perf_counter() - tp) / 3 * 1e3, 4)
         # ---- adversarial scalar distributions (SURVEY 8d cfg 2: reported separately, never part of `value`)
-        if world == 1 and args.workload == "msm20" and not args.no_adversarial:
+        if world == 1 and args.workload == "msm20" and not args.no_adversarial and eng is not None:
             import numpy as np
 
             adv = {}
@@ -515,7 +653,7 @@ def main():
             out["adversarial"] = adv
         # ---- CPU baseline: the oracle's C port on a bounded sample of the same inputs
         threads = thread_counts(args.cpu_threads)
-        if world == 1 and not args.no_cpu_baseline and is_msm:
+        if world == 1 and not args.no_cpu_baseline and is_msm and eng is not None:
             from oracle import cpu as oc
 
             oc.build()
@@ -548,7 +686,10 @@ def main():
                 "matches_gpu_bit_exact": cpu_res == gpu_same,
             }
             assert cpu_res == gpu_same, "GPU MSM differs from the CPU oracle on the baseline sample"
-        eng.close()
+        if dist_extra:
+            out.update(dist_extra)      # `msm26` (configs[3]) and `pianist_kzg22` (configs[4]) of the same launch
+        if eng is not None:
+            eng.close()
         eng = None
         # ---- KZG commit+open latency: the other half of BASELINE.json's metric (configs[2] + the production row sizes)
         if world == 1 and args.workload == "msm20" and not args.no_kzg_rows:

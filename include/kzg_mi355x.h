@@ -92,6 +92,18 @@ int kzg_open(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t T, int 
 int kzg_commit_open(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
                     const uint8_t alpha_be32[32], uint8_t out_commitment48[48], uint8_t out_eval32[32],
                     uint8_t out_proof48[48]);
+/* The UNCHANGED reference miner makes two calls per request with the same row -- worker_commit(i, poly), then
+ * worker_open(i, poly, x) (neurons/miner.py:56-61).  These forms take a 128-bit content tag identifying the row's bytes
+ * (the host codec computes it while decoding the text); the coefficient vectors of the last four rows stay on the
+ * device, and a call whose (tag, T, evaluation_form) is cached skips upload + INTT.  A miss behaves exactly like
+ * kzg_commit / kzg_open and leaves its own coefficients behind.  Results are identical either way.  The caller vouches
+ * that equal tags mean equal rows. */
+int kzg_commit_cached(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
+                      const uint8_t content_tag[16], uint8_t out_commitment48[48]);
+int kzg_open_cached(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
+                    const uint8_t content_tag[16], const uint8_t alpha_be32[32], uint8_t out_eval32[32],
+                    uint8_t out_proof48[48]);
+int kzg_row_cache_stats(kzg_ctx* ctx, uint64_t out_hits_misses[2]);
 /* plain MSM over resident points [srs_offset, srs_offset+n): the headline kernel (BASELINE.json metric) */
 int kzg_msm(kzg_ctx* ctx, const uint8_t* scalars_be32, uint64_t n, uint64_t srs_offset, uint8_t out48[48]);
 /* replaces Client.fft(poly, left, inverse)          (reference neurons/validator.py:58-65); in place */

@@ -51,7 +51,8 @@ for lg in sizes:
         with cl.worker_commit(0, poly) as a, cl.worker_open(0, poly, x) as b:
             assert a.json()["commitment"] == body["commitment"] and b.json()["proof"] == body["proof"]
     two_call = (time.perf_counter() - t0) / reps
-    print(json.dumps({"log2_T": lg, "e2e_fused_ms": round(e2e * 1e3, 3), "text_decode_ms": round(dec * 1e3, 3),
+    hits, misses = cl.engine.row_cache_stats()
+    print(json.dumps({"log2_T": lg, "row_cache_hits_misses": [hits, misses], "e2e_fused_ms": round(e2e * 1e3, 3), "text_decode_ms": round(dec * 1e3, 3),
                       "host_buffer_call_ms": round(host_buf * 1e3, 3), "resident_call_ms": round(resident * 1e3, 3),
                       "two_call_route_ms": round(two_call * 1e3, 3), "wire_ext": codec._wire is not None}), flush=True)
     cl.stop()

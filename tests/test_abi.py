@@ -243,3 +243,50 @@ def test_shipped_library_carries_no_prototype_hooks(lib):
     assert not hasattr(lib, "kzg_proto_baff")
     hdr = open(os.path.join(ROOT, "include", "kzg_mi355x.h")).read()
     assert "kzg_proto" not in hdr and "baff" not in hdr
+
+
+def test_content_tag_identifies_the_decoded_row():
+    """decode_fr_list_into_tagged: the 128-bit keyed tag behind the prover's coefficient cache (kzg_commit_cached /
+    kzg_open_cached).  Same bytes -> same tag whatever the thread split or the decoder (AVX2 / scalar); any changed,
+    swapped, dropped or appended element -> a different tag; the decoded bytes are those of the untagged decoder."""
+    import random
+
+    w = codec._wire
+    assert w is not None
+    rnd = random.Random(11)
+    raw = b"".join(rnd.randrange(codec.R_MODULUS).to_bytes(32, "big") for _ in range(5000))
+    poly = codec.be32_to_fr_list(raw)
+    buf = ctypes.create_string_buffer(len(raw))
+    tags = set()
+    level0 = w.simd_level()
+    for level in (0, 2):
+        w.set_simd(level)
+        for th in (1, 3, 8):
+            n, tag = w.decode_fr_list_into_tagged(poly, ctypes.addressof(buf), len(buf), th)
+            assert n == 5000 and buf.raw == raw and len(tag) == 16
+            tags.add(tag)
+    w.set_simd(level0)
+    assert len(tags) == 1
+    base = tags.pop()
+    one = codec.be32_to_fr((1).to_bytes(32, "big"))
+    variants = []
+    for k in (0, 1, 2499, 4998, 4999):
+        v = list(poly)
+        v[k] = one
+        variants.append(v)
+        low = bytearray(raw[32 * k:32 * k + 32])
+        low[31] ^= 1                                   # a single flipped bit
+        v2 = list(poly)
+        v2[k] = codec.be32_to_fr(bytes(low))
+        variants.append(v2)
+    sw = list(poly)
+    sw[10], sw[11] = sw[11], sw[10]
+    variants += [sw, poly[:-1], poly + [one], poly[1:]]
+    seen = {base}
+    for v in variants:
+        big = ctypes.create_string_buffer(32 * len(v))
+        tag = w.decode_fr_list_into_tagged(v, ctypes.addressof(big), len(big))[1]
+        assert tag not in seen
+        seen.add(tag)
+    with pytest.raises(ValueError):
+        w.decode_fr_list_into_tagged(poly[:5] + ["@" * 43], ctypes.addressof(buf), len(buf))

@@ -920,6 +920,100 @@ def test_setup_cli_file_roundtrip_through_client(hip, tmp_path, fr_kat):
     in_memory.stop()
 
 
+def test_two_call_route_is_served_from_the_row_cache_only_for_the_same_content(hip):
+    """The UNCHANGED reference miner calls worker_commit(i, poly) then worker_open(i, poly, x) (neurons/miner.py:56-61).
+    The second call finds the row's coefficient vector on the device (keyed by the 128-bit content tag of the decoded
+    bytes): no upload, no INTT -- and the results are the oracle's.  A row with ONE changed coefficient between the two
+    calls must NOT be served from the cache."""
+    import threading
+
+    from zkp_subnet_amd.client import Client, derive_taus
+
+    scale, ms, seed = 12, 2, 4321
+    T = 1 << (scale - ms)
+    cl = Client(seed=seed)
+    cl.start(scale, ms)
+    eng = cl.engine
+    tx, ty = derive_taus(seed)
+    srs = {i: oc.srs_gen(tx.to_bytes(32, "big"), ty.to_bytes(32, "big"), scale, ms, i) for i in range(4)}
+    rnd = random.Random(99)
+    alpha = rnd.randrange(o.R)
+    alpha_s, alpha_b = o.fr_to_b64(alpha), alpha.to_bytes(32, "big")
+
+    def expect(i, vals):
+        rb = o.fr_to_be32(vals)
+        ev, pf = oc.open_(srs[i], rb, alpha_b, True)
+        return oc.commit(srs[i], rb, True), ev, pf
+
+    def commit(i, poly):
+        with cl.worker_commit(i, poly) as r:
+            assert r.status_code == 200
+            return base64.b64decode(r.json()["commitment"])
+
+    def open_(i, poly):
+        with cl.worker_open(i, poly, alpha_s) as r:
+            assert r.status_code == 200
+            return o.fr_from_b64(r.json()["eval"]).to_bytes(32, "big"), base64.b64decode(r.json()["proof"])
+
+    vals = [rnd.randrange(o.R) for _ in range(T)]
+    poly = [o.fr_to_b64(v) for v in vals]
+    h0, m0 = eng.row_cache_stats()
+    want = expect(1, vals)
+    assert commit(1, poly) == want[0]
+    assert eng.row_cache_stats() == (h0, m0 + 1)                       # first sight of the row: a miss, now cached
+    assert open_(1, poly) == want[1:]
+    assert eng.row_cache_stats() == (h0 + 1, m0 + 1)                   # the open was served from the cache
+    assert open_(2, list(poly)) == expect(2, vals)[1:]                 # same content, other list object, other worker
+    assert eng.row_cache_stats() == (h0 + 2, m0 + 1)
+    # ONE coefficient changed between commit and open: not the cached row
+    vals2 = list(vals)
+    vals2[T // 2] = (vals2[T // 2] + 1) % o.R
+    poly2 = list(poly)
+    poly2[T // 2] = o.fr_to_b64(vals2[T // 2])
+    assert open_(1, poly2) == expect(1, vals2)[1:] != want[1:]
+    assert eng.row_cache_stats() == (h0 + 2, m0 + 2)
+    assert open_(1, poly) == want[1:]                                  # the original row is still cached
+    assert eng.row_cache_stats() == (h0 + 3, m0 + 2)
+    # a failed call leaves nothing behind: a non-canonical scalar (>= r) is refused again on the retry
+    bad = list(poly)
+    bad[3] = base64.b64encode(o.R.to_bytes(32, "big")).decode().rstrip("=")
+    assert cl.worker_commit(1, bad).status_code == 400
+    assert cl.worker_open(1, bad, alpha_s).status_code == 400
+    # more distinct rows than cache slots, then the first again: evicted, recomputed, still right
+    for k in range(6):
+        vk = [rnd.randrange(o.R) for _ in range(T)]
+        pk = [o.fr_to_b64(v) for v in vk]
+        wk = expect(k % 4, vk)
+        assert commit(k % 4, pk) == wk[0] and open_(k % 4, pk) == wk[1:]
+    assert commit(1, poly) == want[0] and open_(1, poly) == want[1:]
+    # shorter prefix of the same row: other length, other tag
+    assert open_(3, poly[: T // 2]) == expect(3, vals[: T // 2])[1:]
+    # the axon's worker threads: the same and different rows concurrently
+    errors = []
+
+    def worker(t):
+        try:
+            r2 = random.Random(500 + t)
+            for it in range(6):
+                if it % 2:
+                    assert commit(1, poly) == want[0] and open_(1, poly) == want[1:]
+                else:
+                    v = [r2.randrange(o.R) for _ in range(T)]
+                    pv = [o.fr_to_b64(x) for x in v]
+                    w = expect(t % 4, v)
+                    assert commit(t % 4, pv) == w[0] and open_(t % 4, pv) == w[1:]
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    cl.stop()
+
+
 def _write_setup(tmp_path, name, scale, ms, seed, compressed=False):
     from zkp_subnet_amd import setup_cli
 
@@ -1065,9 +1159,26 @@ def test_bench_contract_line(hip):
     # the collective path (1-rank RCCL group: partial -> all_gather -> sum through device buffers) gives the same point
     env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
     out2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--log-n", "14", "--steps", "3", "--warmup", "1",
-                           "--no-cpu-baseline", "--no-adversarial", "--no-kzg-rows"], capture_output=True, text=True,
-                          timeout=600, cwd=root, env=env)
+                           "--no-cpu-baseline", "--no-adversarial", "--no-kzg-rows", "--msm26-log", "16", "--kzg22-log", "12"],
+                          capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert out2.returncode == 0, out2.stderr[-2000:]
     rec2 = json.loads([ln for ln in out2.stdout.splitlines() if ln.strip()][-1])
     assert rec2["result_hex"] == rec["result_hex"] and len(rec["result_hex"]) == 96
+    # a process group + no --workload: the same launch also yields configs[3] (msm26) and configs[4] (pianist_kzg22)
+    assert rec2["config"]["world_size"] == 1 and rec2["config"]["rccl_version"]
+    m26, pk = rec2["msm26"], rec2["pianist_kzg22"]
+    assert m26["scaling"] == "strong" and m26["all_ranks_equal"] and m26["value"] > 0 and m26["roofline"]["kernel_ms"] > 0
+    assert abs(m26["value"] - (1 << 16) * m26["steps"] / (m26["ms_per_step"] * m26["steps"] * 1e-3)) / m26["value"] < 1e-6
+    assert pk["scaling"] == "weak" and pk["value"] > 0 and len(pk["results_hex_by_rank"]) == 1
+    assert pk["aggregate_commitment_hex"] == pk["results_hex_by_rank"][0][:96]      # one row: the sum is the row's own
+    # ... and both agree with the oracle on the same seeded inputs
+    from bench import TAU, uniform_fr
+    e = hip()
+    e.gen_srs(TAU, 1, 16, 0)
+    assert bytes.fromhex(m26["result_hex"]) == oc.msm(e.srs_read(0, 1 << 16), uniform_fr(1 << 16, 1000), threads=4)
+    e.gen_srs(TAU, 0, 12, 0, factors=[1])
+    row, alpha = uniform_fr(1 << 12, 0), uniform_fr(1, 1)
+    srs = e.srs_read(0, 1 << 12)
+    want = oc.commit(srs, row, True) + b"".join(oc.open_(srs, row, alpha, True))
+    assert bytes.fromhex(pk["results_hex_by_rank"][0]) == want
     assert rec2["pipelined"]["value"] > 0 and "RCCL" in rec2["config"]["parallelism"] or rec2["n_gpus"] == 1

@@ -35,6 +35,9 @@ SYMBOLS = {
     "kzg_commit": (_I, [_P, _U32, _B, _U64, _I, _B]),
     "kzg_open": (_I, [_P, _U32, _B, _U64, _I, _B, _B, _B]),
     "kzg_commit_open": (_I, [_P, _U32, _B, _U64, _I, _B, _B, _B, _B]),
+    "kzg_commit_cached": (_I, [_P, _U32, _B, _U64, _I, _B, _B]),
+    "kzg_open_cached": (_I, [_P, _U32, _B, _U64, _I, _B, _B, _B, _B]),
+    "kzg_row_cache_stats": (_I, [_P, ctypes.POINTER(_U64)]),
     "kzg_msm": (_I, [_P, _B, _U64, _U64, _B]),
     "kzg_ntt": (_I, [_P, _B, _U64, _I]),
     "kzg_eval": (_I, [_P, _B, _U64, _B, _B]),

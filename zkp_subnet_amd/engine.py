@@ -179,7 +179,8 @@ class HipEngine:
             eng._chk(eng._lib.kzg_staging_acquire(eng._h, 32 * max(self.n, 1), ctypes.byref(ptr), ctypes.byref(tok)))
             self.token = tok.value
             try:
-                got = codec._wire.decode_fr_list_into(poly, ptr.value, 32 * max(self.n, 1))
+                # one pass: base64 -> bytes in the pinned buffer + the 128-bit content tag of those bytes (row cache)
+                got, self.tag = codec._wire.decode_fr_list_into_tagged(poly, ptr.value, 32 * max(self.n, 1))
             except ValueError as e:
                 eng._lib.kzg_staging_release(eng._h, self.token)
                 raise codec.CodecError(str(e)) from e
@@ -198,14 +199,16 @@ class HipEngine:
 
     def commit_list(self, i: int, poly: Sequence[str], evaluation_form: bool = True) -> bytes:
         out = ctypes.create_string_buffer(48)
+        # tagged: the coefficient vector stays on the device for the worker_open that follows with the same row
+        # (the unchanged reference miner's two-call route, neurons/miner.py:56-61)
         with HipEngine._Staged(self, poly) as st:
-            self._chk(self._lib.kzg_commit(self._h, i, st.row, st.n, int(evaluation_form), out))
+            self._chk(self._lib.kzg_commit_cached(self._h, i, st.row, st.n, int(evaluation_form), st.tag, out))
         return out.raw
 
     def open_list(self, i: int, poly: Sequence[str], alpha_be32: bytes, evaluation_form: bool = True) -> Tuple[bytes, bytes]:
         ev, pf = ctypes.create_string_buffer(32), ctypes.create_string_buffer(48)
         with HipEngine._Staged(self, poly) as st:
-            self._chk(self._lib.kzg_open(self._h, i, st.row, st.n, int(evaluation_form), alpha_be32, ev, pf))
+            self._chk(self._lib.kzg_open_cached(self._h, i, st.row, st.n, int(evaluation_form), st.tag, alpha_be32, ev, pf))
         return ev.raw, pf.raw
 
     def commit_open_list(self, i: int, poly: Sequence[str], alpha_be32: bytes,
@@ -214,6 +217,12 @@ class HipEngine:
         with HipEngine._Staged(self, poly) as st:
             self._chk(self._lib.kzg_commit_open(self._h, i, st.row, st.n, int(evaluation_form), alpha_be32, c, ev, pf))
         return c.raw, ev.raw, pf.raw
+
+    def row_cache_stats(self) -> Tuple[int, int]:
+        """(hits, misses) of the coefficient cache behind commit_list / open_list."""
+        arr = (ctypes.c_uint64 * 2)()
+        self._chk(self._lib.kzg_row_cache_stats(self._h, arr))
+        return int(arr[0]), int(arr[1])
 
     def msm(self, scalars_be32: bytes, srs_offset: int = 0) -> bytes:
         out = ctypes.create_string_buffer(48)
