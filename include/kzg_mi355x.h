@@ -110,6 +110,11 @@ int kzg_msm(kzg_ctx* ctx, const uint8_t* scalars_be32, uint64_t n, uint64_t srs_
 int kzg_ntt(kzg_ctx* ctx, uint8_t* inout_be32, uint64_t n, int inverse);
 /* replaces Client.eval(poly, x)                     (reference neurons/validator.py:97-104) */
 int kzg_eval(kzg_ctx* ctx, const uint8_t* coeffs_be32, uint64_t n, const uint8_t x_be32[32], uint8_t out_be32[32]);
+/* both in one call: y = (NTT / inverse NTT of vals)(x) -- the validator's per-row challenge step
+ * eval(fft(poly[i], left=True, inverse=True), alpha) (reference neurons/validator.py:115-118) with the coefficient
+ * vector staying on the device */
+int kzg_ntt_eval(kzg_ctx* ctx, const uint8_t* vals_be32, uint64_t n, int inverse, const uint8_t x_be32[32],
+                 uint8_t out_y32[32]);
 
 /* ---- verification: replaces Client.worker_verify(i, proof, alpha, eval, commitment)
  *      (reference neurons/validator.py:77-86; tests/test_miner.py:101-111).  Host-side pairing check

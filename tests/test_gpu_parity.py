@@ -791,6 +791,26 @@ def test_client_and_miner_on_hip_engine(hip, fr_kat):
     assert reward(miner.client, ch, responses[0], 0, 15.0) == 0.5
     assert reward(miner.client, ch, responses[0], 1, 0.0) == 0.0
     assert responses[1].eval == ch.evals[1]
+    # the fused validator step (one call, coefficients stay on the device) == the reference's two calls; all rows of a
+    # step verified on a thread pool; random_poly / random_point come from the native generator, uniform below r
+    from zkp_subnet_amd.validator import verify_all
+
+    with miner.client.fft_eval(syn.poly, syn.alpha, left=True, inverse=True) as r:
+        assert r.status_code == 200 and r.json()["y"] == ev
+    ch4 = generate_challenge(miner.client, 4)
+    for i in range(4):
+        with miner.client.fft(ch4.polys[i], left=True, inverse=True) as r:
+            cf = r.json()["poly"]
+        with miner.client.eval(cf, ch4.alpha) as r:
+            assert r.json()["y"] == ch4.evals[i]
+    resp4 = [miner.forward(ch4.to_synapse(i)) for i in range(4)]
+    assert verify_all(miner.client, ch4, resp4, threads=4) == [True] * 4
+    resp4[2] = resp4[2].model_copy(update={"proof": resp4[1].proof})
+    assert verify_all(miner.client, ch4, resp4 + [None], threads=4)[:4] == [True, True, False, True]
+    with miner.client.random_poly() as r:
+        rp = r.json()["poly"]
+    assert len(rp) == 4 and all(len(row) == 16 for row in rp)
+    assert all(int.from_bytes(codec.fr_to_be32(s), "big") < o.R for row in rp for s in row)
     miner.stop()
 
 

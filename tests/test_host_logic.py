@@ -232,3 +232,40 @@ def test_aggregate_commitments_is_the_bivariate_commitment():
     assert c.aggregate_commitments(["AAAA"]).status_code == 400
     with c.aggregate_commitments([]) as r:
         assert base64.b64decode(r.json()["commitment"]) == b"\xc0" + bytes(47)
+
+
+def test_native_random_rows_and_fused_challenge_step_match_the_two_call_form():
+    """Validator side at scale (reference neurons/validator.py:58-120): random_poly comes from the native generator
+    (getrandom + rejection below r, text produced by the codec's thread pool), generate_challenge uses the fused
+    fft_eval step when the client has one -- same evals as the reference's fft-then-eval pair -- and verify_all agrees
+    with reward() row by row."""
+    from zkp_subnet_amd.validator import verify_all
+
+    assert codec._wire is not None
+    c = make_client(8, 2, seed=9)
+    with c.random_poly() as r:
+        rows = r.json()["poly"]
+    assert len(rows) == 4 and all(len(row) == 64 for row in rows)
+    vals = [int.from_bytes(codec.fr_to_be32(s), "big") for row in rows for s in row]
+    assert all(v < o.R for v in vals) and len(set(vals)) == len(vals) and max(vals).bit_length() >= 253
+    with c.random_point() as r:
+        assert int.from_bytes(codec.fr_to_be32(r.json()["point"]), "big") < o.R
+    big = codec._wire.random_fr_rows(3, 40000)                   # several generator batches and thread ranges
+    assert [len(x) for x in big] == [40000] * 3
+    raw = codec.fr_list_to_be32(big[2])
+    assert len({raw[i:i + 32] for i in range(0, len(raw), 32)}) == 40000
+    top = sorted(raw[i] for i in range(0, len(raw), 32))
+    assert top[0] == 0 and top[-1] == 0x73 and 50 < sum(top) / len(top) < 65      # uniform below r: top byte in [0, 0x73]
+    ch = generate_challenge(c, 4)                                # fused step
+    for i in range(4):
+        with c.fft(ch.polys[i], left=True, inverse=True) as r:
+            coeffs = r.json()["poly"]
+        with c.eval(coeffs, ch.alpha) as r:
+            assert r.json()["y"] == ch.evals[i]
+    assert c.fft_eval(ch.polys[0][:5], ch.alpha).status_code == 400       # wrong row length, as fft()
+    miner = Miner(default_config(scale=8, machines_scale=2), client=c)
+    responses = [miner.forward(ch.to_synapse(i)) for i in range(4)]
+    responses[3] = responses[3].model_copy(update={"commitment": responses[0].commitment})
+    got = verify_all(c, ch, responses, threads=3)
+    assert got == [True, True, True, False] == [reward(c, ch, responses[i], i, 0.0) > 0 for i in range(4)]
+    assert verify_all(c, ch, [None, responses[1]], threads=1) == [False, True]

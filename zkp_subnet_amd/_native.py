@@ -41,6 +41,7 @@ SYMBOLS = {
     "kzg_msm": (_I, [_P, _B, _U64, _U64, _B]),
     "kzg_ntt": (_I, [_P, _B, _U64, _I]),
     "kzg_eval": (_I, [_P, _B, _U64, _B, _B]),
+    "kzg_ntt_eval": (_I, [_P, _B, _U64, _I, _B, _B]),
     "kzg_vk_create": (_I, [_B, _B, _U32, ctypes.POINTER(_P)]),
     "kzg_vk_create_synthetic": (_I, [_B, _B, _U32, ctypes.POINTER(_P)]),
     "kzg_vk_destroy": (None, [_P]),

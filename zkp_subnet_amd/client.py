@@ -202,13 +202,35 @@ class Client:
         return {"y": codec.be32_to_fr(y)}
 
     @_guard
+    def fft_eval(self, poly: Sequence[str], x: str, left: bool = True, inverse: bool = True):
+        """Extension: eval(fft(poly, left, inverse), x) in ONE call -- the validator's per-row challenge step (reference
+        neurons/validator.py:115-118 makes the two calls; the 2^16 coefficients then cross the text codec twice)."""
+        n = len(poly)
+        want = 1 << (self.scale - self.machines_scale) if left else 1 << self.machines_scale
+        if self.scale and n != want:
+            raise codec.CodecError(f"fft(left={left}) expects {want} elements, got {n}")
+        fast = getattr(self.engine, "ntt_eval_list", None)
+        xb = codec.fr_to_be32(x)
+        if fast and codec._wire:
+            y = fast(poly, bool(inverse), xb)
+        else:
+            y = self.engine.eval(self.engine.ntt(codec.fr_list_to_be32(poly), bool(inverse)), xb)
+        return {"y": codec.be32_to_fr(y)}
+
+    @_guard
     def random_poly(self):
-        """Bivariate polynomial as 2^machines_scale rows of 2^(scale-machines_scale) Fr (neurons/validator.py:67-75)."""
+        """Bivariate polynomial as 2^machines_scale rows of 2^(scale-machines_scale) Fr (neurons/validator.py:67-75).
+        Uniform on [0, r): getrandom + rejection, generated and encoded natively (csrc/wire_py.c) -- 2^24 strings at
+        mainnet scale, which a Python loop needs ~40 s for, longer than the 30 s challenge deadline."""
         rows, T = 1 << self.machines_scale, 1 << (self.scale - self.machines_scale)
+        if codec._wire is not None:
+            return {"poly": codec._wire.random_fr_rows(rows, T)}
         return {"poly": [[codec.be32_to_fr(_random_fr()) for _ in range(T)] for _ in range(rows)]}
 
     @_guard
     def random_point(self):
+        if codec._wire is not None:
+            return {"point": codec._wire.random_fr_rows(1, 1)[0][0]}
         return {"point": codec.be32_to_fr(_random_fr())}
 
 

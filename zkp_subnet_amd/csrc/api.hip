@@ -1578,6 +1578,50 @@ int kzg_eval(kzg_ctx* ctx, const uint8_t* coeffs_be32, uint64_t n, const uint8_t
     return KZG_OK;
 }
 
+// y = (NTT or inverse NTT of vals)(x): the validator's per-row challenge step -- fft(poly[i], left=True, inverse=True) then
+// eval(coefficients, alpha) (reference neurons/validator.py:115-118) -- without the round trip of 2^16 coefficients through
+// text between the two
+int kzg_ntt_eval(kzg_ctx* ctx, const uint8_t* vals_be32, uint64_t n, int inverse, const uint8_t x_be32[32],
+                 uint8_t out_y32[32]) {
+    if (!ctx || !vals_be32 || !n || !x_be32 || !out_y32) return KZG_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int lg = ilog2_exact(n);
+    if (lg < 0) return fail(ctx, KZG_E_ARG, "NTT length must be a power of two");
+    LaneHold H(ctx);
+    if (int rc = H.take()) return rc;
+    Lane& L = H.L();
+    prof_begin(ctx, L);
+    int rc = clear_flags(ctx, L);
+    if (rc) return rc;
+    HIPCHK(ctx, L.coeffA.ensure(n * 32));
+    HIPCHK(ctx, L.coeffB.ensure(n * 32));
+    HIPCHK(ctx, L.ntt_mid.ensure(n * 48));
+    const uint64_t nchunks = (n + 3) / 4;
+    HIPCHK(ctx, L.hbuf.ensure((nchunks + (nchunks >> 1) + 64) * 32));
+    HIPCHK(ctx, L.hnext.ensure((nchunks + (nchunks >> 1) + 64) * 32));
+    rc = upload_fr(ctx, L, vals_be32, n, L.coeffA.as<uint32_t>(), 1);
+    if (rc) return rc;
+    const uint32_t* coeffs = L.coeffA.as<uint32_t>();
+    if (lg > 0) {
+        uint32_t *tw = nullptr, *invn = nullptr;
+        rc = ensure_twiddles(ctx, L, lg, inverse, &tw, inverse ? &invn : nullptr);
+        if (rc) return rc;
+        Span sp(ctx, L, KZG_T_NTT);
+        launch_fr_ntt(L.stream, L.coeffA.as<uint32_t>(), L.coeffB.as<uint32_t>(), lg, tw, inverse ? invn : nullptr,
+                      L.ntt_mid.as<uint32_t>());
+        coeffs = L.coeffB.as<uint32_t>();
+    }
+    uint32_t* x_m = reinterpret_cast<uint32_t*>(L.tail + TB_ALPHA_M);
+    uint32_t* y_m = reinterpret_cast<uint32_t*>(L.tail + TB_Y_M);
+    launch_poly_open(L.stream, coeffs, n, x_m, L.hbuf.as<uint32_t>(), L.hnext.as<uint32_t>(), y_m, nullptr, x_be32, L.flags(),
+                     L.tail + TB_EVAL);
+    rc = finish(ctx, L);
+    if (rc) return rc;
+    memcpy(out_y32, L.pin + TB_EVAL, 32);
+    H.clean = true;
+    return KZG_OK;
+}
+
 int kzg_upload_fr(kzg_ctx* ctx, int slot, const uint8_t* be32, uint64_t n, int to_mont) {
     if (!ctx || slot < 0 || slot >= N_SLOTS || (n && !be32)) return KZG_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));

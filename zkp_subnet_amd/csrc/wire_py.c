@@ -11,6 +11,7 @@
  *   decode_fr_list_into_tagged(seq, address, capacity[, threads]) -> (n, tag)   the same + a 128-bit content tag of the
  *                                                                  decoded bytes (kzg_commit_cached / kzg_open_cached)
  *   encode_fr_list(bytes[, threads]) -> list[str]
+ *   random_fr_rows(rows, T[, threads]) -> list[list[str]]   uniform field elements (getrandom + rejection), as text
  *
  * Host-side codec only: no field or curve arithmetic happens here. */
 #define PY_SSIZE_T_CLEAN
@@ -128,6 +129,7 @@ typedef struct {
     int bad_kind;   /* 1 = not a 43-char ASCII str, 2 = invalid base64 */
     int want_tag;
     uint64_t tag[2]; /* this range's share of the content tag */
+    int kind;        /* 0 = decode items[lo, hi) into dst; 1 = fill dst[43*lo, 43*hi) with random field elements as text */
 } dec_job;
 
 /* ---- content tag: identifies the decoded row for the prover's coefficient cache (the unchanged reference miner sends the
@@ -149,10 +151,15 @@ static inline void tag_add(uint64_t acc[2], uint64_t idx, const uint64_t w[4]) {
     acc[0] += mum64(w[0] ^ TAG_KEY[0] ^ i1, w[1] ^ TAG_KEY[1]) + mum64(w[2] ^ TAG_KEY[2], w[3] ^ TAG_KEY[3] ^ i2);
     acc[1] += mum64(w[0] ^ TAG_KEY[4] ^ i2, w[2] ^ TAG_KEY[5]) + mum64(w[1] ^ TAG_KEY[6], w[3] ^ TAG_KEY[7] ^ i1);
 }
+static void rand_worker(dec_job* j);
 static void* dec_worker(void* p) {
     dec_job* j = (dec_job*)p;
     j->bad = -1;
     j->bad_kind = 0;
+    if (j->kind == 1) {
+        rand_worker(j);
+        return NULL;
+    }
     j->tag[0] = j->tag[1] = 0;
     for (Py_ssize_t k = j->lo; k < j->hi; k++) {
         if (k + 12 < j->hi) { /* the str objects are scattered over the heap: without this, one cache miss each */
@@ -185,6 +192,42 @@ static void* dec_worker(void* p) {
         }
     }
     return NULL;
+}
+
+/* ---- uniform random field elements as wire text (the validator's challenge: Client.random_poly() is 2^machines_scale
+ * rows of 2^(scale - machines_scale) elements, reference neurons/validator.py:67-75 -- 2^24 strings at mainnet scale).
+ * 32 bytes from getrandom(2), top bit cleared (a 255-bit candidate), accepted when below r (probability 0.906): exactly
+ * uniform on [0, r).  Big-endian comparison against r's bytes. */
+static const uint8_t R_BE[32] = {0x73, 0xed, 0xa7, 0x53, 0x29, 0x9d, 0x7d, 0x48, 0x33, 0x39, 0xd8, 0x08, 0x09, 0xa1, 0xd8, 0x05,
+                                 0x53, 0xbd, 0xa4, 0x02, 0xff, 0xfe, 0x5b, 0xfe, 0xff, 0xff, 0xff, 0xff, 0x00, 0x00, 0x00, 0x01};
+static int fill_random(uint8_t* p, size_t n) {
+    while (n) {
+        ssize_t got = getrandom(p, n > (1u << 24) ? (1u << 24) : n, 0);
+        if (got <= 0) return -1;
+        p += got;
+        n -= (size_t)got;
+    }
+    return 0;
+}
+static void rand_worker(dec_job* j) {
+    uint8_t pool[32 * 512];
+    size_t have = 0, pos = 0;
+    for (Py_ssize_t k = j->lo; k < j->hi;) {
+        if (pos == have) {
+            if (fill_random(pool, sizeof(pool))) {
+                j->bad = k;
+                j->bad_kind = 3;
+                return;
+            }
+            have = 512;
+            pos = 0;
+        }
+        uint8_t* c = pool + 32 * pos++;
+        c[0] &= 0x7f;
+        if (memcmp(c, R_BE, 32) >= 0) continue;   /* >= r: draw again */
+        encode43(c, j->dst + 43 * k);
+        k++;
+    }
 }
 
 #define POOL_MAX 15
@@ -277,6 +320,51 @@ static void pool_run(dec_job* jobs, int n) {
     for (int t = 0; t < n; t++) dec_worker(&jobs[t]);
 }
 
+/* asynchronous form: pool_submit hands ALL jobs to the workers and returns (1), or returns 0 when no worker could be
+ * started (the caller then runs the jobs itself); pool_join helps with unclaimed jobs and waits for the rest.  One
+ * outstanding batch at a time (the GIL serialises callers). */
+static int pool_submit(dec_job* jobs, int n) {
+    pthread_mutex_lock(&pool.mu);
+    if (pool.pid != (long)getpid()) {
+        pool.nthreads = 0;
+        pool.pid = (long)getpid();
+    }
+    while (pool.nthreads < n && pool.nthreads < POOL_MAX) {
+        pthread_attr_t at;
+        pthread_attr_init(&at);
+        pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+        int rc = pthread_create(&pool.th[pool.nthreads], &at, pool_worker, NULL);
+        pthread_attr_destroy(&at);
+        if (rc) break;
+        pool.nthreads++;
+    }
+    if (pool.nthreads == 0) {
+        pthread_mutex_unlock(&pool.mu);
+        return 0;
+    }
+    pool.jobs = jobs;
+    pool.njobs = n;
+    pool.next = 0;
+    pool.finished = 0;
+    pool.generation++;
+    pthread_cond_broadcast(&pool.wake);
+    pthread_mutex_unlock(&pool.mu);
+    return 1;
+}
+static void pool_join(void) {
+    pthread_mutex_lock(&pool.mu);
+    while (pool.next < pool.njobs) {
+        dec_job* j = &pool.jobs[pool.next++];
+        pthread_mutex_unlock(&pool.mu);
+        dec_worker(j);
+        pthread_mutex_lock(&pool.mu);
+        pool.finished++;
+    }
+    while (pool.finished < pool.njobs) pthread_cond_wait(&pool.done, &pool.mu);
+    pool.njobs = 0;
+    pthread_mutex_unlock(&pool.mu);
+}
+
 /* Decodes the sequence into dst (n * 32 bytes).  Returns n, or -1 with a Python error set.  `cap` = room at dst in
  * bytes (0: dst is NULL and a bytes object is created: *out_bytes).  The GIL stays with the calling thread for the
  * whole call (~2 ns per element on 8 threads), which is what makes the lock-free reads above legal. */
@@ -306,6 +394,7 @@ static Py_ssize_t decode_core(PyObject* seq_in, long threads, uint8_t* dst, size
         jobs[t].lo = n * t / T;
         jobs[t].hi = n * (t + 1) / T;
         jobs[t].want_tag = out_tag != NULL;
+        jobs[t].kind = 0;
     }
     pool_run(jobs, T);
     if (out_tag) {
@@ -405,6 +494,80 @@ static PyObject* encode_fr_list(PyObject* self, PyObject* args) {
     return out;
 }
 
+/* random_fr_rows(rows, T[, threads]) -> list of `rows` lists of T 43-character strings.  The text of a batch of rows is
+ * produced by the thread pool (the calling thread keeps the GIL and takes part), then the str objects are created --
+ * that part needs the GIL and sets the pace (~50 ns per element). */
+static PyObject* random_fr_rows(PyObject* self, PyObject* args) {
+    Py_ssize_t rows, T;
+    long threads = 0;
+    if (!PyArg_ParseTuple(args, "nn|l", &rows, &T, &threads)) return NULL;
+    if (rows < 0 || T < 0 || (T && rows > ((Py_ssize_t)1 << 40) / T)) {
+        PyErr_SetString(PyExc_ValueError, "bad shape");
+        return NULL;
+    }
+    PyObject* out = PyList_New(rows);
+    if (!out) return NULL;
+    Py_ssize_t batch = T ? ((Py_ssize_t)1 << 19) / T : rows;      /* ~2^19 elements (22 MB of text) per buffer */
+    if (batch < 1) batch = 1;
+    const size_t buf_bytes = (size_t)43 * (size_t)(batch * T) + 64;
+    uint8_t* text[2] = {(uint8_t*)malloc(buf_bytes), (uint8_t*)malloc(buf_bytes)};
+    dec_job jobs[2][POOL_MAX + 1];
+    int njobs[2] = {0, 0}, async_[2] = {0, 0};
+    int failed = !text[0] || !text[1];
+    if (failed) PyErr_NoMemory();
+    /* batch b+1's text is generated by the pool while this thread (which must keep the GIL) creates batch b's str objects */
+    const Py_ssize_t nbatches = rows ? (rows + batch - 1) / batch : 0;
+    for (Py_ssize_t b = 0; b <= nbatches && !failed; b++) {
+        const int cur = (int)(b & 1), prev = cur ^ 1;
+        if (b < nbatches) {
+            const Py_ssize_t r0 = b * batch, nr = rows - r0 < batch ? rows - r0 : batch, n = nr * T;
+            const int TH = pick_threads(threads ? threads : 16, n);
+            for (int t = 0; t < TH; t++) {
+                jobs[cur][t].items = NULL;
+                jobs[cur][t].dst = text[cur];
+                jobs[cur][t].lo = n * t / TH;
+                jobs[cur][t].hi = n * (t + 1) / TH;
+                jobs[cur][t].want_tag = 0;
+                jobs[cur][t].kind = 1;
+            }
+            njobs[cur] = TH;
+            async_[cur] = pool_submit(jobs[cur], TH);
+            if (!async_[cur])
+                for (int t = 0; t < TH; t++) dec_worker(&jobs[cur][t]);
+        }
+        if (b > 0) {      /* materialise batch b-1 (its generation was joined at the end of the previous iteration) */
+            const Py_ssize_t r0 = (b - 1) * batch, nr = rows - r0 < batch ? rows - r0 : batch;
+            for (Py_ssize_t r = 0; r < nr && !failed; r++) {
+                PyObject* row = PyList_New(T);
+                if (!row) { failed = 1; break; }
+                PyList_SET_ITEM(out, r0 + r, row);
+                const uint8_t* src = text[prev] + (size_t)43 * (size_t)(r * T);
+                for (Py_ssize_t k = 0; k < T; k++) {
+                    PyObject* sobj = PyUnicode_New(43, 127);
+                    if (!sobj) { failed = 1; break; }
+                    memcpy(PyUnicode_1BYTE_DATA(sobj), src + 43 * k, 43);
+                    PyList_SET_ITEM(row, k, sobj);
+                }
+            }
+        }
+        if (b < nbatches) {
+            if (async_[cur]) pool_join();
+            for (int t = 0; t < njobs[cur]; t++)
+                if (jobs[cur][t].bad >= 0 && !failed) {
+                    failed = 1;
+                    PyErr_SetString(PyExc_OSError, "getrandom failed");
+                }
+        }
+    }
+    free(text[0]);
+    free(text[1]);
+    if (failed) {
+        Py_DECREF(out);     /* list deallocation tolerates the NULL slots of rows / elements never reached */
+        return NULL;
+    }
+    return out;
+}
+
 static PyObject* simd_level(PyObject* self, PyObject* args) { return PyLong_FromLong(have_avx2 ? 2 : 0); }
 /* set_simd(level) -> level in force: 0 forces the scalar decoder, 2 asks for AVX2 (granted only when the CPU has it).
  * For A/B runs and for the tests that compare the two decoders (and their content tags) inside one process. */
@@ -424,6 +587,7 @@ static PyMethodDef methods[] = {
     {"decode_fr_list_into", decode_fr_list_into, METH_VARARGS, "decode into a caller-owned buffer (address, capacity)"},
     {"decode_fr_list_into_tagged", decode_fr_list_into_tagged, METH_VARARGS,
      "decode into a caller-owned buffer -> (n, 16-byte keyed content tag of the decoded bytes)"},
+    {"random_fr_rows", random_fr_rows, METH_VARARGS, "rows x T uniform random Fr as 43-char base64 (getrandom + rejection)"},
     {"encode_fr_list", encode_fr_list, METH_VARARGS, "n*32 bytes big-endian -> list of 43-char base64 Fr"},
     {NULL, NULL, 0, NULL}};
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_wire", "Prove synapse text codec", -1, methods};

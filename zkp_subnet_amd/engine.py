@@ -259,6 +259,19 @@ class HipEngine:
         self._chk(self._lib.kzg_eval(self._h, coeffs_be32, len(coeffs_be32) // 32, x_be32, out))
         return out.raw
 
+    def ntt_eval(self, vals_be32: bytes, inverse: bool, x_be32: bytes) -> bytes:
+        """y = (NTT / inverse NTT of vals)(x) in one call: the coefficients never leave the device."""
+        out = ctypes.create_string_buffer(32)
+        self._chk(self._lib.kzg_ntt_eval(self._h, vals_be32, len(vals_be32) // 32, int(inverse), x_be32, out))
+        return out.raw
+
+    def ntt_eval_list(self, poly: Sequence[str], inverse: bool, x_be32: bytes) -> bytes:
+        """The same, fed from the wire text (decoded straight into a pinned staging buffer)."""
+        out = ctypes.create_string_buffer(32)
+        with HipEngine._Staged(self, poly) as st:
+            self._chk(self._lib.kzg_ntt_eval(self._h, st.row, st.n, int(inverse), x_be32, out))
+        return out.raw
+
     # ------------------------------------------------------------------ device-resident inputs
     def upload_fr(self, slot: int, be32: bytes, to_mont: bool) -> None:
         self._chk(self._lib.kzg_upload_fr(self._h, slot, be32, len(be32) // 32, int(to_mont)))

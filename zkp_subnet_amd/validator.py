@@ -4,7 +4,7 @@ neurons/validator.py:35-42,106-120,135-176): challenge generation (IFFT-then-eva
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Optional
+from typing import List, Optional, Sequence
 
 from .protocol import Prove
 
@@ -30,10 +30,34 @@ def generate_challenge(client, machines_count: int) -> Challenge:  # reference n
     poly = _ok(client.random_poly(), "poly", "generate a random polynomial")
     alpha = _ok(client.random_point(), "point", "generate a random x")
     evals = []
+    fused = getattr(client, "fft_eval", None)       # this package's Client: both steps in one call, nothing through text
     for i in range(machines_count):
+        if fused is not None:
+            evals.append(_ok(fused(poly[i], alpha, left=True, inverse=True), "y", "evaluate the polynomial"))
+            continue
         fft_coeffs = _ok(client.fft(poly[i], left=True, inverse=True), "poly", "fft")
         evals.append(_ok(client.eval(fft_coeffs, alpha), "y", "evaluate the polynomial"))
     return Challenge(polys=poly, alpha=alpha, evals=evals)
+
+
+def verify_all(client, challenge: Challenge, responses: Sequence[Optional[Prove]], threads: int = 16) -> List[bool]:
+    """worker_verify for every row of a step (reference neurons/validator.py:168-170 verifies inside reward(), one row
+    at a time: 256 pairing checks of ~7 ms each at mainnet scale).  The checks are independent host-side pairings and
+    ctypes releases the GIL, so a thread pool runs them on the validator's cores."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(i):
+        r = responses[i]
+        if r is None or r.commitment is None or r.proof is None:
+            return False
+        return bool(_ok(client.worker_verify(i, r.proof, challenge.alpha, challenge.evals[i], r.commitment), "valid",
+                        "verify the proof"))
+
+    n = len(responses)
+    if n <= 1 or threads <= 1:
+        return [one(i) for i in range(n)]
+    with ThreadPoolExecutor(max_workers=min(threads, n)) as ex:
+        return list(ex.map(one, range(n)))
 
 
 def reward(client, challenge: Challenge, response: Optional[Prove], index: int, process_time: Optional[float],
