@@ -1,0 +1,14 @@
+#!/bin/bash
+# Same-box A/B of ONE build under two settings of an environment knob (e.g. KZG_SERIAL_ACC=0 / 1) on the commit+open rows.
+#   gpurun -- 'KNOB=KZG_SERIAL_ACC VALUES="0 1" ROWS=22,20 bash scripts/ab_env.sh 3'
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+ROUNDS=${1:-2}
+for r in $(seq $ROUNDS); do
+  for v in ${VALUES:-0 1}; do
+    env ${KNOB}=$v python bench.py --no-adversarial --no-cpu-baseline --no-pipelined --steps 10 --kzg-rows ${ROWS:-22,20} 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('${KNOB}=$v msm20 %.3f ms |' % d['ms_per_step'], ' '.join('%s %.3f [p10 %.3f p90 %.3f]' % (k, v['ms'], v['p10'], v['p90']) for k, v in d['kzg_commit_open'].items()))
+"
+  done
+done

@@ -123,7 +123,7 @@ struct Lane {
     bool flags_clean = false;     // the tail record's flag words are zero (left so by the last request's publish)
     bool sort_ws_clean = false;   // the sort's partition counts are zero (left so by every completed sort)
     int skew_hint = 0;            // > 0: the last fast sort overflowed (skewed scalars): go straight to the exact sort
-    hipEvent_t ev_sorted = nullptr, ev_done = nullptr, ev_coeffs = nullptr, ev_ext = nullptr;
+    hipEvent_t ev_sorted = nullptr, ev_done = nullptr, ev_coeffs = nullptr, ev_ext = nullptr, ev_acc = nullptr;
     int state = LANE_FREE;
     bool partial = false;         // outstanding ticket wants the 192-byte partial
     // profiling spans of the call running on this lane
@@ -166,6 +166,7 @@ struct kzg_ctx {
     uint8_t* aux_pin = nullptr;
     int profiling = 0;   // 0 off, 1 every stage (calls serialise on lane 0), 2 the accumulate kernel only (no serialisation)
     bool host_finish = true;
+    bool serial_accumulate = true;   // two-lane commit+open: one accumulate at a time (KZG_SERIAL_ACC=0: concurrent, the A/B form)
     float tms[KZG_T_COUNT] = {0};  // stage times of the last completed hot-path call
     double load_stats[4] = {0, 0, 0, 0};   // kzg_get_load_stats
     // coefficient vectors of the last few rows, keyed by the caller's 128-bit content tag (kzg_commit_cached /
@@ -440,8 +441,13 @@ static bool poll_pinned(const kzg_ctx* ctx, const Lane& L, uint32_t off, uint32_
         else __builtin_ia32_pause();
     }
 }
+// acc_wait / acc_record: the accumulate kernel -- the one multiplier-bound kernel of the pipeline -- starts only after the
+// event acc_wait (another lane's accumulate) and records acc_record when it ends.  Two accumulates sharing the SIMDs run at
+// ~80 % of the multiplier rate each, one at a time at ~85 %; everything else (sorts, opening, folds, trees) is latency- or
+// LDS-bound and hides under the other lane's accumulate either way (commit_open_dev).
 int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t n, uint64_t srs_offset,
-             g1_xyzz_t* out_xyzz, const uint32_t* scalars2 = nullptr, int mont2 = 0) {
+             g1_xyzz_t* out_xyzz, const uint32_t* scalars2 = nullptr, int mont2 = 0, hipEvent_t acc_wait = nullptr,
+             hipEvent_t acc_record = nullptr) {
     hipStream_t s = L.stream;
     const int nbatch = scalars2 ? 2 : 1;
     if (n == 0) {
@@ -488,11 +494,13 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
                        reinterpret_cast<uint32_t*>(L.pin_dev + PIN_SEQ_SORT), ++L.sort_seq);
         HIPCHK(ctx, hipEventRecord(L.ev_sorted, s));
     }
+    if (acc_wait) HIPCHK(ctx, hipStreamWaitEvent(s, acc_wait, 0));
     {
         Span sp(ctx, L, KZG_T_ACCUMULATE);
         launch_msm_accumulate(s, sh, ctx->table.as<g1_affine_t>(), L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(),
                               L.bufA.as<g1_xyzz_t>(), L.carries.as<g1_xyzz_t>(), L.carry_key.as<uint32_t>(), nchunks);
     }
+    if (acc_record) HIPCHK(ctx, hipEventRecord(acc_record, s));
     // short rows: the tail's ~20 launches must be queued while the (short) accumulate runs -- poll for the two words
     // instead of sleeping on the event
     auto wait_sorted = [&]() -> hipError_t {
@@ -518,6 +526,7 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
             launch_msm_accumulate(s, sh, ctx->table.as<g1_affine_t>(), L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(),
                                   L.bufA.as<g1_xyzz_t>(), L.carries.as<g1_xyzz_t>(), L.carry_key.as<uint32_t>(), nchunks);
         }
+        if (acc_record) HIPCHK(ctx, hipEventRecord(acc_record, s));   // re-recorded: a later waiter sees this launch
         HIPCHK(ctx, wait_sorted());
     }
     {
@@ -709,8 +718,12 @@ int commit_open_dev(kzg_ctx* ctx, LaneHold& H, uint32_t i, const uint32_t* row_d
         HIPCHK(ctx, hipEventRecord(A.ev_coeffs, s));
         HIPCHK(ctx, hipStreamWaitEvent(so, A.ev_coeffs, 0));
     }
+    // two lanes: the opening's accumulate queues behind the commitment's (one multiplier-bound kernel at a time); the
+    // opening's evaluation / quotient / sort hide under the commitment's accumulate, the commitment's fold / tree / final
+    // under the opening's
+    const bool serial_acc = B && ctx->serial_accumulate;
     if (out_c48 && !batched) {
-        rc = msm_core(ctx, A, coeffs, 1, T, offset, res);
+        rc = msm_core(ctx, A, coeffs, 1, T, offset, res, nullptr, 0, nullptr, serial_acc ? A.ev_acc : nullptr);
         if (rc) return rc;
     }
     if (out_p48) {
@@ -731,7 +744,8 @@ int commit_open_dev(kzg_ctx* ctx, LaneHold& H, uint32_t i, const uint32_t* row_d
             // length-T scalar set
             rc = msm_core(ctx, A, coeffs, 1, T, offset, res, O.qbuf.as<uint32_t>(), 0);
         } else {
-            rc = msm_core(ctx, O, O.qbuf.as<uint32_t>(), 0, T - 1, offset, res + 1);
+            rc = msm_core(ctx, O, O.qbuf.as<uint32_t>(), 0, T - 1, offset, res + 1, nullptr, 0,
+                          (serial_acc && out_c48) ? A.ev_acc : nullptr, nullptr);
         }
         if (rc) return rc;
         if (B) {
@@ -985,6 +999,7 @@ int kzg_create(int device_id, kzg_ctx** out) {
         return fail(nullptr, KZG_E_HIP, "this library is built for gfx950 (MI355X) only");
     kzg_ctx* ctx = new kzg_ctx();
     ctx->device = device_id;
+    if (const char* e = getenv("KZG_SERIAL_ACC")) ctx->serial_accumulate = e[0] != '0';
     bool ok = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) == hipSuccess &&
               hipHostMalloc((void**)&ctx->aux_pin, 256, hipHostMallocDefault) == hipSuccess;
     for (int l = 0; ok && l < N_LANES; l++) {
@@ -1001,7 +1016,8 @@ int kzg_create(int device_id, kzg_ctx** out) {
              hipEventCreateWithFlags(&L.ev_sorted, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&L.ev_coeffs, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&L.ev_ext, hipEventDisableTiming) == hipSuccess;
+             hipEventCreateWithFlags(&L.ev_ext, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&L.ev_acc, hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) {
         kzg_destroy(ctx);
@@ -1020,7 +1036,7 @@ void kzg_destroy(kzg_ctx* ctx) {
                           &L.in_be, &L.scal, &L.coeffA, &L.coeffB, &L.qbuf, &L.hbuf, &L.hnext, &L.out_be, &L.ntt_mid, &L.gather})
             b->release();
         for (hipEvent_t e : L.ev_pool) (void)hipEventDestroy(e);
-        for (hipEvent_t e : {L.ev_sorted, L.ev_done, L.ev_coeffs, L.ev_ext})
+        for (hipEvent_t e : {L.ev_sorted, L.ev_done, L.ev_coeffs, L.ev_ext, L.ev_acc})
             if (e) (void)hipEventDestroy(e);
         if (L.tail) (void)hipFree(L.tail);
         if (L.pin) (void)hipHostFree(L.pin);

@@ -130,7 +130,7 @@ typedef struct {
     int want_tag;
     uint64_t tag[2]; /* this range's share of the content tag */
     int kind;        /* 0 = decode items[lo, hi) into dst; 1 = fill dst[43*lo, 43*hi) with random field elements as text */
-} dec_job;
+} __attribute__((aligned(64))) dec_job;
 
 /* ---- content tag: identifies the decoded row for the prover's coefficient cache (the unchanged reference miner sends the
  * same row in worker_commit and worker_open, neurons/miner.py:56-61).  tag = sum over elements of a keyed 128-bit hash
@@ -160,7 +160,9 @@ static void* dec_worker(void* p) {
         rand_worker(j);
         return NULL;
     }
-    j->tag[0] = j->tag[1] = 0;
+    /* accumulated in locals: the job records of different threads share cache lines (measured on the 16-core box: +25 ns
+     * per element of false sharing when every element's tag went straight into j->tag) */
+    uint64_t tag[2] = {0, 0};
     for (Py_ssize_t k = j->lo; k < j->hi; k++) {
         if (k + 12 < j->hi) { /* the str objects are scattered over the heap: without this, one cache miss each */
             __builtin_prefetch(j->items[k + 12]);
@@ -184,13 +186,15 @@ static void* dec_worker(void* p) {
                 if (decode43((const uint8_t*)PyUnicode_1BYTE_DATA(it), j->dst + 32 * k)) kind = 2;
                 memcpy(w, j->dst + 32 * k, 32);
             }
-            if (!kind) tag_add(j->tag, (uint64_t)k, w);
+            if (!kind) tag_add(tag, (uint64_t)k, w);
         }
         if (kind && j->bad < 0) {
             j->bad = k;
             j->bad_kind = kind;
         }
     }
+    j->tag[0] = tag[0];
+    j->tag[1] = tag[1];
     return NULL;
 }
 
