@@ -11,16 +11,24 @@
  * by (a) the reference's Fr known-answer vector tests/test_miner.py:33-55 and (b) bit-for-bit
  * agreement with the independent pure-Python oracle (oracle/bls12_381.py) on tests/golden/.
  *
- * Deliberately different from the GPU design: 64-bit limbs via unsigned __int128, Jacobian
- * coordinates, unsigned Pippenger windows, no precomputed tables.
+ * Deliberately different from the GPU design: 64-bit limbs via unsigned __int128 (6 for Fp, 4 for
+ * Fr), Booth-recoded signed windows chosen per call from a cost model, buckets in XYZZ
+ * coordinates filled by mixed additions, one bucket set per (window, point-chunk) task reduced
+ * by the classic running sum, windows combined by doublings; no sort, no precomputed tables.
+ * It is also the reported CPU baseline, so it is written the way a careful CPU implementation
+ * is (tasks over windows x chunks spread on a thread pool, threaded NTT), not as a toy.
  *
  * Byte conventions: Fr = 32 B big-endian canonical; G1 affine = x||y 2x48 B big-endian
  * (96 zero bytes = infinity); G1 compressed = 48 B ZCash encoding.
  */
 #include <pthread.h>
+#include <stdatomic.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#if defined(__x86_64__)
+#include <x86intrin.h>
+#endif
 
 typedef unsigned __int128 u128;
 typedef uint64_t u64;
@@ -68,7 +76,27 @@ static inline u64 limbs_sub(u64 *r, const u64 *a, const u64 *b, int n) {
 static inline int limbs_is_zero(const u64 *a, int n) {
     u64 t = 0; for (int i = 0; i < n; i++) t |= a[i]; return t == 0;
 }
-/* branch-free modular add / sub (inputs and outputs fully reduced) */
+/* modular add / sub (inputs and outputs fully reduced).  The carry chains go through the add-with-carry intrinsics where
+ * the compiler has them: the portable 128-bit form below costs ~8x as much with gcc and dominated a point addition. */
+#if defined(__x86_64__)
+#define ADC(c, a, b, out) _addcarry_u64((c), (a), (b), (unsigned long long *)(out))
+#define SBB(c, a, b, out) _subborrow_u64((c), (a), (b), (unsigned long long *)(out))
+static inline void mod_add(u64 *r, const u64 *a, const u64 *b, const u64 *m, int n) {
+    u64 s[NP], d[NP];
+    unsigned char c = 0, br = 0;
+    for (int i = 0; i < n; i++) c = ADC(c, a[i], b[i], &s[i]);
+    for (int i = 0; i < n; i++) br = SBB(br, s[i], m[i], &d[i]);
+    const int use_d = c | (br ^ 1);           /* carry out, or no borrow -> take s - m */
+    for (int i = 0; i < n; i++) r[i] = use_d ? d[i] : s[i];
+}
+static inline void mod_sub(u64 *r, const u64 *a, const u64 *b, const u64 *m, int n) {
+    u64 d[NP];
+    unsigned char br = 0, c = 0;
+    for (int i = 0; i < n; i++) br = SBB(br, a[i], b[i], &d[i]);
+    const u64 mask = (u64)0 - (u64)br;
+    for (int i = 0; i < n; i++) c = ADC(c, d[i], m[i] & mask, &r[i]);
+}
+#else
 static inline void mod_add(u64 *r, const u64 *a, const u64 *b, const u64 *m, int n) {
     u64 s[NP], d[NP];
     u64 c = limbs_add(s, a, b, n);
@@ -82,6 +110,7 @@ static inline void mod_sub(u64 *r, const u64 *a, const u64 *b, const u64 *m, int
     u128 c = 0;
     for (int i = 0; i < n; i++) { c += (u128)d[i] + (m[i] & mask); r[i] = (u64)c; c >>= 64; }
 }
+#endif
 /* CIOS Montgomery product; instantiated with a literal limb count so the loops fully unroll */
 #define DEFINE_MONT_MUL(NAME, N)                                                                   \
     static inline void NAME(u64 *r, const u64 *a, const u64 *b, const u64 *m, u64 inv) {          \
@@ -262,6 +291,65 @@ static void g1j_add(g1j *r, const g1j *p, const g1j *q) { /* add-2007-bl + speci
     fp_mul(&z3, &z3, &H);
     r->x = t; fp_sub(&r->y, &t2, &S1); r->z = z3;
 }
+/* ------------------------------------------------------------------ G1 buckets in XYZZ (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2) */
+typedef struct { fp x, y, zz, zzz; } g1x;   /* zz == 0 -> infinity */
+static void g1x_set_inf(g1x *p) { memset(p, 0, sizeof(*p)); }
+static inline int g1x_is_inf(const g1x *p) { return fp_is_zero(&p->zz); }
+static void g1x_double_affine(g1x *r, const fp *x, const fp *y) { /* mdbl-2008-s-1, a = 0 */
+    fp U, V, W, S, M, t;
+    fp_dbl(&U, y); fp_sqr(&V, &U); fp_mul(&W, &U, &V); fp_mul(&S, x, &V);
+    fp_sqr(&M, x); fp_dbl(&t, &M); fp_add(&M, &M, &t);
+    fp_sqr(&r->x, &M); fp_sub(&r->x, &r->x, &S); fp_sub(&r->x, &r->x, &S);
+    fp_sub(&t, &S, &r->x); fp_mul(&t, &M, &t);
+    fp_mul(&U, &W, y); fp_sub(&r->y, &t, &U);
+    r->zz = V; r->zzz = W;
+}
+/* r += q (neg: r -= q), q affine: madd-2008-s, 8M + 2S */
+static void g1x_madd(g1x *r, const g1a *q, int neg) {
+    if (q->inf) return;
+    fp qy = q->y;
+    if (neg) fp_neg(&qy, &q->y);
+    if (g1x_is_inf(r)) { r->x = q->x; r->y = qy; r->zz = FP_ONE; r->zzz = FP_ONE; return; }
+    fp U2, S2, P, R, PP, PPP, Q, t;
+    fp_mul(&U2, &q->x, &r->zz); fp_mul(&S2, &qy, &r->zzz);
+    fp_sub(&P, &U2, &r->x); fp_sub(&R, &S2, &r->y);
+    if (fp_is_zero(&P)) {
+        if (fp_is_zero(&R)) g1x_double_affine(r, &q->x, &qy); else g1x_set_inf(r);
+        return;
+    }
+    fp_sqr(&PP, &P); fp_mul(&PPP, &P, &PP); fp_mul(&Q, &r->x, &PP);
+    fp_sqr(&t, &R); fp_sub(&t, &t, &PPP); fp_sub(&t, &t, &Q); fp_sub(&t, &t, &Q);          /* X3 */
+    fp_sub(&Q, &Q, &t); fp_mul(&Q, &R, &Q); fp_mul(&S2, &r->y, &PPP); fp_sub(&r->y, &Q, &S2);
+    r->x = t;
+    fp_mul(&r->zz, &r->zz, &PP); fp_mul(&r->zzz, &r->zzz, &PPP);
+}
+static void g1x_to_jac(g1j *r, const g1x *p) { /* (X ZZ, Y ZZZ, ZZ): X ZZ / ZZ^2 = x, Y ZZZ / ZZ^3 = Y / ZZZ = y */
+    if (g1x_is_inf(p)) { g1j_set_inf(r); return; }
+    fp_mul(&r->x, &p->x, &p->zz); fp_mul(&r->y, &p->y, &p->zzz); r->z = p->zz;
+}
+/* r += q, both XYZZ: add-2008-s, 12M + 2S */
+static void g1x_add(g1x *r, const g1x *q) {
+    if (g1x_is_inf(q)) return;
+    if (g1x_is_inf(r)) { *r = *q; return; }
+    fp U1, U2, S1, S2, P, R, PP, PPP, Q, t;
+    fp_mul(&U1, &r->x, &q->zz); fp_mul(&U2, &q->x, &r->zz);
+    fp_mul(&S1, &r->y, &q->zzz); fp_mul(&S2, &q->y, &r->zzz);
+    fp_sub(&P, &U2, &U1); fp_sub(&R, &S2, &S1);
+    if (fp_is_zero(&P)) {
+        if (!fp_is_zero(&R)) { g1x_set_inf(r); return; }
+        g1j a, d; g1x_to_jac(&a, r); g1j_double(&d, &a);                 /* rare: equal points */
+        if (g1j_is_inf(&d)) { g1x_set_inf(r); return; }
+        fp z2; fp_sqr(&z2, &d.z); r->x = d.x; r->y = d.y; r->zz = z2; fp_mul(&r->zzz, &z2, &d.z);
+        return;
+    }
+    fp_sqr(&PP, &P); fp_mul(&PPP, &P, &PP); fp_mul(&Q, &U1, &PP);
+    fp_sqr(&t, &R); fp_sub(&t, &t, &PPP); fp_sub(&t, &t, &Q); fp_sub(&t, &t, &Q);
+    fp_sub(&Q, &Q, &t); fp_mul(&Q, &R, &Q); fp_mul(&S1, &S1, &PPP); fp_sub(&r->y, &Q, &S1);
+    r->x = t;
+    fp_mul(&t, &r->zz, &q->zz); fp_mul(&r->zz, &t, &PP);
+    fp_mul(&t, &r->zzz, &q->zzz); fp_mul(&r->zzz, &t, &PPP);
+}
+
 static void g1j_to_affine(g1a *r, const g1j *p) {
     if (g1j_is_inf(p)) { memset(r, 0, sizeof(*r)); r->inf = 1; return; }
     fp zi, zi2;
@@ -326,88 +414,186 @@ static void orc_init(void) {
     g_init = 1;
 }
 
-/* ------------------------------------------------------------------ NTT (radix-2 CT, natural order) */
-static void fr_ntt_inplace(fr *a, size_t n, int inverse) {
-    if (n <= 1) return;
-    int logn = 0; while (((size_t)1 << logn) < n) logn++;
-    for (size_t i = 0; i < n; i++) {
-        size_t j = 0;
-        for (int b = 0; b < logn; b++) if (i >> b & 1) j |= (size_t)1 << (logn - 1 - b);
-        if (i < j) { fr t = a[i]; a[i] = a[j]; a[j] = t; }
+/* ------------------------------------------------------------------ a tiny fork-join helper: fn(arg, t, nthreads) on t = 0..nthreads-1 */
+typedef struct { void (*fn)(void *, int, int); void *arg; int t, n; } fj_item;
+static void *fj_tramp(void *p) { fj_item *it = (fj_item *)p; it->fn(it->arg, it->t, it->n); return NULL; }
+static void fork_join(void (*fn)(void *, int, int), void *arg, int threads) {
+    if (threads <= 1) { fn(arg, 0, 1); return; }
+    fj_item *it = (fj_item *)calloc(threads, sizeof(fj_item));
+    pthread_t *th = (pthread_t *)calloc(threads, sizeof(pthread_t));
+    int started = 0;
+    for (int t = 1; t < threads; t++) {
+        it[t].fn = fn; it[t].arg = arg; it[t].t = t; it[t].n = threads;
+        if (pthread_create(&th[t], NULL, fj_tramp, &it[t])) break;
+        started = t;
     }
-    fr wn; fr_root_of_unity(&wn, logn);
-    if (inverse) fr_inv(&wn, &wn);
-    fr *tw = (fr *)malloc((n / 2) * sizeof(fr));
-    tw[0] = FR_ONE;
-    for (size_t k = 1; k < n / 2; k++) fr_mul(&tw[k], &tw[k - 1], &wn);
-    for (size_t len = 2; len <= n; len <<= 1) {
-        size_t half = len / 2, step = n / len;
-        for (size_t s = 0; s < n; s += len)
-            for (size_t k = 0; k < half; k++) {
-                fr u = a[s + k], v;
-                fr_mul(&v, &a[s + k + half], &tw[k * step]);
-                fr_add(&a[s + k], &u, &v); fr_sub(&a[s + k + half], &u, &v);
-            }
+    if (started + 1 < threads) {         /* could not start them all: run the missing shares here */
+        for (int t = started + 1; t < threads; t++) fn(arg, t, threads);
     }
-    free(tw);
-    if (inverse) {
-        fr ninv; fr_from_u64(&ninv, (u64)n); fr_inv(&ninv, &ninv);
-        for (size_t i = 0; i < n; i++) fr_mul(&a[i], &a[i], &ninv);
-    }
+    fn(arg, 0, threads);
+    for (int t = 1; t <= started; t++) pthread_join(th[t], NULL);
+    free(it); free(th);
 }
 
-/* ------------------------------------------------------------------ Pippenger */
-static int pick_window(size_t n) {
-    int c = 1; while (((size_t)1 << (c + 1)) < n) c++;   /* ~log2 n */
-    c = c > 4 ? c - 3 : 2;
-    if (c > 16) c = 16;
-    return c;
+/* ------------------------------------------------------------------ NTT (radix-2 CT, natural order), stages split over threads */
+typedef struct { fr *a; fr *tw; size_t n; int logn; fr wn; pthread_barrier_t bar; } ntt_ctx;
+static void ntt_share(void *arg, int t, int nt) {
+    ntt_ctx *c = (ntt_ctx *)arg;
+    const size_t n = c->n, half_n = n / 2;
+    /* twiddles w^k for this thread's range of k, started from w^lo by one exponentiation */
+    size_t lo = half_n * (size_t)t / nt, hi = half_n * (size_t)(t + 1) / nt;
+    if (lo < hi) {
+        u64 e[NR] = {lo, 0, 0, 0};
+        fr cur; fr_pow(&cur, &c->wn, e, NR);
+        for (size_t k = lo; k < hi; k++) { c->tw[k] = cur; fr_mul(&cur, &cur, &c->wn); }
+    }
+    /* bit reversal: the pair (i, j) is swapped by the thread owning the smaller index */
+    lo = n * (size_t)t / nt; hi = n * (size_t)(t + 1) / nt;
+    for (size_t i = lo; i < hi; i++) {
+        size_t j = 0;
+        for (int b = 0; b < c->logn; b++) if (i >> b & 1) j |= (size_t)1 << (c->logn - 1 - b);
+        if (i < j) { fr x = c->a[i]; c->a[i] = c->a[j]; c->a[j] = x; }
+    }
+    pthread_barrier_wait(&c->bar);
+    lo = half_n * (size_t)t / nt; hi = half_n * (size_t)(t + 1) / nt;
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const size_t half = len / 2, step = n / len;
+        for (size_t bf = lo; bf < hi; bf++) {            /* butterfly bf of this stage */
+            const size_t k = bf & (half - 1), s0 = (bf - k) * 2;
+            fr u = c->a[s0 + k], v;
+            fr_mul(&v, &c->a[s0 + k + half], &c->tw[k * step]);
+            fr_add(&c->a[s0 + k], &u, &v); fr_sub(&c->a[s0 + k + half], &u, &v);
+        }
+        pthread_barrier_wait(&c->bar);
+    }
 }
-static unsigned get_window(const u64 *s, int lo, int c) {
+typedef struct { fr *a; size_t n; fr f; } scale_ctx;
+static void scale_share(void *arg, int t, int nt) {
+    scale_ctx *c = (scale_ctx *)arg;
+    for (size_t i = c->n * (size_t)t / nt; i < c->n * (size_t)(t + 1) / nt; i++) fr_mul(&c->a[i], &c->a[i], &c->f);
+}
+static void fr_ntt_inplace_mt(fr *a, size_t n, int inverse, int threads) {
+    if (n <= 1) return;
+    int logn = 0; while (((size_t)1 << logn) < n) logn++;
+    if (threads < 1) threads = 1;
+    while (threads > 1 && (size_t)threads * 1024 > n) threads--;     /* at least ~1000 butterflies per thread and stage */
+    ntt_ctx c; c.a = a; c.n = n; c.logn = logn;
+    fr_root_of_unity(&c.wn, logn);
+    if (inverse) fr_inv(&c.wn, &c.wn);
+    c.tw = (fr *)malloc((n / 2) * sizeof(fr));
+    pthread_barrier_init(&c.bar, NULL, (unsigned)threads);
+    fork_join(ntt_share, &c, threads);
+    pthread_barrier_destroy(&c.bar);
+    free(c.tw);
+    if (inverse) {
+        scale_ctx sc; sc.a = a; sc.n = n;
+        fr_from_u64(&sc.f, (u64)n); fr_inv(&sc.f, &sc.f);
+        fork_join(scale_share, &sc, threads);
+    }
+}
+static void fr_ntt_inplace(fr *a, size_t n, int inverse) { fr_ntt_inplace_mt(a, n, inverse, 1); }
+
+/* ------------------------------------------------------------------ Pippenger
+ * Booth-recoded signed windows of c bits: digit d in [-2^(c-1), 2^(c-1)], |d| selects the bucket, the sign negates the
+ * point.  The work is cut into tasks (window w, chunk k of the points); a task fills its own 2^(c-1) XYZZ buckets with
+ * mixed additions and reduces them by the running sum  sum_b b B_b = sum_b (sum_{b' >= b} B_b').  c and the number of
+ * chunks come from a cost model (mixed additions n/K + 2^c bucket additions per task, ceil(tasks / threads) rounds), so
+ * that few threads use wide windows and many threads still find >= `threads` tasks of useful size -- the old scheme gave
+ * each thread a whole Pippenger on n/threads points and got SLOWER beyond 16 threads.  Window sums are added per window
+ * and combined by c doublings per window at the end. */
+static unsigned get_window(const u64 *s, int lo, int c) {   /* plain unsigned window (fixed-base table of orc_srs_gen) */
     int w = lo / 64, b = lo % 64;
     u64 v = s[w] >> b;
     if (b + c > 64 && w + 1 < NR) v |= s[w + 1] << (64 - b);
     return (unsigned)(v & (((u64)1 << c) - 1));
 }
-static void msm_serial(g1j *out, const g1a *pts, const u64 (*sc)[NR], size_t n) {
-    g1j total; g1j_set_inf(&total);
-    if (n == 0) { *out = total; return; }
-    int c = pick_window(n), nwin = (255 + c - 1) / c;
-    size_t nb = (size_t)1 << c;
-    g1j *buckets = (g1j *)malloc(nb * sizeof(g1j));
-    for (int w = nwin - 1; w >= 0; w--) {
-        for (int k = 0; k < c; k++) g1j_double(&total, &total);
-        for (size_t b = 0; b < nb; b++) g1j_set_inf(&buckets[b]);
-        for (size_t i = 0; i < n; i++) {
-            unsigned d = get_window(sc[i], w * c, c);
-            if (d) g1j_add_affine(&buckets[d], &buckets[d], &pts[i]);
+static int booth_digit(const u64 *s, int w, int c) {        /* bits [w c - 1, w c + c) of the scalar, bit -1 = 0 */
+    const int lo = w * c - 1;
+    u64 v;
+    if (lo < 0) v = s[0] << 1;
+    else {
+        const int q = lo / 64, b = lo % 64;
+        v = q < NR ? s[q] >> b : 0;
+        if (b + c + 1 > 64 && q + 1 < NR) v |= s[q + 1] << (64 - b);
+    }
+    v &= ((u64)1 << (c + 1)) - 1;
+    const int neg = (int)(v >> c) & 1;
+    int d = (int)((v + 1) >> 1);
+    return neg ? d - (1 << c) : d;                           /* = ((v + 1) >> 1) - 2^c * top_bit */
+}
+typedef struct {
+    const g1a *pts; const u64 (*sc)[NR]; size_t n;
+    int c, nwin, chunks;
+    g1j *partial;               /* [nwin][chunks] */
+    atomic_int next;
+} msm_plan;
+static void msm_task(const msm_plan *pl, int task, g1x *buckets) {
+    const int w = task / pl->chunks, k = task % pl->chunks, c = pl->c;
+    const size_t lo = pl->n * (size_t)k / pl->chunks, hi = pl->n * (size_t)(k + 1) / pl->chunks;
+    const size_t nb = (size_t)1 << (c - 1);
+    for (size_t b = 0; b <= nb; b++) g1x_set_inf(&buckets[b]);
+    enum { AHEAD = 6 };           /* the bucket of point i + AHEAD is requested while point i is added (768-KB+ bucket sets miss the L2) */
+    int dq[AHEAD];
+    for (size_t i = lo; i < hi && i < lo + AHEAD; i++) dq[i - lo] = booth_digit(pl->sc[i], w, c);
+    for (size_t i = lo; i < hi; i++) {
+        const int d = dq[(i - lo) % AHEAD];
+        if (i + AHEAD < hi) {
+            const int dn = booth_digit(pl->sc[i + AHEAD], w, c);
+            dq[(i - lo) % AHEAD] = dn;
+            __builtin_prefetch(&buckets[dn < 0 ? -dn : dn]);
+            __builtin_prefetch((const char *)&buckets[dn < 0 ? -dn : dn] + 64);
+            __builtin_prefetch((const char *)&buckets[dn < 0 ? -dn : dn] + 128);
         }
-        g1j run, acc; g1j_set_inf(&run); g1j_set_inf(&acc);
-        for (size_t b = nb - 1; b >= 1; b--) { g1j_add(&run, &run, &buckets[b]); g1j_add(&acc, &acc, &run); }
-        g1j_add(&total, &total, &acc);
+        if (d > 0) g1x_madd(&buckets[d], &pl->pts[i], 0);
+        else if (d < 0) g1x_madd(&buckets[-d], &pl->pts[i], 1);
+    }
+    g1x run, acc; g1x_set_inf(&run); g1x_set_inf(&acc);
+    for (size_t b = nb; b >= 1; b--) { g1x_add(&run, &buckets[b]); g1x_add(&acc, &run); }
+    g1x_to_jac(&pl->partial[task], &acc);
+}
+static void msm_worker(void *arg, int t, int nt) {
+    (void)t; (void)nt;
+    msm_plan *pl = (msm_plan *)arg;
+    g1x *buckets = (g1x *)malloc((((size_t)1 << (pl->c - 1)) + 1) * sizeof(g1x));
+    const int ntask = pl->nwin * pl->chunks;
+    for (;;) {
+        const int task = atomic_fetch_add(&pl->next, 1);
+        if (task >= ntask) break;
+        msm_task(pl, task, buckets);
     }
     free(buckets);
-    *out = total;
 }
-typedef struct { g1j out; const g1a *pts; const u64 (*sc)[NR]; size_t n; } msm_job;
-static void *msm_thread(void *arg) { msm_job *j = (msm_job *)arg; msm_serial(&j->out, j->pts, j->sc, j->n); return NULL; }
-static void msm_mt(g1j *out, const g1a *pts, const u64 (*sc)[NR], size_t n, int threads) {
-    if (threads < 1) threads = 1;
-    if ((size_t)threads > n) threads = n ? (int)n : 1;
-    if (threads == 1) { msm_serial(out, pts, sc, n); return; }
-    msm_job *jobs = (msm_job *)calloc(threads, sizeof(msm_job));
-    pthread_t *th = (pthread_t *)calloc(threads, sizeof(pthread_t));
-    size_t per = (n + threads - 1) / threads;
-    for (int t = 0; t < threads; t++) {
-        size_t lo = (size_t)t * per, hi = lo + per > n ? n : lo + per;
-        if (lo > n) lo = n;
-        jobs[t].pts = pts + lo; jobs[t].sc = sc + lo; jobs[t].n = hi - lo;
-        pthread_create(&th[t], NULL, msm_thread, &jobs[t]);
+static void msm_choose(size_t n, int threads, int *out_c, int *out_chunks) {
+    double best = -1; int bc = 2, bk = 1;
+    for (int c = 2; c <= 16; c++) {
+        const int nwin = (256 + c - 1) / c;
+        int k = (threads + nwin - 1) / nwin;                 /* enough tasks for every thread */
+        if (k < 1) k = 1;
+        if ((size_t)k > n) k = n ? (int)n : 1;
+        const double per_task = (double)n / k + 1.4 * 2.0 * (double)((size_t)1 << (c - 1));   /* full additions cost ~1.4 mixed */
+        const int rounds = (nwin * k + threads - 1) / threads;
+        const double cost = rounds * per_task;
+        if (best < 0 || cost < best) { best = cost; bc = c; bk = k; }
     }
-    g1j acc; g1j_set_inf(&acc);
-    for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); g1j_add(&acc, &acc, &jobs[t].out); }
-    free(jobs); free(th);
-    *out = acc;
+    *out_c = bc; *out_chunks = bk;
+}
+static void msm_mt(g1j *out, const g1a *pts, const u64 (*sc)[NR], size_t n, int threads) {
+    g1j total; g1j_set_inf(&total);
+    if (n == 0) { *out = total; return; }
+    if (threads < 1) threads = 1;
+    msm_plan pl; pl.pts = pts; pl.sc = sc; pl.n = n;
+    msm_choose(n, threads, &pl.c, &pl.chunks);
+    pl.nwin = (256 + pl.c - 1) / pl.c;
+    const int ntask = pl.nwin * pl.chunks;
+    pl.partial = (g1j *)malloc((size_t)ntask * sizeof(g1j));
+    atomic_init(&pl.next, 0);
+    fork_join(msm_worker, &pl, threads < ntask ? threads : ntask);
+    for (int w = pl.nwin - 1; w >= 0; w--) {
+        for (int k = 0; k < pl.c; k++) g1j_double(&total, &total);
+        for (int k = 0; k < pl.chunks; k++) g1j_add(&total, &total, &pl.partial[w * pl.chunks + k]);
+    }
+    free(pl.partial);
+    *out = total;
 }
 
 /* ------------------------------------------------------------------ exported C API (ctypes) */
@@ -544,10 +730,10 @@ int orc_msm_run(void *inst, int threads, uint8_t out48[48]) {
 }
 void orc_msm_free(void *inst) { orc_msm_inst *m = (orc_msm_inst *)inst; if (m) { free(m->pts); free(m->sc); free(m); } }
 
-static int load_coeffs(fr **out, const uint8_t *row, uint64_t T, int evaluation_form) {
+static int load_coeffs(fr **out, const uint8_t *row, uint64_t T, int evaluation_form, int threads) {
     fr *a = (fr *)malloc((T ? T : 1) * sizeof(fr));
     for (uint64_t i = 0; i < T; i++) if (fr_from_be(&a[i], row + 32 * i)) { free(a); return -2; }
-    if (evaluation_form) fr_ntt_inplace(a, T, 1);
+    if (evaluation_form) fr_ntt_inplace_mt(a, T, 1, threads);
     *out = a; return 0;
 }
 /* KZG worker commit: commitment = MSM(slice[0..T), IFFT(row)) */
@@ -555,7 +741,7 @@ int orc_commit(const uint8_t *slice_be96, const uint8_t *row_be32, uint64_t T, i
                uint8_t out48[48]) {
     orc_init();
     if (T == 0 || (T & (T - 1))) return -1;
-    fr *a; int rc = load_coeffs(&a, row_be32, T, evaluation_form); if (rc) return rc;
+    fr *a; int rc = load_coeffs(&a, row_be32, T, evaluation_form, threads); if (rc) return rc;
     g1a *pts = (g1a *)malloc(T * sizeof(g1a)); u64 (*sc)[NR] = (u64(*)[NR])malloc(T * sizeof(u64[NR]));
     for (uint64_t i = 0; i < T; i++) { g1a_from_be96(&pts[i], slice_be96 + 96 * i); fr_to_limbs(sc[i], &a[i]); }
     g1j r; msm_mt(&r, pts, (const u64(*)[NR])sc, T, threads);
@@ -569,7 +755,7 @@ int orc_open(const uint8_t *slice_be96, const uint8_t *row_be32, uint64_t T, int
     orc_init();
     if (T == 0 || (T & (T - 1))) return -1;
     fr alpha; if (fr_from_be(&alpha, alpha_be32)) return -2;
-    fr *a; int rc = load_coeffs(&a, row_be32, T, evaluation_form); if (rc) return rc;
+    fr *a; int rc = load_coeffs(&a, row_be32, T, evaluation_form, threads); if (rc) return rc;
     g1a *pts = (g1a *)malloc(T * sizeof(g1a)); u64 (*sc)[NR] = (u64(*)[NR])malloc(T * sizeof(u64[NR]));
     fr acc = a[T - 1];
     for (uint64_t j = T - 1; j >= 1; j--) {

@@ -166,7 +166,11 @@ struct kzg_ctx {
     uint8_t* aux_pin = nullptr;
     int profiling = 0;   // 0 off, 1 every stage (calls serialise on lane 0), 2 the accumulate kernel only (no serialisation)
     bool host_finish = true;
-    bool serial_accumulate = true;   // two-lane commit+open: one accumulate at a time (KZG_SERIAL_ACC=0: concurrent, the A/B form)
+    // two-lane commit+open: one accumulate at a time instead of two sharing the SIMDs.  Same-box A/B
+    // (profiles/r03_ab_serial_accumulate.log): 19.22 / 19.22 / 19.09 ms against 19.34 / 19.20 / 19.21 at 2^22, 5.37-5.40 either
+    // way at 2^20 -- no difference: what overlaps the accumulates (sort, opening, trees) is throughput-bound work on the
+    // same SIMDs, not idle latency.  Off by default; KZG_SERIAL_ACC=1 turns it on.
+    bool serial_accumulate = false;
     float tms[KZG_T_COUNT] = {0};  // stage times of the last completed hot-path call
     double load_stats[4] = {0, 0, 0, 0};   // kzg_get_load_stats
     // coefficient vectors of the last few rows, keyed by the caller's 128-bit content tag (kzg_commit_cached /
@@ -718,9 +722,7 @@ int commit_open_dev(kzg_ctx* ctx, LaneHold& H, uint32_t i, const uint32_t* row_d
         HIPCHK(ctx, hipEventRecord(A.ev_coeffs, s));
         HIPCHK(ctx, hipStreamWaitEvent(so, A.ev_coeffs, 0));
     }
-    // two lanes: the opening's accumulate queues behind the commitment's (one multiplier-bound kernel at a time); the
-    // opening's evaluation / quotient / sort hide under the commitment's accumulate, the commitment's fold / tree / final
-    // under the opening's
+    // two lanes.  Optionally (KZG_SERIAL_ACC=1) the opening's accumulate queues behind the commitment's -- measured: no gain
     const bool serial_acc = B && ctx->serial_accumulate;
     if (out_c48 && !batched) {
         rc = msm_core(ctx, A, coeffs, 1, T, offset, res, nullptr, 0, nullptr, serial_acc ? A.ev_acc : nullptr);

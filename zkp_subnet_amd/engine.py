@@ -169,7 +169,7 @@ class HipEngine:
         """One pinned staging buffer of the library's pool holding the decoded polynomial; released on exit.  Concurrent
         requests (the axon's worker threads) each hold their own buffer, so their decodes and GPU calls overlap."""
 
-        def __init__(self, eng: "HipEngine", poly: Sequence[str]):
+        def __init__(self, eng: "HipEngine", poly: Sequence[str], tagged: bool = False):
             from . import codec
 
             if codec._wire is None:
@@ -179,8 +179,10 @@ class HipEngine:
             eng._chk(eng._lib.kzg_staging_acquire(eng._h, 32 * max(self.n, 1), ctypes.byref(ptr), ctypes.byref(tok)))
             self.token = tok.value
             try:
-                # one pass: base64 -> bytes in the pinned buffer + the 128-bit content tag of those bytes (row cache)
-                got, self.tag = codec._wire.decode_fr_list_into_tagged(poly, ptr.value, 32 * max(self.n, 1))
+                if tagged:   # one pass: base64 -> bytes in the pinned buffer + the 128-bit content tag of those bytes
+                    got, self.tag = codec._wire.decode_fr_list_into_tagged(poly, ptr.value, 32 * max(self.n, 1))
+                else:        # fused / one-shot calls have no use for the tag (it costs ~0.7 ns per element and thread)
+                    got, self.tag = codec._wire.decode_fr_list_into(poly, ptr.value, 32 * max(self.n, 1)), None
             except ValueError as e:
                 eng._lib.kzg_staging_release(eng._h, self.token)
                 raise codec.CodecError(str(e)) from e
@@ -201,13 +203,13 @@ class HipEngine:
         out = ctypes.create_string_buffer(48)
         # tagged: the coefficient vector stays on the device for the worker_open that follows with the same row
         # (the unchanged reference miner's two-call route, neurons/miner.py:56-61)
-        with HipEngine._Staged(self, poly) as st:
+        with HipEngine._Staged(self, poly, tagged=True) as st:
             self._chk(self._lib.kzg_commit_cached(self._h, i, st.row, st.n, int(evaluation_form), st.tag, out))
         return out.raw
 
     def open_list(self, i: int, poly: Sequence[str], alpha_be32: bytes, evaluation_form: bool = True) -> Tuple[bytes, bytes]:
         ev, pf = ctypes.create_string_buffer(32), ctypes.create_string_buffer(48)
-        with HipEngine._Staged(self, poly) as st:
+        with HipEngine._Staged(self, poly, tagged=True) as st:
             self._chk(self._lib.kzg_open_cached(self._h, i, st.row, st.n, int(evaluation_form), st.tag, alpha_be32, ev, pf))
         return ev.raw, pf.raw
 
