@@ -8,7 +8,7 @@ for r in $(seq $ROUNDS); do
     env ${KNOB}=$v python bench.py --no-adversarial --no-cpu-baseline --no-pipelined --steps 10 --kzg-rows ${ROWS:-22,20} 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print('${KNOB}=$v msm20 %.3f ms |' % d['ms_per_step'], ' '.join('%s %.3f [p10 %.3f p90 %.3f]' % (k, v['ms'], v['p10'], v['p90']) for k, v in d['kzg_commit_open'].items()))
+print('${KNOB}=$v msm20 %.3f ms |' % d['ms_per_step'], ' '.join('%s %.3f [p10 %.3f p90 %.3f ntt %.4f poly %.4f]' % (k, v['ms'], v['p10'], v['p90'], v['stages_ms_profiled_serial']['ntt'], v['stages_ms_profiled_serial']['poly']) for k, v in d['kzg_commit_open'].items()))
 "
   done
 done

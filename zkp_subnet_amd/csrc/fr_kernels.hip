@@ -3,6 +3,7 @@
 // Replaces what the external prover does behind fft(poly,left,inverse) / eval / the implicit IFFT + synthetic
 // division of worker_commit / worker_open (reference neurons/validator.py:59-65,98-104; neurons/miner.py:39,48).
 // Domain convention: w_n = 7^((r-1)/n), natural order in and out, inverse carries 1/n.
+#include <cstdlib>
 #include <cstring>
 
 #include "fr_kernels.hip.h"
@@ -291,6 +292,181 @@ __global__ void __launch_bounds__(NT_) k_fr_ntt_pass(const uint32_t* __restrict_
     }
 }
 
+// ---- the register-blocked form: TWO stages per LDS round trip.  A lane takes the four elements i, i+h, i+2h, i+3h
+// (h = 2^l) through stage l -- (x0, x1) and (x2, x3), both with twiddle A = w^(k) of that stage -- and stage l+1 --
+// (y0, y2) with B0 and (y1, y3) with B1 -- without leaving its registers: 8 LDS reads + 8 writes of a limb per butterfly
+// pair instead of 16 + 16 (the radix-2 kernel moved 36 LDS words per butterfly, this one 18), half the barriers, one index
+// computation per four butterflies.  The multiplication count is that of radix 2 (a prime field has no cheap w_4): A, B0
+// and B1 are three loads from the same table -- with table index t for A, B0 sits at t/2 and B1 at t/2 + n/4.  Tiles hold 2048
+// elements (72 KB of LDS, 512 lanes, two workgroups per CU): up to 9 stages x >= 4 columns, i.e. rows of >= 192 contiguous
+// bytes in HBM (an 11 + 11 split of 2^22 would need single-element rows: 48-byte gathers at a 98-KB stride).  Lazy bounds: inputs normalised (limbs < 2^29); after stage l limbs < 2^29 + 2^30, still a legal
+// first operand of the product; after stage l+1 limbs < 2^29 + 2^31 fit a word and are normalised before they go back to
+// LDS; values grow <= 4r per stage, < 2r + 36r over the 9 stages of a pass (< 64r).  An odd stage count starts with one radix-2 stage.
+#define NTT4_PASS_LOG 9      // stages per pass: 2^9 rows x >= 4 columns, so that a tile row is >= 192 contiguous bytes of HBM
+#define NTT4_TILE_ELEMS 2048
+struct NttTile4 {
+    uint32_t l[9][NTT4_TILE_ELEMS];
+};
+KZG_DEV void tile4_get(fr9_t& v, const NttTile4& sm, uint32_t e) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) v.l[i] = sm.l[i][e];
+}
+KZG_DEV void tile4_put(NttTile4& sm, uint32_t e, const fr9_t& v) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) sm.l[i][e] = v.l[i];
+}
+KZG_DEV void bfly(fr9_t& u, fr9_t& v, const fr9_t& w) {     // (u, v) <- (u + v w, u + 4r - v w), lazy
+    fr9_t t;
+    fr9_mul(t, v, w);
+    fr9_sub4(v, u, t);
+    fr9_add(u, u, t);
+}
+template <uint32_t NT_, bool LAST>
+__global__ void __launch_bounds__(NT_) k_fr_ntt_pass4(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                       uint32_t* __restrict__ mid, int log_n, int s0, int S, int logC,
+                                                       const uint32_t* __restrict__ tw,
+                                                       const uint32_t* __restrict__ scale_or_null) {
+    __shared__ NttTile4 sm;
+    const uint32_t R = 1u << S, C = 1u << logC, E = R << logC;
+    const bool first = s0 == 0;
+    const uint64_t n = (uint64_t)1 << log_n;
+    const int log_nt = log_n - S;
+    // ---- load (as k_fr_ntt_pass: bit reversal folded into the first pass, 48-byte slots between passes)
+    uint64_t base = 0, col0 = 0;
+    if (first) {
+        const uint64_t NT = (uint64_t)1 << log_nt;
+        const uint64_t u = blockIdx.x;
+        for (uint32_t e = threadIdx.x; e < E; e += NT_) {
+            const uint32_t rp = e >> logC, c = e & (C - 1);
+            fr9_t v;
+            fr9_load(v, in + 8 * ((uint64_t)rp * NT + u * C + c));
+            tile4_put(sm, (c << S) + brev_bits(rp, S), v);    // LDS layout [tile][row]
+        }
+    } else {
+        const uint64_t groups = ((uint64_t)1 << s0) >> logC;
+        const uint64_t h = blockIdx.x / groups, cg = blockIdx.x - h * groups;
+        base = (h << (s0 + S)) + (cg << logC);
+        col0 = cg << logC;
+        for (uint32_t e = threadIdx.x; e < E; e += NT_) {
+            const uint32_t r = e >> logC, c = e & (C - 1);
+            fr9_t v;
+            mid_get(v, mid, n, base + ((uint64_t)r << s0) + c);
+            tile4_put(sm, e, v);                              // LDS layout [row][column]
+        }
+    }
+    __syncthreads();
+    int l = 0;
+    if (S & 1) {      // one radix-2 stage first
+        const int s = s0;
+        for (uint32_t b = threadIdx.x; b < E / 2; b += NT_) {
+            uint32_t ei, ej;
+            uint64_t k;
+            if (first) {
+                const uint32_t c = b >> (S - 1), bb = b & ((R >> 1) - 1);
+                ei = (c << S) + (bb << 1);
+                ej = ei + 1;
+                k = 0;
+            } else {
+                const uint32_t c = b & (C - 1), bb = b >> logC;
+                ei = ((bb << 1) << logC) + c;
+                ej = ei + C;
+                k = col0 + c;
+            }
+            fr9_t u, v, w;
+            tile4_get(u, sm, ei);
+            tile4_get(v, sm, ej);
+            limbs12_get(w, tw, k << (log_n - s - 1));
+            bfly(u, v, w);
+            fr9_norm(u, u);
+            fr9_norm(v, v);
+            tile4_put(sm, ei, u);
+            tile4_put(sm, ej, v);
+        }
+        __syncthreads();
+        l = 1;
+    }
+    for (; l < S; l += 2) {
+        const uint32_t half = 1u << l;
+        const int s = s0 + l;
+        for (uint32_t b = threadIdx.x; b < E / 4; b += NT_) {
+            uint32_t e0, st;
+            uint64_t k;
+            if (first) {
+                const uint32_t c = b >> (S - 2), bb = b & ((R >> 2) - 1);
+                const uint32_t kk = bb & (half - 1);
+                e0 = (c << S) + ((bb >> l) << (l + 2)) + kk;
+                st = half;
+                k = kk;
+            } else {
+                const uint32_t c = b & (C - 1), bb = b >> logC;
+                const uint32_t kk = bb & (half - 1);
+                e0 = ((((bb >> l) << (l + 2)) + kk) << logC) + c;
+                st = half << logC;
+                k = ((uint64_t)kk << s0) + col0 + c;
+            }
+            const uint64_t ia = k << (log_n - s - 1), ib = ia >> 1;
+            fr9_t x0, x1, x2, x3, w;
+            tile4_get(x1, sm, e0 + st);
+            tile4_get(x3, sm, e0 + 3 * st);
+            limbs12_get(w, tw, ia);
+            tile4_get(x0, sm, e0);
+            tile4_get(x2, sm, e0 + 2 * st);
+            bfly(x0, x1, w);                 // stage l
+            bfly(x2, x3, w);
+            limbs12_get(w, tw, ib);
+            bfly(x0, x2, w);                 // stage l + 1
+            limbs12_get(w, tw, ib + (n >> 2));
+            bfly(x1, x3, w);
+            fr9_norm(x0, x0);
+            fr9_norm(x1, x1);
+            fr9_norm(x2, x2);
+            fr9_norm(x3, x3);
+            tile4_put(sm, e0, x0);
+            tile4_put(sm, e0 + st, x1);
+            tile4_put(sm, e0 + 2 * st, x2);
+            tile4_put(sm, e0 + 3 * st, x3);
+        }
+        __syncthreads();
+    }
+    // ---- store
+    fr9_t f;
+    fr9_zero(f);
+    if constexpr (LAST) {
+        if (scale_or_null) fr9_load(f, scale_or_null);
+    }
+    if (first) {
+        const uint32_t u = blockIdx.x;
+        const uint64_t tiles_per_c = ((uint64_t)1 << log_nt) >> logC;
+        const uint64_t t_low = brev_bits(u, log_nt - logC);
+        for (uint32_t e = threadIdx.x; e < E; e += NT_) {
+            const uint32_t c = e >> S, r = e & (R - 1);
+            const uint64_t t = (uint64_t)brev_bits(c, logC) * tiles_per_c + t_low;
+            fr9_t v;
+            tile4_get(v, sm, e);
+            if constexpr (LAST) {
+                if (scale_or_null) { fr9_mul(v, v, f); fr9_canon(v, v); }
+                else fr9_reduce(v, v);
+                fr9_store(out + 8 * ((t << S) + r), v);
+            } else {
+                mid_put(mid, n, (t << S) + r, v);
+            }
+        }
+    } else {
+        for (uint32_t e = threadIdx.x; e < E; e += NT_) {
+            const uint32_t r = e >> logC, c = e & (C - 1);
+            fr9_t v;
+            tile4_get(v, sm, e);
+            if constexpr (LAST) {
+                if (scale_or_null) { fr9_mul(v, v, f); fr9_canon(v, v); }
+                else fr9_reduce(v, v);
+                fr9_store(out + 8 * (base + ((uint64_t)r << s0) + c), v);
+            } else {
+                mid_put(mid, n, base + ((uint64_t)r << s0) + c, v);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ eval + quotient
 // Chunk length L = 2^lchunk coefficients per lane: 16 for large polynomials, down to 4 for small rows: the chunk loops
 // are chains of dependent Fr products, so short chunks + more levels beat long ones.  Inside a chain the running value
@@ -491,13 +667,9 @@ void launch_fr_twiddles(hipStream_t s, uint32_t* tw, int log_n, int inverse) {
     k_fr_twiddles<<<nblk((half + 63) / 64, 256), 256, 0, s>>>(tw, log_n, inverse);
 }
 void launch_fr_inv_pow2(hipStream_t s, uint32_t* out, int log_n) { k_fr_inv_pow2<<<1, 64, 0, s>>>(out, log_n); }
-void launch_fr_ntt(hipStream_t s, const uint32_t* in, uint32_t* out, int log_n, const uint32_t* tw,
-                   const uint32_t* scale_or_null, uint32_t* mid) {
+static void launch_fr_ntt_radix2(hipStream_t s, const uint32_t* in, uint32_t* out, int log_n, const uint32_t* tw,
+                                 const uint32_t* scale_or_null, uint32_t* mid) {
     const uint64_t n = (uint64_t)1 << log_n;
-    if (log_n == 0) {  // length 1: the transform is the identity (1/1 = 1)
-        (void)hipMemcpyAsync(out, in, 32, hipMemcpyDeviceToDevice, s);
-        return;
-    }
     // split log_n into ceil(log_n / 8) passes of near-equal depth (22 -> 8 + 7 + 7)
     const int passes = (log_n + NTT_PASS_LOG - 1) / NTT_PASS_LOG;
     int s0 = 0;
@@ -510,14 +682,55 @@ void launch_fr_ntt(hipStream_t s, const uint32_t* in, uint32_t* out, int log_n, 
         if (p == 0 && logC > 2) logC = 2;  // first pass: 4 tiles (128 B source rows) keep the tiles' stores long
         const uint32_t blocks = (uint32_t)(n >> (S + logC));
         const bool last = p == passes - 1;
-        // one butterfly per thread and stage when the tile allows it (512 threads for a full 1024-element tile): a stage
-        // is then ONE dependent Fr product deep instead of two -- what counts for short rows (2^16: two passes on 64
-        // workgroups, pure latency) -- and long rows just run more waves per CU
         const bool big = (1u << (S + logC)) >= 1024;
         if (big && last) k_fr_ntt_pass<512, true><<<blocks, 512, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, scale_or_null);
         else if (big) k_fr_ntt_pass<512, false><<<blocks, 512, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, nullptr);
         else if (last) k_fr_ntt_pass<256, true><<<blocks, 256, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, scale_or_null);
         else k_fr_ntt_pass<256, false><<<blocks, 256, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, nullptr);
+        s0 += S;
+    }
+}
+// KZG_NTT_RADIX2=1 selects the round-2 kernel (one stage per LDS round trip, 1024-element tiles) for same-box A/B runs
+static int ntt_use_radix2() {
+    static const int v = [] {
+        const char* e = getenv("KZG_NTT_RADIX2");
+        return (e && e[0] == '1') ? 1 : 0;
+    }();
+    return v;
+}
+void launch_fr_ntt(hipStream_t s, const uint32_t* in, uint32_t* out, int log_n, const uint32_t* tw,
+                   const uint32_t* scale_or_null, uint32_t* mid) {
+    const uint64_t n = (uint64_t)1 << log_n;
+    if (log_n == 0) {  // length 1: the transform is the identity (1/1 = 1)
+        (void)hipMemcpyAsync(out, in, 32, hipMemcpyDeviceToDevice, s);
+        return;
+    }
+    if (ntt_use_radix2()) {
+        launch_fr_ntt_radix2(s, in, out, log_n, tw, scale_or_null, mid);
+        return;
+    }
+    // ceil(log_n / 9) passes of near-equal depth (22 -> 8 + 7 + 7, 18 -> 9 + 9, 16 -> 8 + 8, 12 -> 6 + 6, <= 9 -> one pass)
+    const int passes = (log_n + NTT4_PASS_LOG - 1) / NTT4_PASS_LOG;
+    int s0 = 0;
+    for (int p = 0; p < passes; p++) {
+        const int S = (log_n - s0 + (passes - p) - 1) / (passes - p);
+        int logC = 11 - S;
+        const int avail = p == 0 ? log_n - S : s0;
+        if (logC > avail) logC = avail;
+        if (p == 0 && logC > 2) logC = 2;  // first pass: 4 tiles (128 B source rows) keep the tiles' stores long
+        const uint32_t blocks = (uint32_t)(n >> (S + logC));
+        const bool last = p == passes - 1;
+        const uint32_t quads = (1u << (S + logC)) >> 2;     // one lane per four elements when the tile allows it
+        if (quads >= 512) {
+            if (last) k_fr_ntt_pass4<512, true><<<blocks, 512, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, scale_or_null);
+            else k_fr_ntt_pass4<512, false><<<blocks, 512, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, nullptr);
+        } else if (quads >= 256) {
+            if (last) k_fr_ntt_pass4<256, true><<<blocks, 256, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, scale_or_null);
+            else k_fr_ntt_pass4<256, false><<<blocks, 256, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, nullptr);
+        } else {
+            if (last) k_fr_ntt_pass4<64, true><<<blocks, 64, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, scale_or_null);
+            else k_fr_ntt_pass4<64, false><<<blocks, 64, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, nullptr);
+        }
         s0 += S;
     }
 }
