@@ -304,14 +304,17 @@ __global__ void __launch_bounds__(NT_) k_fr_ntt_pass(const uint32_t* __restrict_
 // LDS; values grow <= 4r per stage, < 2r + 36r over the 9 stages of a pass (< 64r).  An odd stage count starts with one radix-2 stage.
 #define NTT4_PASS_LOG 9      // stages per pass: 2^9 rows x >= 4 columns, so that a tile row is >= 192 contiguous bytes of HBM
 #define NTT4_TILE_ELEMS 2048
-struct NttTile4 {
-    uint32_t l[9][NTT4_TILE_ELEMS];
+template <uint32_t ELEMS>
+struct NttTile4 {            // four elements per lane: a 64-lane workgroup stages 256 elements (9 KB), a 512-lane one 2048 (72 KB)
+    uint32_t l[9][ELEMS];
 };
-KZG_DEV void tile4_get(fr9_t& v, const NttTile4& sm, uint32_t e) {
+template <class TILE>
+KZG_DEV void tile4_get(fr9_t& v, const TILE& sm, uint32_t e) {
 #pragma unroll
     for (int i = 0; i < 9; i++) v.l[i] = sm.l[i][e];
 }
-KZG_DEV void tile4_put(NttTile4& sm, uint32_t e, const fr9_t& v) {
+template <class TILE>
+KZG_DEV void tile4_put(TILE& sm, uint32_t e, const fr9_t& v) {
 #pragma unroll
     for (int i = 0; i < 9; i++) sm.l[i][e] = v.l[i];
 }
@@ -326,7 +329,7 @@ __global__ void __launch_bounds__(NT_) k_fr_ntt_pass4(const uint32_t* __restrict
                                                        uint32_t* __restrict__ mid, int log_n, int s0, int S, int logC,
                                                        const uint32_t* __restrict__ tw,
                                                        const uint32_t* __restrict__ scale_or_null) {
-    __shared__ NttTile4 sm;
+    __shared__ NttTile4<4 * NT_> sm;     // the launcher never gives a workgroup more than 4 elements per lane
     const uint32_t R = 1u << S, C = 1u << logC, E = R << logC;
     const bool first = s0 == 0;
     const uint64_t n = (uint64_t)1 << log_n;
@@ -405,18 +408,20 @@ __global__ void __launch_bounds__(NT_) k_fr_ntt_pass4(const uint32_t* __restrict
                 k = ((uint64_t)kk << s0) + col0 + c;
             }
             const uint64_t ia = k << (log_n - s - 1), ib = ia >> 1;
-            fr9_t x0, x1, x2, x3, w;
+            // all three twiddles are requested before anything else: ONE wait on global memory per four butterflies (loaded
+            // one by one in front of their products, each product stalled on its own load: +12 % on the radix-2 kernel)
+            fr9_t x0, x1, x2, x3, wa, wb0, wb1;
+            limbs12_get(wa, tw, ia);
+            limbs12_get(wb0, tw, ib);
+            limbs12_get(wb1, tw, ib + (n >> 2));
             tile4_get(x1, sm, e0 + st);
             tile4_get(x3, sm, e0 + 3 * st);
-            limbs12_get(w, tw, ia);
             tile4_get(x0, sm, e0);
             tile4_get(x2, sm, e0 + 2 * st);
-            bfly(x0, x1, w);                 // stage l
-            bfly(x2, x3, w);
-            limbs12_get(w, tw, ib);
-            bfly(x0, x2, w);                 // stage l + 1
-            limbs12_get(w, tw, ib + (n >> 2));
-            bfly(x1, x3, w);
+            bfly(x0, x1, wa);                // stage l
+            bfly(x2, x3, wa);
+            bfly(x0, x2, wb0);               // stage l + 1
+            bfly(x1, x3, wb1);
             fr9_norm(x0, x0);
             fr9_norm(x1, x1);
             fr9_norm(x2, x2);
@@ -705,32 +710,49 @@ void launch_fr_ntt(hipStream_t s, const uint32_t* in, uint32_t* out, int log_n, 
         (void)hipMemcpyAsync(out, in, 32, hipMemcpyDeviceToDevice, s);
         return;
     }
-    if (ntt_use_radix2()) {
+    // Same-box A/B of the two kernels (profiles/r03_ab_ntt_radix4.log; NTT time inside a commit+open, ms):
+    //   size   radix-2 (1024-tile)   radix-2^2, 2048-element tiles   radix-2^2, 1024-element tiles
+    //   2^22   0.554 / 0.561         0.580 / 0.585                   0.540 / 0.539
+    //   2^20   0.156 / 0.156         0.157 / 0.156                   0.153 / 0.150
+    //   2^18   0.059 / 0.060         0.076 / 0.076                   0.061 / 0.059
+    //   2^16   0.042 / 0.042         0.051 / 0.050                   0.042 / 0.042
+    //   2^12   0.028 / 0.027         0.038 / 0.038                   0.030 / 0.030
+    // Halving the LDS traffic and the barriers buys 3 % at best: the kernel is bound by the products themselves (153 mads
+    // + ~120 other instructions per butterfly whatever the blocking) and by the vector's three HBM round trips (1.07 GB at
+    // 2^22, ~0.25 ms at the bandwidth such tiles reach), which only partly overlap.  Larger tiles lose (two workgroups per
+    // CU instead of four hide less of the load / store phases).  So: the register-blocked kernel with 1024-element tiles
+    // from 2^18 up, the radix-2 kernel (one butterfly per lane: more lanes for the latency-bound short rows) below.
+    if (ntt_use_radix2() || log_n < 18) {
         launch_fr_ntt_radix2(s, in, out, log_n, tw, scale_or_null, mid);
         return;
     }
-    // ceil(log_n / 9) passes of near-equal depth (22 -> 8 + 7 + 7, 18 -> 9 + 9, 16 -> 8 + 8, 12 -> 6 + 6, <= 9 -> one pass)
-    const int passes = (log_n + NTT4_PASS_LOG - 1) / NTT4_PASS_LOG;
+    static const int tile_log = [] {
+        const char* e = getenv("KZG_NTT_TILE_LOG");
+        const int v = e ? atoi(e) : 10;
+        return v >= 8 && v <= 11 ? v : 10;
+    }();
+    const int max_s = tile_log - 2;
+    const int passes = (log_n + max_s - 1) / max_s;
     int s0 = 0;
     for (int p = 0; p < passes; p++) {
         const int S = (log_n - s0 + (passes - p) - 1) / (passes - p);
-        int logC = 11 - S;
+        int logC = tile_log - S;
         const int avail = p == 0 ? log_n - S : s0;
         if (logC > avail) logC = avail;
         if (p == 0 && logC > 2) logC = 2;  // first pass: 4 tiles (128 B source rows) keep the tiles' stores long
         const uint32_t blocks = (uint32_t)(n >> (S + logC));
         const bool last = p == passes - 1;
-        const uint32_t quads = (1u << (S + logC)) >> 2;     // one lane per four elements when the tile allows it
-        if (quads >= 512) {
-            if (last) k_fr_ntt_pass4<512, true><<<blocks, 512, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, scale_or_null);
-            else k_fr_ntt_pass4<512, false><<<blocks, 512, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, nullptr);
-        } else if (quads >= 256) {
-            if (last) k_fr_ntt_pass4<256, true><<<blocks, 256, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, scale_or_null);
-            else k_fr_ntt_pass4<256, false><<<blocks, 256, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, nullptr);
-        } else {
-            if (last) k_fr_ntt_pass4<64, true><<<blocks, 64, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, scale_or_null);
-            else k_fr_ntt_pass4<64, false><<<blocks, 64, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, nullptr);
-        }
+        const uint32_t quads = (1u << (S + logC)) >> 2;     // one lane per four elements (the tile is sized 4 x lanes)
+#define NTT4_LAUNCH(NT)                                                                                                      \
+    do {                                                                                                                     \
+        if (last) k_fr_ntt_pass4<NT, true><<<blocks, NT, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, scale_or_null);      \
+        else k_fr_ntt_pass4<NT, false><<<blocks, NT, 0, s>>>(in, out, mid, log_n, s0, S, logC, tw, nullptr);               \
+    } while (0)
+        if (quads > 256) NTT4_LAUNCH(512);
+        else if (quads > 128) NTT4_LAUNCH(256);
+        else if (quads > 64) NTT4_LAUNCH(128);
+        else NTT4_LAUNCH(64);
+#undef NTT4_LAUNCH
         s0 += S;
     }
 }
