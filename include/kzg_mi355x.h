@@ -70,6 +70,10 @@ int kzg_load_srs_file(kzg_ctx* ctx, const char* path, int compressed, int scale,
 /* seconds spent by the last successful load: [0] host copies into the pinned tiles, [1] host waiting for upload + decode
  * (decompression), [2] window-table build, [3] whole call */
 int kzg_get_load_stats(kzg_ctx* ctx, double out_s[4]);
+/* The loaders check every point: coordinates reduced, on the curve, AND in the prime-order subgroup G1 (E(Fp) has a
+ * cofactor of ~2^126; the test is the endomorphism identity [z^2]P == -sigma(P), ~0.3 s for 2^24 points).  A failure is
+ * KZG_E_POINT.  enable = 0 skips the membership part for a file whose provenance is already established. */
+int kzg_set_srs_subgroup_check(kzg_ctx* ctx, int enable);
 
 /* synthetic SRS with known discrete logs (tests / benches; stands in for `fourier setup --generate-setup`,
  * reference tests/conftest.py:50-65): slice k, point j = [s0_k * tau^j] G.  s0_be32: n_slices x 32 bytes. */

@@ -128,6 +128,18 @@ def test_load_srs_roundtrip_and_rejects_bad_points(hip):
     bad[95] ^= 1                                              # y off the curve
     with pytest.raises(KzgError):
         hip().load_srs(bytes(bad), 4, 0)
+    # ON the curve but outside G1 (x = 5; E(Fp) has a ~2^126 cofactor): refused by the membership test of the loaders,
+    # uncompressed and compressed; accepted only when that test is switched off explicitly
+    y5 = o.fp_sqrt((5 ** 3 + 4) % o.P)
+    rogue = srs[:96 * 7] + o.g1_to_be96((5, y5)) + srs[96 * 8:]
+    for data, comp in ((rogue, False), (b"".join(o.g1_compress(o.g1_from_be96(rogue[96 * k:96 * k + 96])) for k in range(16)), True)):
+        e2 = hip()
+        with pytest.raises(KzgError) as ei:
+            e2.load_srs(data, 4, 0, compressed=comp)
+        assert "subgroup" in str(ei.value)
+        e2.set_srs_subgroup_check(False)
+        e2.load_srs(data, 4, 0, compressed=comp)
+        assert e2.srs_read(7, 1) == o.g1_to_be96((5, y5))
     with pytest.raises(KzgError):
         hip().load_srs(o.P.to_bytes(48, "big") * 2 + srs[96:], 4, 0)   # unreduced coordinate
 

@@ -28,6 +28,7 @@ SYMBOLS = {
     "kzg_load_srs_compressed": (_I, [_P, _B, _U64, _I, _I]),
     "kzg_load_srs_file": (_I, [_P, _B, _I, _I, _I]),
     "kzg_get_load_stats": (_I, [_P, ctypes.POINTER(ctypes.c_double)]),
+    "kzg_set_srs_subgroup_check": (_I, [_P, _I]),
     "kzg_gen_srs": (_I, [_P, _B, _B, _U32, _I, _I]),
     "kzg_srs_points": (_U64, [_P]),
     "kzg_srs_read": (_I, [_P, _I, _U64, _U64, _B]),

@@ -166,6 +166,7 @@ struct kzg_ctx {
     uint8_t* aux_pin = nullptr;
     int profiling = 0;   // 0 off, 1 every stage (calls serialise on lane 0), 2 the accumulate kernel only (no serialisation)
     bool host_finish = true;
+    bool srs_subgroup_check = true;  // kzg_load_srs*: G1 membership of every point (kzg_set_srs_subgroup_check)
     // two-lane commit+open: one accumulate at a time instead of two sharing the SIMDs.  Same-box A/B
     // (profiles/r03_ab_serial_accumulate.log): 19.22 / 19.22 / 19.09 ms against 19.34 / 19.20 / 19.21 at 2^22, 5.37-5.40 either
     // way at 2^20 -- no difference: what overlaps the accumulates (sort, opening, trees) is throughput-bound work on the
@@ -600,7 +601,8 @@ int finish(kzg_ctx* ctx, Lane& L, bool allow_poll = true) {
     prof_end(ctx, L);
     const uint32_t* f = reinterpret_cast<const uint32_t*>(L.pin + TB_FLAGS);
     if (f[0]) return fail(ctx, KZG_E_SCALAR, "non-canonical Fr scalar (>= r)");
-    if (f[1]) return fail(ctx, KZG_E_POINT, "G1 input not reduced or not on the curve");
+    if (f[1]) return fail(ctx, KZG_E_POINT, (f[1] & 3u) ? "G1 input not reduced or not on the curve"
+                                                        : "G1 input on the curve but outside the prime-order subgroup");
     return KZG_OK;
 }
 // encodes result point `which` (0 / 1) of a finished request: on the host from the XYZZ working form (default), or
@@ -1163,6 +1165,8 @@ static int load_srs_common(kzg_ctx* ctx, const uint8_t* data, uint64_t n_points,
         pin.used[b] = true;
         if (compressed) launch_srs_from_c48(L.stream, dev_in[b].as<uint8_t>(), table + first, cnt, L.flags() + 1);
         else launch_srs_from_be96(L.stream, dev_in[b].as<uint8_t>(), table + first, cnt, L.flags() + 1);
+        // on the curve is not in G1 (cofactor ~2^126): every point of the file is put through the endomorphism test
+        if (ctx->srs_subgroup_check) launch_g1_subgroup_check_bulk(L.stream, table + first, cnt, L.flags() + 1);
     }
     if (err != hipSuccess) {
         (void)hipStreamSynchronize(L.stream);
@@ -1223,6 +1227,12 @@ int kzg_load_srs_file(kzg_ctx* ctx, const char* path, int compressed, int scale,
 }
 // seconds of the last successful kzg_load_srs*: [0] host copies file/buffer -> pinned tiles, [1] host waits for the GPU
 // (upload + decode / decompression), [2] window-table build, [3] the whole call
+int kzg_set_srs_subgroup_check(kzg_ctx* ctx, int enable) {
+    if (!ctx) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->srs_subgroup_check = enable != 0;
+    return KZG_OK;
+}
 int kzg_get_load_stats(kzg_ctx* ctx, double out_s[4]) {
     if (!ctx || !out_s) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);

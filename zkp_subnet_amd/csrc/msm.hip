@@ -1134,6 +1134,48 @@ __global__ void __launch_bounds__(64) k_g1_subgroup_check_lp(const g1_affine_t* 
     if (!ok) atomicOr(bad, 4u);
 }
 
+// the same test, one LANE per point, for whole setup files (throughput form: 2^24 points are ~2 x 10^9 point operations,
+// ~0.3 s -- the lane-parallel form above is for a few hundred untrusted commitments where latency counts)
+__global__ void __launch_bounds__(256) k_g1_subgroup_check(const g1_affine_t* __restrict__ in, uint64_t n,
+                                                            uint32_t* __restrict__ bad) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    g1_aff28 a;
+    g1_load_aff(a, &in[j]);
+    if (g1_aff_is_inf(a)) return;
+    g1_xyzz_t acc, t;
+    g1_from_aff(acc, a);
+    for (int b = 62; b >= 0; b--) {                    // acc <- [z] P : the base is affine, mixed additions
+        g1_dbl(t, acc);
+        acc = t;
+        if ((BLS_Z >> b) & 1ull) g1_madd_checked(acc, a);
+    }
+    g1_xyzz_t base = acc, q = acc;
+    for (int b = 62; b >= 0; b--) {                    // q <- [z] ([z] P)
+        g1_dbl(t, q);
+        q = t;
+        if ((BLS_Z >> b) & 1ull) {
+            g1_add(t, q, base);
+            q = t;
+        }
+    }
+    if (g1_is_inf(q)) { atomicOr(bad, 4u); return; }
+    fp_t beta, one, u, d, chk;
+#pragma unroll
+    for (int i = 0; i < 14; i++) beta.l[i] = g1_beta_mont(i);
+    fp_one(one);
+    fp_mul(u, beta, a.x);
+    fp_mul(u, u, q.zz);
+    fp_sub16(d, u, q.x);
+    fp_mul(chk, d, one);
+    bool ok = fp_is_zero_n(chk);
+    fp_mul(u, a.y, q.zzz);
+    fp_add(d, u, q.y);
+    fp_mul(chk, d, one);
+    ok &= fp_is_zero_n(chk);
+    if (!ok) atomicOr(bad, 4u);
+}
+
 __global__ void __launch_bounds__(64) k_g1_compress(const g1_xyzz_t* __restrict__ in, uint8_t* __restrict__ out48) {
     tail_priority();
     if (threadIdx.x != 0) return;
@@ -1671,6 +1713,9 @@ void launch_g1_sum_affine(hipStream_t s, const g1_affine_t* in, uint32_t count, 
 }
 void launch_g1_subgroup_check(hipStream_t s, const g1_affine_t* in, uint32_t count, uint32_t* bad_flag) {
     if (count) k_g1_subgroup_check_lp<<<count, 64, 0, s>>>(in, count, bad_flag);
+}
+void launch_g1_subgroup_check_bulk(hipStream_t s, const g1_affine_t* in, uint64_t n, uint32_t* bad_flag) {
+    if (n) k_g1_subgroup_check<<<nblk(n, 256), 256, 0, s>>>(in, n, bad_flag);
 }
 void launch_g1_compress(hipStream_t s, const g1_xyzz_t* in, uint8_t* out48) {
     k_g1_compress<<<1, 64, 0, s>>>(in, out48);

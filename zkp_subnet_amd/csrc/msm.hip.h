@@ -81,6 +81,8 @@ void launch_g1_sum(hipStream_t s, const g1_xyzz_t* in, uint32_t count, g1_xyzz_t
 void launch_g1_sum_affine(hipStream_t s, const g1_affine_t* in, uint32_t count, g1_xyzz_t* out_xyzz);
 // G1 membership (prime-order subgroup) of `count` affine table-format points, one wave each: *bad_flag |= 4 on a failure
 void launch_g1_subgroup_check(hipStream_t s, const g1_affine_t* in, uint32_t count, uint32_t* bad_flag);
+// the same test, one lane per point: whole setup files
+void launch_g1_subgroup_check_bulk(hipStream_t s, const g1_affine_t* in, uint64_t n, uint32_t* bad_flag);
 // affine + ZCash compression of one point
 void launch_g1_compress(hipStream_t s, const g1_xyzz_t* in, uint8_t* out48);
 // two points, one shared inversion

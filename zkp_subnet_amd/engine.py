@@ -101,6 +101,10 @@ class HipEngine:
         self.scale, self.machines_scale = scale, machines_scale
         self.verifier = None
 
+    def set_srs_subgroup_check(self, enable: bool) -> None:
+        """Loaders test every SRS point for membership in G1 (default on); off for files of established provenance."""
+        self._chk(self._lib.kzg_set_srs_subgroup_check(self._h, int(enable)))
+
     def load_stats(self) -> Dict[str, float]:
         """Seconds of the last successful SRS load: host copies, waits for upload + decode, window tables, total."""
         arr = (ctypes.c_double * 4)()
