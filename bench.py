@@ -662,7 +662,7 @@ def main():
             per = {}
             cpu_res = None
             for th in threads:
-                mm = m if th > 1 else min(m, 1 << 16)          # one thread: 2^16 points (~1 s)
+                mm = m if th > 1 else min(m, 1 << 18)          # one thread: 2^18 points (~1-2 s)
                 prep = oc.PreparedMsm(srs[: 96 * mm], scal[: 32 * mm])
                 tc = time.perf_counter()
                 r = prep.run(th)
