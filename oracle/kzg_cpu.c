@@ -13,7 +13,7 @@
  *
  * Deliberately different from the GPU design: 64-bit limbs via unsigned __int128 (6 for Fp, 4 for
  * Fr), Booth-recoded signed windows chosen per call from a cost model, AFFINE buckets filled by
- * batched affine additions (one shared inversion per 1024 additions), one bucket set per
+ * batched affine additions (one shared inversion per up to 4096 additions), one bucket set per
  * (window, point-chunk) task reduced by the classic running sum in XYZZ, windows combined by
  * doublings; no sort, no precomputed tables.
  * It is also the reported CPU baseline, so it is written the way a careful CPU implementation
@@ -529,19 +529,19 @@ typedef struct {
     atomic_int next;
 } msm_plan;
 /* Bucket filling by BATCHED AFFINE additions (what the fast CPU provers do): buckets are affine points; a batch collects up
- * to BA_BATCH additions bucket += point that touch DISTINCT buckets, inverts all their denominators x2 - x1 with one
+ * to `batch` additions bucket += point that touch DISTINCT buckets, inverts all their denominators x2 - x1 with one
  * field inversion (Montgomery's trick: 3 products per element), and finishes each addition with 2M + 1S -- ~6.6 products
  * per addition instead of the 10 of a mixed XYZZ addition.  A point whose bucket is already in the open batch waits in a
  * pending list; if that list outgrows a batch (skewed scalars: many points on few buckets) its entries go into a second,
  * XYZZ bucket set by ordinary mixed additions, so the worst case costs what the plain method costs.  The running-sum
  * reduction reads both sets. */
-enum { BA_BATCH = 1024 };
+enum { BA_BATCH_MAX = 4096 };   /* a batch holds at most a quarter of the bucket count (few collisions), 256 .. 4096 */
 typedef struct { fp x, y; } apoint;
 typedef struct { uint32_t b; int kind; apoint q; fp den; } ba_op;    /* kind 0 add, 1 double, 2 cancel (P + -P) */
 typedef struct {
     apoint *bk; unsigned char *full, *open;      /* affine buckets, occupancy, "in the open batch" */
     g1x *spill; int have_spill; size_t nb;
-    ba_op *ops; int n_ops;
+    ba_op *ops; int n_ops, batch;
     fp *pre;
     uint32_t *pend_b; apoint *pend_q; int n_pend, cap_pend;
 } ba_state;
@@ -596,7 +596,7 @@ static int ba_try(ba_state *st, uint32_t b, const apoint *q) {
 static void ba_drain_pending(ba_state *st) {      /* after a flush: retry what waited; what still collides keeps waiting */
     int kept = 0;
     for (int i = 0; i < st->n_pend; i++) {
-        if (st->n_ops < BA_BATCH && ba_try(st, st->pend_b[i], &st->pend_q[i])) continue;
+        if (st->n_ops < st->batch && ba_try(st, st->pend_b[i], &st->pend_q[i])) continue;
         st->pend_b[kept] = st->pend_b[i]; st->pend_q[kept] = st->pend_q[i]; kept++;
     }
     st->n_pend = kept;
@@ -610,7 +610,7 @@ static void ba_add(ba_state *st, uint32_t b, const apoint *q) {
         st->pend_b[st->n_pend] = b; st->pend_q[st->n_pend] = *q; st->n_pend++;
         return;
     }
-    if (st->n_ops == BA_BATCH) { ba_flush(st); ba_drain_pending(st); }
+    if (st->n_ops == st->batch) { ba_flush(st); ba_drain_pending(st); }
 }
 static void msm_task(const msm_plan *pl, int task, ba_state *st) {
     const int w = task / pl->chunks, k = task % pl->chunks, c = pl->c;
@@ -660,9 +660,10 @@ static void msm_worker(void *arg, int t, int nt) {
     st.bk = (apoint *)malloc((nb + 1) * sizeof(apoint));
     st.full = (unsigned char *)malloc(nb + 1);
     st.open = (unsigned char *)malloc(nb + 1);
-    st.ops = (ba_op *)malloc(BA_BATCH * sizeof(ba_op));
-    st.pre = (fp *)malloc((BA_BATCH + 1) * sizeof(fp));
-    st.cap_pend = BA_BATCH;
+    st.batch = (int)(nb / 4 < 256 ? 256 : nb / 4 > BA_BATCH_MAX ? BA_BATCH_MAX : nb / 4);
+    st.ops = (ba_op *)malloc((size_t)st.batch * sizeof(ba_op));
+    st.pre = (fp *)malloc(((size_t)st.batch + 1) * sizeof(fp));
+    st.cap_pend = st.batch;
     st.pend_b = (uint32_t *)malloc(st.cap_pend * sizeof(uint32_t));
     st.pend_q = (apoint *)malloc(st.cap_pend * sizeof(apoint));
     const int ntask = pl->nwin * pl->chunks;
