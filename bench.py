@@ -114,11 +114,13 @@ def host_cores():
         return os.cpu_count() or 1
 
 
-def thread_counts(user):
-    """CPU-baseline thread counts: 1, the box's share for one GPU (16) and every visible core."""
+def thread_counts(user, usable=None):
+    """CPU-baseline thread counts: 1, the box's share for one GPU (16) and every core this process may actually use
+    (`usable`: the affinity mask cut down to the cgroup's CPU quota -- a box that SHOWS 256 cores but grants 16 has 16)."""
     if user:
         return sorted({1, user})
-    return sorted({1, min(16, host_cores()), host_cores()})
+    n = usable or host_cores()
+    return sorted({1, min(16, n), n})
 
 
 def pctl(xs, q):
@@ -653,10 +655,14 @@ def main():
             out["adversarial"] = adv
         # ---- CPU baseline: the oracle's C port on a bounded sample of the same inputs
         threads = thread_counts(args.cpu_threads)
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import cpu as oc     # the checker / reported baseline: only this leg touches oracle/
+
+            oc.build()
+            threads = thread_counts(args.cpu_threads, oc.usable_cpus())
         if world == 1 and not args.no_cpu_baseline and is_msm and eng is not None:
             from oracle import cpu as oc
 
-            oc.build()
             m = 1 << min(args.cpu_sample_log, lg)
             srs = eng.srs_read(0, m)
             per = {}
@@ -678,7 +684,8 @@ def main():
             out["cpu_baseline"] = {
                 "value": rates[best], "unit": "points/s", "cores": best, "kind": "port",
                 "sample": f"first 2^{m.bit_length() - 1} points/scalars of the same workload, one Pippenger MSM split over "
-                          f"the threads ({host_cores()} host cores visible, {cpu_model()}); points/s by thread count: "
+                          f"the threads ({host_cores()} host cores visible, {oc.usable_cpus()} usable under the cgroup quota, "
+                          f"{cpu_model()}); points/s by thread count: "
                           + ", ".join(f"{th}: {r:.0f} (2^{per[th][0].bit_length() - 1} pts, {per[th][1]:.2f} s)"
                                       for th, r in sorted(rates.items())),
                 "points_per_s_by_threads": {str(th): r for th, r in sorted(rates.items())},

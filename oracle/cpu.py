@@ -44,12 +44,18 @@ def lib() -> ctypes.CDLL:
         _lib.orc_msm_free.argtypes = [ctypes.c_void_p]
         _lib.orc_commit.argtypes = [u8p, u8p, u64, i32, i32, u8p]
         _lib.orc_open.argtypes = [u8p, u8p, u64, i32, u8p, i32, u8p, u8p]
+        _lib.orc_usable_cpus.restype = i32
     return _lib
 
 
 def _chk(rc: int, what: str) -> None:
     if rc != 0:
         raise ValueError(f"oracle {what} failed rc={rc}")
+
+
+def usable_cpus() -> int:
+    """CPUs this process may actually use: affinity mask cut down to the cgroup quota (thread counts above it are capped)."""
+    return int(lib().orc_usable_cpus())
 
 
 def g1_mul_gen(k_be32: bytes) -> bytes:

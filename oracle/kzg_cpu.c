@@ -22,7 +22,10 @@
  * Byte conventions: Fr = 32 B big-endian canonical; G1 affine = x||y 2x48 B big-endian
  * (96 zero bytes = infinity); G1 compressed = 48 B ZCash encoding.
  */
+#define _GNU_SOURCE
 #include <pthread.h>
+#include <sched.h>
+#include <stdio.h>
 #include <stdatomic.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -415,6 +418,7 @@ static void orc_init(void) {
     g_init = 1;
 }
 
+static int usable_cpus(void);
 /* ------------------------------------------------------------------ a tiny fork-join helper: fn(arg, t, nthreads) on t = 0..nthreads-1 */
 typedef struct { void (*fn)(void *, int, int); void *arg; int t, n; } fj_item;
 static void *fj_tramp(void *p) { fj_item *it = (fj_item *)p; it->fn(it->arg, it->t, it->n); return NULL; }
@@ -477,6 +481,7 @@ static void fr_ntt_inplace_mt(fr *a, size_t n, int inverse, int threads) {
     if (n <= 1) return;
     int logn = 0; while (((size_t)1 << logn) < n) logn++;
     if (threads < 1) threads = 1;
+    if (threads > usable_cpus()) threads = usable_cpus();
     while (threads > 1 && (size_t)threads * 1024 > n) threads--;     /* at least ~1000 butterflies per thread and stage */
     ntt_ctx c; c.a = a; c.n = n; c.logn = logn;
     fr_root_of_unity(&c.wn, logn);
@@ -690,10 +695,45 @@ static void msm_choose(size_t n, int threads, int *out_c, int *out_chunks) {
     }
     *out_c = bc; *out_chunks = bk;
 }
+/* CPUs this process may actually use: the affinity mask, cut down to the cgroup's CPU quota when there is one (a container
+ * that SEES 256 cores but is allowed 16 gains nothing from 256 threads -- and a plan made for 256-way parallelism, with
+ * narrower windows and smaller chunks, is a worse plan for the 16 that run) */
+static int usable_cpus(void) {
+    static int cached = 0;
+    if (cached) return cached;
+    int n = 0;
+#ifdef __linux__
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");                  /* cgroup v2: "<quota|max> <period>" */
+    if (f) {
+        char q[32]; long period = 0;
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && q[0] != 'm' && period > 0) {
+            const long quota = atol(q);
+            const int lim = (int)((quota + period - 1) / period);
+            if (lim >= 1 && (n == 0 || lim < n)) n = lim;
+        }
+        fclose(f);
+    } else {
+        long quota = -1, period = 0;                                  /* cgroup v1 */
+        if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"))) { if (fscanf(f, "%ld", &quota) != 1) quota = -1; fclose(f); }
+        if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r"))) { if (fscanf(f, "%ld", &period) != 1) period = 0; fclose(f); }
+        if (quota > 0 && period > 0) {
+            const int lim = (int)((quota + period - 1) / period);
+            if (lim >= 1 && (n == 0 || lim < n)) n = lim;
+        }
+    }
+#endif
+    if (n < 1) n = 1;
+    cached = n;
+    return n;
+}
+int orc_usable_cpus(void) { return usable_cpus(); }
 static void msm_mt(g1j *out, const g1a *pts, const u64 (*sc)[NR], size_t n, int threads) {
     g1j total; g1j_set_inf(&total);
     if (n == 0) { *out = total; return; }
     if (threads < 1) threads = 1;
+    if (threads > usable_cpus()) threads = usable_cpus();
     msm_plan pl; pl.pts = pts; pl.sc = sc; pl.n = n;
     msm_choose(n, threads, &pl.c, &pl.chunks);
     pl.nwin = (256 + pl.c - 1) / pl.c;
