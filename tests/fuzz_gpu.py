@@ -1,7 +1,9 @@
 """Randomised cross-check of the HIP path against the C oracle (not collected by pytest; needs the GPU; lives under
 tests/ because it uses the oracle):
 MSM (random size / window / scalar distribution / offset), NTT round trips and oracle equality, commit / open /
-commit+open on random rows incl. special alphas.  `python tests/fuzz_gpu.py [seconds] [seed]`"""
+commit+open on random rows incl. special alphas, the same through the text path and the row cache (with and without a
+coefficient changed between the two calls), and the fused transform + evaluation.
+`python tests/fuzz_gpu.py [seconds] [seed]`"""
 import os
 import random
 import sys
@@ -10,7 +12,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import bls12_381 as o          # noqa: E402
 from oracle import cpu as oc               # noqa: E402
-from zkp_subnet_amd import HipEngine       # noqa: E402
+from zkp_subnet_amd import HipEngine, codec  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
@@ -18,7 +20,7 @@ rnd = random.Random(seed)
 print("seed", seed, flush=True)
 oc.build()
 t_end = time.time() + budget
-stats = {"msm": 0, "ntt": 0, "kzg": 0}
+stats = {"msm": 0, "ntt": 0, "kzg": 0, "cache_hits": 0, "cache_misses_after_mutation": 0}
 
 
 def scalars(n, kind):
@@ -82,5 +84,26 @@ while time.time() < t_end:
         assert eng.commit_open(0, row, alpha, ev_form) == (c, ev, pf), ("commit_open", lg, ms, window, ev_form)
         assert eng.commit(0, row, ev_form) == c and eng.open(0, row, alpha, ev_form) == (ev, pf), ("commit/open", lg, ms)
         stats["kzg"] += 1
+        # the unchanged miner's two calls from the wire text: the second is served from the row cache -- unless the row
+        # changed in between, in which case it must be recomputed
+        poly = codec.be32_to_fr_list(row)
+        h0, m0 = eng.row_cache_stats()
+        assert eng.commit_list(0, poly, ev_form) == c, ("commit_list", lg, ms)
+        if rnd.random() < 0.5:
+            assert eng.open_list(0, poly, alpha, ev_form) == (ev, pf), ("open_list hit", lg, ms)
+            assert eng.row_cache_stats()[0] == h0 + 1
+            stats["cache_hits"] += 1
+        else:
+            k = rnd.randrange(T)
+            v = (int.from_bytes(row[32 * k:32 * k + 32], "big") + 1 + rnd.randrange(o.R - 1)) % o.R
+            row2 = row[:32 * k] + v.to_bytes(32, "big") + row[32 * k + 32:]
+            poly2 = list(poly)
+            poly2[k] = codec.be32_to_fr(v.to_bytes(32, "big"))
+            assert eng.open_list(0, poly2, alpha, ev_form) == oc.open_(srs, row2, alpha, ev_form, threads=8), ("open_list miss", lg, ms, k)
+            assert eng.row_cache_stats()[0] == h0
+            stats["cache_misses_after_mutation"] += 1
+        if T > 1:
+            inv = rnd.random() < 0.5
+            assert eng.ntt_eval(row, inv, alpha) == oc.fr_eval(oc.fr_ntt(row, inv), alpha), ("ntt_eval", lg - ms, inv)
     eng.close()
 print("fuzz ok", stats, flush=True)

@@ -206,3 +206,30 @@ def test_endomorphism_subgroup_criterion_constants():
     assert y is not None and o.is_on_curve((x, y)) and mul((x, y), o.R) is not None
     q = o.g1_neg(mul((x, y), z * z))
     assert (beta * x % o.P, y) != (q[0], q[1])
+
+
+def test_c_oracle_thread_counts_are_capped_and_agree(oracle_cpu):
+    """The C oracle spreads (window x chunk) tasks over a thread pool; any thread count -- also far above the CPUs this
+    process may use (the count is capped at the affinity mask / cgroup quota) -- gives the same point, for uniform and for
+    skewed scalars (the latter exercise the batched-affine collision / spill path)."""
+    assert oracle_cpu.usable_cpus() >= 1
+    rnd = random.Random(31)
+    n = 3000
+    srs = oracle_cpu.srs_gen((9).to_bytes(32, "big"), (1).to_bytes(32, "big"), 12, 0, 0)[: 96 * n]
+    for kind in ("uniform", "equal", "few", "tiny"):
+        if kind == "uniform":
+            sc = [rnd.randrange(o.R) for _ in range(n)]
+        elif kind == "equal":
+            sc = [rnd.randrange(o.R)] * n
+        elif kind == "few":
+            pool = [rnd.randrange(o.R) for _ in range(3)]
+            sc = [rnd.choice(pool) for _ in range(n)]
+        else:
+            sc = [rnd.randrange(4) for _ in range(n)]
+        sb = o.fr_to_be32(sc)
+        ref = oracle_cpu.msm(srs, sb, threads=1)
+        for th in (2, 7, 64, 100000):
+            assert oracle_cpu.msm(srs, sb, threads=th) == ref, (kind, th)
+    pts = [o.g1_from_be96(srs[96 * k:96 * k + 96]) for k in range(200)]
+    sc = [rnd.randrange(o.R) for _ in range(200)]
+    assert oracle_cpu.msm(srs[: 96 * 200], o.fr_to_be32(sc), threads=3) == o.g1_compress(o.msm_pippenger(pts, sc))
