@@ -279,9 +279,12 @@ static void* pool_worker(void* arg) {
     }
     return NULL;
 }
-/* runs jobs[0..n) (n >= 1): job 0 on the calling thread, the rest on pool workers (or inline if none could start) */
+/* runs jobs[0..n) (n >= 1): job 0 on the calling thread, the rest on pool workers (or inline if none could start, or if
+ * the pool's job slot is held by an asynchronous batch -- creating Python objects between pool_submit and pool_join can
+ * run arbitrary finalizers, which may decode) */
+static int pool_async_out;
 static void pool_run(dec_job* jobs, int n) {
-    if (n > 1) {
+    if (n > 1 && !pool_async_out) {
         pthread_mutex_lock(&pool.mu);
         if (pool.pid != (long)getpid()) { /* first use, or a forked child: no workers here */
             pool.nthreads = 0;
@@ -327,7 +330,9 @@ static void pool_run(dec_job* jobs, int n) {
 /* asynchronous form: pool_submit hands ALL jobs to the workers and returns (1), or returns 0 when no worker could be
  * started (the caller then runs the jobs itself); pool_join helps with unclaimed jobs and waits for the rest.  One
  * outstanding batch at a time (the GIL serialises callers). */
+/* pool_async_out: an asynchronous batch is outstanding (random_fr_rows): the pool's one job slot is taken */
 static int pool_submit(dec_job* jobs, int n) {
+    if (pool_async_out) return 0;
     pthread_mutex_lock(&pool.mu);
     if (pool.pid != (long)getpid()) {
         pool.nthreads = 0;
@@ -351,6 +356,7 @@ static int pool_submit(dec_job* jobs, int n) {
     pool.next = 0;
     pool.finished = 0;
     pool.generation++;
+    pool_async_out = 1;
     pthread_cond_broadcast(&pool.wake);
     pthread_mutex_unlock(&pool.mu);
     return 1;
@@ -366,6 +372,7 @@ static void pool_join(void) {
     }
     while (pool.finished < pool.njobs) pthread_cond_wait(&pool.done, &pool.mu);
     pool.njobs = 0;
+    pool_async_out = 0;
     pthread_mutex_unlock(&pool.mu);
 }
 
