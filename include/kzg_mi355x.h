@@ -134,6 +134,14 @@ void kzg_vk_destroy(kzg_vk* vk);
 int kzg_vk_export(const kzg_vk* vk, uint8_t* out, uint64_t out_len);
 int kzg_vk_verify(const kzg_vk* vk, uint32_t i, const uint8_t proof48[48], const uint8_t alpha_be32[32],
                   const uint8_t eval_be32[32], const uint8_t commitment48[48], int* out_valid);
+/* Every row of a validator step in ONE pairing check (the rows share alpha: neurons/validator.py:106-120).  Random
+ * 128-bit weights r_i (getrandom) fold the n checks into two Miller loops on sum r_i (C_i - y_i L_i) and sum r_i pi_i;
+ * the per-row work (decompression, G1 membership, three scalar multiplications) runs on `threads` host threads.
+ * *out_all_valid = 1 only when every row is valid (an invalid one slips through with probability 2^-128); on 0 call
+ * kzg_vk_verify row by row to find which.  idx: the worker index of each row. */
+int kzg_vk_verify_batch(const kzg_vk* vk, uint32_t n, const uint32_t* idx, const uint8_t* proofs48,
+                        const uint8_t alpha_be32[32], const uint8_t* evals_be32, const uint8_t* commitments48, int threads,
+                        int* out_all_valid);
 /* test hook: final_exp(miller(P, Q)) as 12 x 48 B in tower order (Fp12 = Fp6[w], Fp6 = Fp2[v], Fp2 = Fp[u]) */
 int kzg_vk_pairing(const uint8_t p_be96[96], const uint8_t q_be192[192], uint8_t out_fp12[576]);
 

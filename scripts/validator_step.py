@@ -4,7 +4,8 @@ neurons/validator.py:58-133, Makefile:63-74) on this library, timed part by part
                                 of neurons/validator.py:206 is the yardstick -- a Python loop needs ~40 s for this alone)
   generate_challenge(client,256) random_poly + random_point + 256 x eval(fft(row, inverse), alpha)
   256 x Miner.forward           the miner side of the same step, one GPU, the UNCHANGED two-call route
-  verify_all                    256 pairing checks on a host thread pool
+  verify_all                    all 256 rows in ONE batched pairing check (random linear combination; per-row work on a host
+                                thread pool); beside it the row-by-row form (256 pairing checks on the same pool)
     python scripts/validator_step.py [--scale 24] [--machines-scale 8] [--out profiles/r03_validator_step.json]"""
 import argparse
 import json
@@ -48,6 +49,19 @@ t0 = time.perf_counter()
 ok = verify_all(cl, ch, responses, threads=a.threads)
 res["verify_all_s"] = round(time.perf_counter() - t0, 3)
 assert all(ok), "a proof failed to verify"
+from concurrent.futures import ThreadPoolExecutor             # noqa: E402
+
+t0 = time.perf_counter()
+with ThreadPoolExecutor(max_workers=a.threads) as ex:
+    rowwise = list(ex.map(lambda i: reward(cl, ch, responses[i], i, 0.0) == 1.0, range(rows)))
+res["verify_row_by_row_on_pool_s"] = round(time.perf_counter() - t0, 3)
+assert all(rowwise)
+spoiled = list(responses)
+spoiled[rows // 2] = spoiled[rows // 2].model_copy(update={"proof": responses[0].proof})
+t0 = time.perf_counter()
+ok2 = verify_all(cl, ch, spoiled, threads=a.threads)           # batch fails -> row by row finds the culprit
+res["verify_all_with_one_bad_row_s"] = round(time.perf_counter() - t0, 3)
+assert ok2 == [i != rows // 2 for i in range(rows)]
 t0 = time.perf_counter()
 one = [reward(cl, ch, responses[i], i, 0.0) for i in range(min(rows, 16))]
 res["worker_verify_serial_ms_per_row"] = round((time.perf_counter() - t0) / len(one) * 1e3, 3)

@@ -126,3 +126,48 @@ def test_bad_key_material_is_refused():
     bad[-1] ^= 1
     with pytest.raises(KzgError):
         Verifier.from_points(bytes(bad), o.g1_to_be96(o.G1))
+
+
+def test_batch_verification_of_a_step_one_pairing_check():
+    """kzg_vk_verify_batch: all rows of a step (common alpha) folded into ONE pairing check by random 128-bit weights.
+    True exactly when every row is valid; a single wrong eval, a proof of another row, a row verified against another
+    worker's basis, a point outside G1 or a malformed encoding make it False; thread counts do not matter."""
+    rnd = random.Random(44)
+    tx, ty = rnd.randrange(1, o.R), rnd.randrange(1, o.R)
+    ms, scale = 2, 5
+    lis = [o.lagrange_at(i, 4, ty) for i in range(4)]
+    vk = Verifier.synthetic(tx, lis)
+    alpha = rnd.randrange(o.R)
+    ab = alpha.to_bytes(32, "big")
+    idx, proofs, evals, comms = [], [], [], []
+    for i in (0, 1, 2, 3, 1, 3):
+        srs = o.srs_slice(tx, ty, scale, ms, i)
+        row = [rnd.randrange(o.R) for _ in range(8)]
+        c = o.worker_commit(srs, row)
+        y, pi = o.worker_open(srs, row, alpha)
+        idx.append(i); proofs.append(o.g1_compress(pi)); evals.append(y.to_bytes(32, "big")); comms.append(o.g1_compress(c))
+    for th in (1, 3, 16):
+        assert vk.verify_batch(idx, proofs, ab, evals, comms, threads=th)
+    assert vk.verify_batch([], [], ab, [], [])                                     # nothing to refute
+    assert vk.verify_batch(idx[:1], proofs[:1], ab, evals[:1], comms[:1])
+    bad_eval = list(evals)
+    bad_eval[4] = ((int.from_bytes(evals[4], "big") + 1) % o.R).to_bytes(32, "big")
+    assert not vk.verify_batch(idx, proofs, ab, bad_eval, comms)
+    swapped = list(proofs)
+    swapped[0], swapped[5] = swapped[5], swapped[0]
+    assert not vk.verify_batch(idx, swapped, ab, evals, comms)
+    assert not vk.verify_batch([idx[1]] + idx[1:], proofs, ab, evals, comms)       # row 0 against worker 1's basis
+    assert not vk.verify_batch(idx, proofs, ((alpha + 1) % o.R).to_bytes(32, "big"), evals, comms)
+    x = 4
+    while o.fp_sqrt((x ** 3 + 4) % o.P) is None:
+        x += 1
+    stray = o.g1_compress((x, o.fp_sqrt((x ** 3 + 4) % o.P)))                      # on the curve, outside G1
+    assert not vk.verify_batch(idx, [stray] + proofs[1:], ab, evals, comms)
+    assert not vk.verify_batch(idx, [b"\x00" * 48] + proofs[1:], ab, evals, comms)  # not a compressed point
+    with pytest.raises(Exception):
+        vk.verify_batch([9] + idx[1:], proofs, ab, evals, comms)                   # slice index out of range
+    with pytest.raises(Exception):
+        vk.verify_batch(idx, proofs, o.R.to_bytes(32, "big"), evals, comms)        # non-canonical alpha
+    # every row agrees with the row-by-row verifier
+    assert all(vk.verify(i, p, ab, e, c) for i, p, e, c in zip(idx, proofs, evals, comms))
+    vk.close()

@@ -48,6 +48,7 @@ SYMBOLS = {
     "kzg_vk_destroy": (None, [_P]),
     "kzg_vk_export": (_I, [_P, _B, _U64]),
     "kzg_vk_verify": (_I, [_P, _U32, _B, _B, _B, _B, ctypes.POINTER(_I)]),
+    "kzg_vk_verify_batch": (_I, [_P, _U32, ctypes.POINTER(_U32), _B, _B, _B, _B, _I, ctypes.POINTER(_I)]),
     "kzg_vk_pairing": (_I, [_B, _B, _B]),
     "kzg_msm_partial": (_I, [_P, _B, _U64, _U64, _B]),
     "kzg_g1_sum": (_I, [_P, _B, _U32, _B]),

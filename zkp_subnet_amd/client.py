@@ -188,6 +188,19 @@ class Client:
         return {"valid": bool(ok)}
 
     @_guard
+    def worker_verify_batch(self, indices: Sequence[int], proofs: Sequence[str], alpha: str, evals: Sequence[str],
+                            commitments: Sequence[str], threads: int = 16):
+        """Extension: every row of a validator step (they share alpha, neurons/validator.py:106-120) in ONE pairing check
+        on a random linear combination of the rows.  {"valid": True} only when every row verifies; False does not say
+        which row failed -- `validator.verify_all` then falls back to `worker_verify` row by row."""
+        vb = getattr(self.engine, "verify_batch", None)
+        if vb is None:
+            raise NotImplementedError("this engine has no batch verifier")
+        ok = vb([self._slice(i) for i in indices], [codec.g1_from_b64(p) for p in proofs], codec.fr_to_be32(alpha),
+                [codec.fr_to_be32(e) for e in evals], [codec.g1_from_b64(c) for c in commitments], threads)
+        return {"valid": bool(ok)}
+
+    @_guard
     def fft(self, poly: Sequence[str], left: bool = True, inverse: bool = False):
         n = len(poly)
         want = 1 << (self.scale - self.machines_scale) if left else 1 << self.machines_scale

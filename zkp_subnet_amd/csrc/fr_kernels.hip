@@ -236,8 +236,12 @@ __global__ void __launch_bounds__(NT_) k_fr_ntt_pass(const uint32_t* __restrict_
             fr9_t u, v, w, t;
             tile_get(u, sm, ei);
             tile_get(v, sm, ej);
-            limbs12_get(w, tw, k << (log_n - s - 1));
-            fr9_mul(t, v, w);
+            if (first && l == 0) {
+                t = v;          // stage 0: every twiddle is w^0 = 1 and v is a canonical input -- no product (1/log2(n) of them all)
+            } else {
+                limbs12_get(w, tw, k << (log_n - s - 1));
+                fr9_mul(t, v, w);
+            }
             fr9_add(v, u, t);
             fr9_sub4(w, u, t);
             if (renorm) {   // every second stage, and always the last: in between the limbs stay below 2^31 (header of fr29.hip.h)
@@ -378,8 +382,14 @@ __global__ void __launch_bounds__(NT_) k_fr_ntt_pass4(const uint32_t* __restrict
             fr9_t u, v, w;
             tile4_get(u, sm, ei);
             tile4_get(v, sm, ej);
-            limbs12_get(w, tw, k << (log_n - s - 1));
-            bfly(u, v, w);
+            if (first) {        // stage 0: w^0 = 1 everywhere, v canonical: the butterfly without its product
+                w = v;
+                fr9_sub4(v, u, w);
+                fr9_add(u, u, w);
+            } else {
+                limbs12_get(w, tw, k << (log_n - s - 1));
+                bfly(u, v, w);
+            }
             fr9_norm(u, u);
             fr9_norm(v, v);
             tile4_put(sm, ei, u);
@@ -418,8 +428,14 @@ __global__ void __launch_bounds__(NT_) k_fr_ntt_pass4(const uint32_t* __restrict
             tile4_get(x3, sm, e0 + 3 * st);
             tile4_get(x0, sm, e0);
             tile4_get(x2, sm, e0 + 2 * st);
-            bfly(x0, x1, wa);                // stage l
-            bfly(x2, x3, wa);
+            if (first && l == 0) {           // stage 0 of the transform: twiddle 1, canonical inputs -- no products
+                fr9_t t1 = x1, t3 = x3;
+                fr9_sub4(x1, x0, t1); fr9_add(x0, x0, t1);
+                fr9_sub4(x3, x2, t3); fr9_add(x2, x2, t3);
+            } else {
+                bfly(x0, x1, wa);            // stage l
+                bfly(x2, x3, wa);
+            }
             bfly(x0, x2, wb0);               // stage l + 1
             bfly(x1, x3, wb1);
             fr9_norm(x0, x0);

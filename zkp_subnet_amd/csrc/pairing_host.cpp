@@ -13,7 +13,11 @@
 #include <cstdint>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
+
+#include <sys/random.h>
+#include <sys/types.h>
 
 #include "../../include/kzg_mi355x.h"
 
@@ -481,6 +485,74 @@ int kzg_vk_verify(const kzg_vk* vk, uint32_t i, const uint8_t proof48[48], const
     G2A rhs_q = to_aff(jac_add(to_jac(vk->k.tau_g2), to_jac(aff_neg(to_aff(ag)))));
     Fp12 f = miller_loop(lhs, aff_neg(vk->k.g2)) * miller_loop(pi, rhs_q);
     *out_valid = is_one(final_exp_fast(f)) ? 1 : 0;   // the cube of the exact value: 1 exactly when that is 1
+    return KZG_OK;
+}
+
+/* All rows of a validator step in ONE pairing check.  The rows of a step share alpha (reference neurons/validator.py:
+ * 106-120 draws one random point per challenge), so with random 128-bit weights r_i
+ *     prod_i [ e(C_i - y_i L_i, G2) * e(pi_i, tau G2 - alpha G2)^-1 ]^(r_i) == 1
+ * collapses to two Miller loops on A = sum_i r_i (C_i - y_i L_i) and B = sum_i r_i pi_i: an invalid row survives with
+ * probability 2^-128.  Per row that leaves two decompressions, two G1 membership tests and three scalar multiplications
+ * (one of them by the 255-bit y_i), spread over `threads` host threads; the pairing is paid once.  *out_all_valid = 1
+ * only if EVERY row is valid; on 0 the caller checks row by row to find the culprits (kzg_vk_verify). */
+int kzg_vk_verify_batch(const kzg_vk* vk, uint32_t n, const uint32_t* idx, const uint8_t* proofs48,
+                        const uint8_t alpha_be32[32], const uint8_t* evals_be32, const uint8_t* commitments48, int threads,
+                        int* out_all_valid) {
+    if (!vk || !out_all_valid || (n && (!idx || !proofs48 || !alpha_be32 || !evals_be32 || !commitments48))) return KZG_E_ARG;
+    *out_all_valid = 0;
+    u64 alpha[4];
+    if (!fr_from_be32(alpha, alpha_be32)) return KZG_E_SCALAR;
+    for (uint32_t i = 0; i < n; i++) {
+        u64 y[4];
+        if (idx[i] >= vk->k.li.size()) return KZG_E_ARG;
+        if (!fr_from_be32(y, evals_be32 + 32 * (size_t)i)) return KZG_E_SCALAR;
+    }
+    if (n == 0) { *out_all_valid = 1; return KZG_OK; }
+    std::vector<u64> w(2 * (size_t)n);                       // the weights: 128 random bits per row
+    {
+        size_t need = w.size() * sizeof(u64), got = 0;
+        while (got < need) {
+            const ssize_t r = getrandom(reinterpret_cast<uint8_t*>(w.data()) + got, need - got, 0);
+            if (r <= 0) return KZG_E_HIP;                    // no randomness, no batch check
+            got += (size_t)r;
+        }
+    }
+    if (threads < 1) threads = 1;
+    if ((uint32_t)threads > n) threads = (int)n;
+    std::vector<Jac<Fp>> accA((size_t)threads, jac_inf<Fp>()), accB((size_t)threads, jac_inf<Fp>());
+    std::vector<int> bad((size_t)threads, 0);
+    auto work = [&](int t) {
+        for (uint32_t i = (uint32_t)t; i < n; i += (uint32_t)threads) {
+            G1A c, pi;
+            u64 y[4];
+            (void)fr_from_be32(y, evals_be32 + 32 * (size_t)i);
+            if (!g1_decompress(c, commitments48 + 48 * (size_t)i) || !g1_decompress(pi, proofs48 + 48 * (size_t)i) ||
+                !in_subgroup(c) || !in_subgroup(pi)) {
+                bad[(size_t)t] = 1;
+                return;
+            }
+            const Jac<Fp> yl = jac_mul(vk->k.li[idx[i]], y, 4);
+            const G1A d = to_aff(jac_add(to_jac(c), to_jac(aff_neg(to_aff(yl)))));
+            accA[(size_t)t] = jac_add(accA[(size_t)t], jac_mul(d, &w[2 * (size_t)i], 2));
+            accB[(size_t)t] = jac_add(accB[(size_t)t], jac_mul(pi, &w[2 * (size_t)i], 2));
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < threads; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+    }
+    Jac<Fp> A = jac_inf<Fp>(), B = jac_inf<Fp>();
+    for (int t = 0; t < threads; t++) {
+        if (bad[(size_t)t]) return KZG_OK;                   // a malformed / off-curve / out-of-subgroup element: not all valid
+        A = jac_add(A, accA[(size_t)t]);
+        B = jac_add(B, accB[(size_t)t]);
+    }
+    const Jac<Fp2> ag = jac_mul(vk->k.g2, alpha, 4);
+    const G2A rhs_q = to_aff(jac_add(to_jac(vk->k.tau_g2), to_jac(aff_neg(to_aff(ag)))));
+    const Fp12 f = miller_loop(to_aff(A), aff_neg(vk->k.g2)) * miller_loop(to_aff(B), rhs_q);
+    *out_all_valid = is_one(final_exp_fast(f)) ? 1 : 0;
     return KZG_OK;
 }
 

@@ -143,6 +143,13 @@ class HipEngine:
             raise NotImplementedError("no verifier key: call set_verifier_key() after load_srs()")
         return self.verifier.verify(i, proof48, alpha32, eval32, commitment48)
 
+    def verify_batch(self, indices: Sequence[int], proofs48: Sequence[bytes], alpha32: bytes, evals32: Sequence[bytes],
+                     commitments48: Sequence[bytes], threads: int = 16) -> bool:
+        """All rows of a validator step (common alpha) in one pairing check; True only if every row is valid."""
+        if self.verifier is None:
+            raise NotImplementedError("no verifier key: call set_verifier_key() after load_srs()")
+        return self.verifier.verify_batch(indices, proofs48, alpha32, evals32, commitments48, threads)
+
     def srs_read(self, first: int, count: int, window: int = 0, compressed: bool = False) -> bytes:
         out = ctypes.create_string_buffer((48 if compressed else 96) * count)
         fn = self._lib.kzg_srs_read_compressed if compressed else self._lib.kzg_srs_read

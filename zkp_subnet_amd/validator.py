@@ -42,9 +42,22 @@ def generate_challenge(client, machines_count: int) -> Challenge:  # reference n
 
 def verify_all(client, challenge: Challenge, responses: Sequence[Optional[Prove]], threads: int = 16) -> List[bool]:
     """worker_verify for every row of a step (reference neurons/validator.py:168-170 verifies inside reward(), one row
-    at a time: 256 pairing checks of ~7 ms each at mainnet scale).  The checks are independent host-side pairings and
-    ctypes releases the GIL, so a thread pool runs them on the validator's cores."""
+    at a time: 256 pairing checks of ~4-7 ms each at mainnet scale).  First ONE batched check of all answered rows (they
+    share alpha; `Client.worker_verify_batch`: a random linear combination, two Miller loops in total); if that passes
+    every answered row is valid.  Otherwise -- or with a client that has no batch verifier -- the independent host-side
+    checks run row by row on a thread pool (ctypes releases the GIL) to tell the valid rows from the invalid ones."""
     from concurrent.futures import ThreadPoolExecutor
+
+    n = len(responses)
+    answered = [i for i in range(n) if responses[i] is not None and responses[i].commitment is not None
+                and responses[i].proof is not None]
+    batch = getattr(client, "worker_verify_batch", None)
+    if batch is not None and len(answered) > 1:
+        with batch(answered, [responses[i].proof for i in answered], challenge.alpha,
+                   [challenge.evals[i] for i in answered], [responses[i].commitment for i in answered], threads) as r:
+            if r.status_code == 200 and r.json().get("valid") is True:
+                ok = set(answered)
+                return [i in ok for i in range(n)]
 
     def one(i):
         r = responses[i]
@@ -53,21 +66,7 @@ def verify_all(client, challenge: Challenge, responses: Sequence[Optional[Prove]
         return bool(_ok(client.worker_verify(i, r.proof, challenge.alpha, challenge.evals[i], r.commitment), "valid",
                         "verify the proof"))
 
-    n = len(responses)
     if n <= 1 or threads <= 1:
         return [one(i) for i in range(n)]
     with ThreadPoolExecutor(max_workers=min(threads, n)) as ex:
         return list(ex.map(one, range(n)))
-
-
-def reward(client, challenge: Challenge, response: Optional[Prove], index: int, process_time: Optional[float],
-           timeout: float = 30.0) -> float:  # reference neurons/validator.py:135-176
-    if response is None or response.commitment is None or response.proof is None:
-        return 0.0
-    if process_time is None or process_time > timeout:
-        return 0.0
-    valid = _ok(client.worker_verify(index, response.proof, challenge.alpha, challenge.evals[index],
-                                     response.commitment), "valid", "verify the proof")
-    if not valid:
-        return 0.0
-    return 1 - process_time / timeout

@@ -51,6 +51,23 @@ class Verifier:
             raise KzgError(rc, "kzg_vk_verify: bad argument (index or non-canonical scalar)")
         return bool(ok.value)
 
+    def verify_batch(self, indices: Sequence[int], proofs48: Sequence[bytes], alpha32: bytes, evals32: Sequence[bytes],
+                     commitments48: Sequence[bytes], threads: int = 16) -> bool:
+        """True only if EVERY (index, proof, eval, commitment) row verifies against the common alpha: one pairing check
+        on a random linear combination of the rows (2^-128 soundness error).  False says nothing about which row."""
+        n = len(indices)
+        if not (n == len(proofs48) == len(evals32) == len(commitments48)):
+            raise ValueError("verify_batch: ragged input")
+        if any(len(p) != 48 for p in proofs48) or any(len(c) != 48 for c in commitments48):
+            return False
+        idx = (ctypes.c_uint32 * max(n, 1))(*indices)
+        ok = ctypes.c_int(0)
+        rc = self._lib.kzg_vk_verify_batch(self._h, n, idx, b"".join(proofs48), alpha32, b"".join(evals32),
+                                           b"".join(commitments48), threads, ctypes.byref(ok))
+        if rc != 0:
+            raise KzgError(rc, "kzg_vk_verify_batch: bad argument (index or non-canonical scalar)")
+        return bool(ok.value)
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             self._lib.kzg_vk_destroy(self._h)
