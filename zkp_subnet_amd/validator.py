@@ -70,3 +70,16 @@ def verify_all(client, challenge: Challenge, responses: Sequence[Optional[Prove]
         return [one(i) for i in range(n)]
     with ThreadPoolExecutor(max_workers=min(threads, n)) as ex:
         return list(ex.map(one, range(n)))
+
+
+def reward(client, challenge: Challenge, response: Optional[Prove], index: int, process_time: Optional[float],
+           timeout: float = 30.0) -> float:  # reference neurons/validator.py:135-176
+    if response is None or response.commitment is None or response.proof is None:
+        return 0.0
+    if process_time is None or process_time > timeout:
+        return 0.0
+    valid = _ok(client.worker_verify(index, response.proof, challenge.alpha, challenge.evals[index],
+                                     response.commitment), "valid", "verify the proof")
+    if not valid:
+        return 0.0
+    return 1 - process_time / timeout
