@@ -189,6 +189,31 @@ template <class F>
 bool in_subgroup(const Aff<F>& p) {
     return is_zero(jac_mul(p, R_ORDER, 4).z);
 }
+// G1 only, ~4x cheaper: with sigma(x, y) = (beta x, y) and z = |BLS parameter|, the endomorphism sigma + z^2 has degree
+// z^4 - z^2 + 1 = r and kills G1, so its kernel IS G1:  P in G1  <=>  [z^2] P == -sigma(P)  (two multiplications by the
+// 64-bit z instead of one by the 255-bit r; the same test as k_g1_subgroup_check on the GPU).
+// beta = 0x5f19672f...fffefffe is the cube root of unity that pairs with -z^2; it is re-derived here as 2^((p-1)/3) or its
+// square, whichever satisfies the identity on the generator.
+Aff<Fp> g1_generator();
+static bool g1_endo_identity(const Aff<Fp>& p, const Fp& beta) {
+    const Aff<Fp> zp = to_aff(jac_mul(p, &ATE_LOOP, 1));
+    if (zp.inf) return false;
+    const Jac<Fp> q = jac_mul(zp, &ATE_LOOP, 1);            // [z^2] P = (X / Z^2, Y / Z^3)
+    if (is_zero(q.z)) return false;
+    const Fp z2 = q.z * q.z, z3 = z2 * q.z;
+    return q.x == beta * p.x * z2 && q.y == neg(p.y * z3);
+}
+static const Fp& g1_beta() {
+    static const Fp beta = [] {
+        // (p - 1) / 3
+        static const u64 E[6] = {0x9354ffffffffe38eULL, 0x0a395554e5c6aaaaULL, 0xcd104635a790520cULL, 0xcc27c3d6fbd7063fULL,
+                                 0x190937e76bc3e447ULL, 0x08ab05f8bdd54cdeULL};
+        const Fp b1 = fp_pow(fp_small(2), E, 6), b2 = b1 * b1;
+        return g1_endo_identity(g1_generator(), b1) ? b1 : b2;
+    }();
+    return beta;
+}
+bool g1_in_subgroup_fast(const Aff<Fp>& p) { return p.inf || g1_endo_identity(p, g1_beta()); }
 G1A g1_generator() {
     static const uint8_t gx[48] = {0x17, 0xf1, 0xd3, 0xa7, 0x31, 0x97, 0xd7, 0x94, 0x26, 0x95, 0x63, 0x8c, 0x4f, 0xa9, 0xac, 0x0f,
                                    0xc3, 0x68, 0x8c, 0x4f, 0x97, 0x74, 0xb9, 0x05, 0xa1, 0x4e, 0x3a, 0x3f, 0x17, 0x1b, 0xac, 0x58,
@@ -477,7 +502,7 @@ int kzg_vk_verify(const kzg_vk* vk, uint32_t i, const uint8_t proof48[48], const
     G1A c, pi;
     // malformed or off-curve / out-of-subgroup group elements are an invalid proof, not a call failure
     if (!g1_decompress(c, commitment48) || !g1_decompress(pi, proof48)) return KZG_OK;
-    if (!in_subgroup(c) || !in_subgroup(pi)) return KZG_OK;
+    if (!g1_in_subgroup_fast(c) || !g1_in_subgroup_fast(pi)) return KZG_OK;
     // lhs = C - y * L_i ; rhs_q = tau_G2 - alpha * G2
     Jac<Fp> yl = jac_mul(vk->k.li[i], y, 4);
     G1A lhs = to_aff(jac_add(to_jac(c), to_jac(aff_neg(to_aff(yl)))));
@@ -527,7 +552,7 @@ int kzg_vk_verify_batch(const kzg_vk* vk, uint32_t n, const uint32_t* idx, const
             u64 y[4];
             (void)fr_from_be32(y, evals_be32 + 32 * (size_t)i);
             if (!g1_decompress(c, commitments48 + 48 * (size_t)i) || !g1_decompress(pi, proofs48 + 48 * (size_t)i) ||
-                !in_subgroup(c) || !in_subgroup(pi)) {
+                !g1_in_subgroup_fast(c) || !g1_in_subgroup_fast(pi)) {
                 bad[(size_t)t] = 1;
                 return;
             }
