@@ -446,10 +446,9 @@ static bool poll_pinned(const kzg_ctx* ctx, const Lane& L, uint32_t off, uint32_
         else __builtin_ia32_pause();
     }
 }
-// acc_wait / acc_record: the accumulate kernel -- the one multiplier-bound kernel of the pipeline -- starts only after the
-// event acc_wait (another lane's accumulate) and records acc_record when it ends.  Two accumulates sharing the SIMDs run at
-// ~80 % of the multiplier rate each, one at a time at ~85 %; everything else (sorts, opening, folds, trees) is latency- or
-// LDS-bound and hides under the other lane's accumulate either way (commit_open_dev).
+// acc_wait / acc_record (both optional): the accumulate kernel starts only after the event acc_wait (another lane's
+// accumulate) and records acc_record when it ends -- the "one multiplier-bound kernel at a time" form of a two-lane
+// commit+open (KZG_SERIAL_ACC=1).  Measured against two concurrent accumulates: no difference (kzg_ctx::serial_accumulate).
 int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t n, uint64_t srs_offset,
              g1_xyzz_t* out_xyzz, const uint32_t* scalars2 = nullptr, int mont2 = 0, hipEvent_t acc_wait = nullptr,
              hipEvent_t acc_record = nullptr) {
