@@ -152,8 +152,8 @@ KZG_DEV void tile_put(NttTile& sm, uint32_t e, const fr9_t& v) {
 #pragma unroll
     for (int i = 0; i < 9; i++) sm.l[i][e] = v.l[i];
 }
-// Between the passes of a transform the vector is kept in `mid`, the nine 29-bit limbs of an element in a 48-byte slot,
-// values partially reduced (< 2r, fr9_reduce_approx): a pass that is not the last stores without
+// Between the passes of a transform the vector is kept in `mid`, values partially reduced (< 2r, fr9_reduce_approx) --
+// round 2: the nine 29-bit limbs in a 48-byte slot; round 3: packed into 8 words (below): a pass that is not the last stores without
 // the canonicalising product (27 % of the products of a three-pass transform), a pass that is not the first loads without
 // unpacking.  LAST: this pass writes `out` (8-word canonical elements, 1/n applied).  The first pass reads `in`.
 // nine limbs in a 48-byte slot (three 16-byte accesses; element-major, so a tile row stays C x 48 contiguous bytes)
@@ -170,12 +170,26 @@ KZG_DEV void limbs12_put(uint32_t* __restrict__ base, uint64_t e, const fr9_t& v
     q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
     q[2] = make_uint4(v.l[8], 0u, 0u, 0u);
 }
+#ifndef KZG_NTT_MID48
+// Round 3: the partially reduced value (< 2r < 2^256) is PACKED into 8 words between passes -- 2/3 of the bytes, at the
+// price of a pack and an unpack (~20 instructions each) per element and pass boundary.  Same-box A/B against the 48-byte
+// slots of round 2 (profiles/r03_ab_ntt_mid32.log): 2^22 0.580 / 0.572 / 0.580 -> 0.547 / 0.542 / 0.557 ms, 2^20 0.158 /
+// 0.162 / 0.159 -> 0.153 / 0.151 / 0.152: -5 %.  The transform is partly bound by its HBM round trips, and
+// instructions are cheaper than bytes here.  -DKZG_NTT_MID48 restores the slot form (the scratch is sized for it either way).
+KZG_DEV void mid_get(fr9_t& v, const uint32_t* __restrict__ mid, uint64_t, uint64_t e) { fr9_load(v, mid + 8 * e); }
+KZG_DEV void mid_put(uint32_t* __restrict__ mid, uint64_t, uint64_t e, const fr9_t& v_norm) {
+    fr9_t t;
+    fr9_reduce_approx(t, v_norm);
+    fr9_store(mid + 8 * e, t);
+}
+#else
 KZG_DEV void mid_get(fr9_t& v, const uint32_t* __restrict__ mid, uint64_t, uint64_t e) { limbs12_get(v, mid, e); }
 KZG_DEV void mid_put(uint32_t* __restrict__ mid, uint64_t, uint64_t e, const fr9_t& v_norm) {
     fr9_t t;
     fr9_reduce_approx(t, v_norm);
     limbs12_put(mid, e, t);
 }
+#endif
 template <uint32_t NT_, bool LAST>
 __global__ void __launch_bounds__(NT_) k_fr_ntt_pass(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                       uint32_t* __restrict__ mid, int log_n, int s0, int S, int logC,
