@@ -639,7 +639,11 @@ KZG_DEV void tree_operands(const g1_xyzz_t* in, const g1_xyzz_t* prev, uint32_t 
         pb = pa + 1;
     }
 }
-__global__ void __launch_bounds__(256) k_msm_tree_level(const g1_xyzz_t* __restrict__ in,
+// (A/B knob: waves per SIMD the wide tree kernel and the carry heads are compiled for; 3 costs 62 spilled dwords per lane)
+#ifndef KZG_TREE_MIN_WAVES
+#define KZG_TREE_MIN_WAVES 2
+#endif
+__global__ void __launch_bounds__(256, KZG_TREE_MIN_WAVES) k_msm_tree_level(const g1_xyzz_t* __restrict__ in,
                                                          const g1_xyzz_t* __restrict__ prev,
                                                          g1_xyzz_t* __restrict__ out, uint32_t n_in, int level) {
     tail_priority();
