@@ -211,20 +211,23 @@ def dist_extra_workloads(args, torch, dist, HipEngine, lagrange_factor, rank, lo
       pianist_kzg22  configs[4]: one degree-2^22 commit+open per rank (Pianist worker row `rank`), no exchange (weak)
     Same timing discipline as the headline: W warm-up steps, K steps between barrier + synchronize, MAX over ranks.
     Every rank's MSM result must equal rank 0's."""
-    from zkp_subnet_amd.distributed import DeviceGather
+    from zkp_subnet_amd.distributed import DeviceGather, sharded_msm
+
+    rccl = dist.get_backend() == "nccl"          # gloo: the two-process self-test on one GPU (tensors cross on the host)
+    tdev = "cuda" if rccl else "cpu"
 
     def barrier():
         dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(x):
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def gather_bytes(b):
-        src = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
-        out = torch.empty(world * len(b), dtype=torch.uint8, device="cuda")
+        src = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(tdev)
+        out = torch.empty(world * len(b), dtype=torch.uint8, device=tdev)
         dist.all_gather_into_tensor(out, src)
         raw = out.cpu().numpy().tobytes()
         return [raw[i * len(b):(i + 1) * len(b)] for i in range(world)]
@@ -243,15 +246,16 @@ def dist_extra_workloads(args, torch, dist, HipEngine, lagrange_factor, rank, lo
         eng.gen_srs(TAU, 1, lg, 0, factors=[pow(TAU, rank * n, R_MOD)])
         eng.upload_fr(0, scal, False)
         setup_s = time.time() - t0
-        g = DeviceGather(eng)
+        g = DeviceGather(eng) if rccl else None
+        step = (lambda: g.msm(0, n, 0)) if rccl else (lambda: sharded_msm(eng, slot=0, n=n))
         for _ in range(warm):
-            ref = g.msm(0, n, 0)
+            ref = step()
         eng.set_profiling(2)
         barrier()
         t0 = time.perf_counter()
         acc = 0.0
         for _ in range(steps):
-            r = g.msm(0, n, 0)
+            r = step()
             acc += eng.timings().get("accumulate", 0.0)
             assert r == ref, "non-deterministic sharded MSM"
         barrier()
@@ -355,12 +359,23 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # BENCH_ONE_GPU=1 + BENCH_BACKEND=gloo: every rank on device 0, partials exchanged through the host -- the self-test
+    # of the N > 1 logic (rank-dependent SRS segments, cross-rank checks, msm26 / pianist_kzg22) on a one-GPU box, where
+    # RCCL cannot form a group of two (tests/test_gpu_parity.py).  Never what a measurement uses.
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if os.environ.get("BENCH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the latter: 1-rank RCCL group (self-test)
+    rccl = backend == "nccl"
+    tdev = "cuda" if rccl else "cpu"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rccl:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from zkp_subnet_amd import HipEngine
     from zkp_subnet_amd.distributed import all_gather_partials
@@ -419,7 +434,7 @@ def main():
 
     # N > 1, one request at a time: partial -> RCCL all_gather -> sum entirely through device buffers
     gather = None
-    if use_dist and is_msm and depth == 1:
+    if use_dist and rccl and is_msm and depth == 1:
         from zkp_subnet_amd.distributed import DeviceGather
 
         gather = DeviceGather(eng)
@@ -482,7 +497,7 @@ def main():
         pipe_s = time.perf_counter() - tp
         state["depth"], state["gather"] = 1, gather
         if use_dist:
-            t = torch.tensor([pipe_s], dtype=torch.float64, device="cuda")
+            t = torch.tensor([pipe_s], dtype=torch.float64, device=tdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             pipe_s = float(t.item())
         pipelined = {"requests_in_flight": 2, "value": n_total * args.steps / pipe_s, "unit": "points/s",
@@ -526,7 +541,7 @@ def main():
         lat.append((time.perf_counter() - tl) * 1e3)
     latency_ms = sorted(lat)[len(lat) // 2]
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert all(r == results[0] for r in results), "non-deterministic result across steps"
@@ -535,12 +550,12 @@ def main():
     rccl_version = None
     if use_dist:
         try:
-            rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+            rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version()) if rccl else f"none ({backend} self-test)"
         except Exception:                      # noqa: BLE001 -- informational only
             rccl_version = "unknown"
         if is_msm:                             # every rank computed the same sum: check it, do not assume it
-            src = torch.frombuffer(bytearray(results[0]), dtype=torch.uint8).cuda()
-            allr = torch.empty(world * 48, dtype=torch.uint8, device="cuda")
+            src = torch.frombuffer(bytearray(results[0]), dtype=torch.uint8).to(tdev)
+            allr = torch.empty(world * 48, dtype=torch.uint8, device=tdev)
             dist.all_gather_into_tensor(allr, src)
             allr = allr.cpu().numpy().tobytes()
             assert all(allr[48 * i:48 * i + 48] == results[0] for i in range(world)), "ranks disagree on the MSM result"

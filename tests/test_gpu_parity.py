@@ -1239,3 +1239,51 @@ def test_bench_contract_line(hip):
     want = oc.commit(srs, row, True) + b"".join(oc.open_(srs, row, alpha, True))
     assert bytes.fromhex(pk["results_hex_by_rank"][0]) == want
     assert rec2["pipelined"]["value"] > 0 and "RCCL" in rec2["config"]["parallelism"] or rec2["n_gpus"] == 1
+
+
+def test_bench_two_ranks_on_one_gpu_exercises_the_multi_rank_logic(hip):
+    """What a driver SCALE launch runs, with TWO real ranks: `torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`.
+    A one-GPU box cannot form an RCCL group of two, so both ranks share device 0 and exchange their partials through gloo
+    (BENCH_ONE_GPU / BENCH_BACKEND: self-test knobs): everything rank-dependent is real -- SRS segment r of the 2 n-point
+    SRS per rank, scalars of its index range, partial -> all_gather -> sum, the cross-rank equality checks, and the
+    `msm26` (strong scaling) and `pianist_kzg22` (one row per rank) objects of the same launch.  All three results are
+    compared with the oracle on the concatenated inputs."""
+    import subprocess
+    import sys
+
+    from bench import TAU, R_MOD, uniform_fr
+    from zkp_subnet_amd.engine import lagrange_factor
+
+    env = dict(os.environ, BENCH_ONE_GPU="1", BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29561", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-n", "13", "--steps", "3",
+           "--warmup", "1", "--msm26-log", "15", "--kzg22-log", "11"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["config"]["world_size"] == 2 and rec["scaling"] == "weak"
+    assert abs(rec["value"] - 2 * (1 << 13) * 3 / (rec["ms_per_step"] * 3e-3)) / rec["value"] < 1e-6
+    e = hip()
+    # headline: 2 x 2^13 points, rank r = segment r, scalars seeded by the rank
+    e.gen_srs(TAU, 1, 14, 0)
+    want = oc.msm(e.srs_read(0, 1 << 14), uniform_fr(1 << 13, 0) + uniform_fr(1 << 13, 1), threads=4)
+    assert bytes.fromhex(rec["result_hex"]) == want
+    # msm26 object: ONE 2^15-point MSM in two segments
+    m26 = rec["msm26"]
+    assert m26["n_gpus"] == 2 and m26["points_per_gpu"] == 1 << 14 and m26["all_ranks_equal"] and m26["scaling"] == "strong"
+    e.gen_srs(TAU, 1, 15, 0)
+    want = oc.msm(e.srs_read(0, 1 << 15), uniform_fr(1 << 14, 1000) + uniform_fr(1 << 14, 1001), threads=4)
+    assert bytes.fromhex(m26["result_hex"]) == want
+    # pianist object: worker rows 0 and 1 of a 2-machine setup, one per rank, and their aggregated commitment
+    pk = rec["pianist_kzg22"]
+    assert pk["n_gpus"] == 2 and len(pk["results_hex_by_rank"]) == 2
+    alpha = uniform_fr(1, 1)
+    comms = []
+    for r in range(2):
+        e.gen_srs(TAU, 0, 12, 1, factors=[lagrange_factor(r, 1, (TAU * 7 + 1) % R_MOD)])
+        srs = e.srs_read(0, 1 << 11)
+        row = uniform_fr(1 << 11, r)
+        want = oc.commit(srs, row, True) + b"".join(oc.open_(srs, row, alpha, True))
+        assert bytes.fromhex(pk["results_hex_by_rank"][r]) == want, r
+        comms.append(want[:48])
+    assert bytes.fromhex(pk["aggregate_commitment_hex"]) == e.g1_sum_compressed(b"".join(comms))
