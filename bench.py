@@ -211,10 +211,9 @@ def dist_extra_workloads(args, torch, dist, HipEngine, lagrange_factor, rank, lo
       pianist_kzg22  configs[4]: one degree-2^22 commit+open per rank (Pianist worker row `rank`), no exchange (weak)
     Same timing discipline as the headline: W warm-up steps, K steps between barrier + synchronize, MAX over ranks.
     Every rank's MSM result must equal rank 0's."""
-    from zkp_subnet_amd.distributed import DeviceGather, sharded_msm
+    from zkp_subnet_amd.distributed import DeviceGather
 
-    rccl = dist.get_backend() == "nccl"          # gloo: the two-process self-test on one GPU (tensors cross on the host)
-    tdev = "cuda" if rccl else "cpu"
+    tdev = "cuda"          # device tensors under RCCL and under the gloo self-test alike (gloo moves them through the host)
 
     def barrier():
         dist.barrier()
@@ -246,8 +245,8 @@ def dist_extra_workloads(args, torch, dist, HipEngine, lagrange_factor, rank, lo
         eng.gen_srs(TAU, 1, lg, 0, factors=[pow(TAU, rank * n, R_MOD)])
         eng.upload_fr(0, scal, False)
         setup_s = time.time() - t0
-        g = DeviceGather(eng) if rccl else None
-        step = (lambda: g.msm(0, n, 0)) if rccl else (lambda: sharded_msm(eng, slot=0, n=n))
+        g = DeviceGather(eng)
+        step = lambda: g.msm(0, n, 0)          # noqa: E731 -- partial -> all_gather -> sum, chained through streams
         for _ in range(warm):
             ref = step()
         eng.set_profiling(2)
@@ -359,7 +358,7 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    # BENCH_ONE_GPU=1 + BENCH_BACKEND=gloo: every rank on device 0, partials exchanged through the host -- the self-test
+    # BENCH_ONE_GPU=1 + BENCH_BACKEND=gloo: every rank on device 0, the SAME code path with gloo as the transport -- the self-test
     # of the N > 1 logic (rank-dependent SRS segments, cross-rank checks, msm26 / pianist_kzg22) on a one-GPU box, where
     # RCCL cannot form a group of two (tests/test_gpu_parity.py).  Never what a measurement uses.
     backend = os.environ.get("BENCH_BACKEND", "nccl")
@@ -368,7 +367,7 @@ def main():
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the latter: 1-rank RCCL group (self-test)
     rccl = backend == "nccl"
-    tdev = "cuda" if rccl else "cpu"
+    tdev = "cuda"        # gloo carries device tensors too (through the host): one code path for both backends
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -434,7 +433,7 @@ def main():
 
     # N > 1, one request at a time: partial -> RCCL all_gather -> sum entirely through device buffers
     gather = None
-    if use_dist and rccl and is_msm and depth == 1:
+    if use_dist and is_msm and depth == 1:
         from zkp_subnet_amd.distributed import DeviceGather
 
         gather = DeviceGather(eng)

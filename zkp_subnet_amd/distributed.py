@@ -30,7 +30,7 @@ def all_gather_partials(partial: bytes, group=None) -> List[bytes]:
         return [partial]
     world = dist.get_world_size(group)
     backend = dist.get_backend(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")   # host bytes in, host bytes out
     src = torch.frombuffer(bytearray(partial), dtype=torch.uint8).to(dev)
     out = torch.empty(world * PARTIAL_BYTES, dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(out, src, group=group)
@@ -41,7 +41,8 @@ def all_gather_partials(partial: bytes, group=None) -> List[bytes]:
 class DeviceGather:
     """The collective step with no host round trip for the partials: the engine writes its 192-byte partial into a
     torch device tensor, RCCL all_gathers device-to-device, the engine sums the gathered tensor on the GPU.  Tensors are
-    allocated once.  nccl (RCCL) backend only."""
+    allocated once.  Backend nccl (= RCCL); gloo also moves device tensors (through the host), which is how the tests run
+    this step with two real ranks on one GPU."""
 
     def __init__(self, engine, group=None):
         import torch
