@@ -117,6 +117,15 @@ KZG_DEV void fp_neg_canon(fp_t& r, const fp_t& a) {
     }
 }
 
+// (A/B knob -DKZG_FP_ONE_ACC: ONE accumulator per column instead of two -- 28 fewer 64-bit additions per product, a longer
+// dependent chain of mads)
+#ifdef KZG_FP_ONE_ACC
+#define FP_ACC1 acc0
+#define FP_ACC_SUM acc0
+#else
+#define FP_ACC1 acc1
+#define FP_ACC_SUM (acc0 + acc1)
+#endif
 // Montgomery product, product scanning (FIPS), one 64-bit accumulator pair per column; inputs loose, output N.
 KZG_DEV void fp_mul_inline(fp_t& r, const fp_t& a, const fp_t& b) {
     uint32_t q[14];
@@ -128,7 +137,7 @@ KZG_DEV void fp_mul_inline(fp_t& r, const fp_t& a, const fp_t& b) {
         for (int i = 0; i < 14; i++) {
             const int j = k - i;
             if (j >= 0 && j < 14) {
-                if (i & 1) acc1 += (uint64_t)a.l[i] * b.l[j];
+                if (i & 1) FP_ACC1 += (uint64_t)a.l[i] * b.l[j];
                 else acc0 += (uint64_t)a.l[i] * b.l[j];
             }
         }
@@ -137,10 +146,10 @@ KZG_DEV void fp_mul_inline(fp_t& r, const fp_t& a, const fp_t& b) {
             const int j = k - i;
             if (i < k && i < 14 && j >= 0 && j < 14) {
                 if (i & 1) acc0 += (uint64_t)q[i] * fp28_p(j);
-                else acc1 += (uint64_t)q[i] * fp28_p(j);
+                else FP_ACC1 += (uint64_t)q[i] * fp28_p(j);
             }
         }
-        uint64_t acc = acc0 + acc1;
+        uint64_t acc = FP_ACC_SUM;
         if (k < 14) {
             q[k] = ((uint32_t)acc * FP28_PINV) & FP28_MASK;
             acc += (uint64_t)q[k] * fp28_p(0);
@@ -163,20 +172,20 @@ KZG_DEV void fp_sqr_inline(fp_t& r, const fp_t& a) {
         for (int i = 0; i < 14; i++) {
             const int j = k - i;
             if (j >= 0 && j < 14 && i < j) {
-                if (i & 1) acc1 += (uint64_t)a.l[i] * a2[j];
+                if (i & 1) FP_ACC1 += (uint64_t)a.l[i] * a2[j];
                 else acc0 += (uint64_t)a.l[i] * a2[j];
             }
         }
-        if (!(k & 1) && (k >> 1) < 14) acc1 += (uint64_t)a.l[k >> 1] * a.l[k >> 1];
+        if (!(k & 1) && (k >> 1) < 14) FP_ACC1 += (uint64_t)a.l[k >> 1] * a.l[k >> 1];
 #pragma unroll
         for (int i = 0; i < 14; i++) {
             const int j = k - i;
             if (i < k && i < 14 && j >= 0 && j < 14) {
                 if (i & 1) acc0 += (uint64_t)q[i] * fp28_p(j);
-                else acc1 += (uint64_t)q[i] * fp28_p(j);
+                else FP_ACC1 += (uint64_t)q[i] * fp28_p(j);
             }
         }
-        uint64_t acc = acc0 + acc1;
+        uint64_t acc = FP_ACC_SUM;
         if (k < 14) {
             q[k] = ((uint32_t)acc * FP28_PINV) & FP28_MASK;
             acc += (uint64_t)q[k] * fp28_p(0);
@@ -203,7 +212,7 @@ KZG_DEV void fp_mul2_inline(fp_t& r, const fp_t& a, const fp_t& b, const fp_t& c
             const int j = k - i;
             if (j >= 0 && j < 14) {
                 acc0 += (uint64_t)a.l[i] * b.l[j];
-                acc1 += (uint64_t)c.l[i] * d.l[j];
+                FP_ACC1 += (uint64_t)c.l[i] * d.l[j];
             }
         }
 #pragma unroll
@@ -211,10 +220,10 @@ KZG_DEV void fp_mul2_inline(fp_t& r, const fp_t& a, const fp_t& b, const fp_t& c
             const int j = k - i;
             if (i < k && i < 14 && j >= 0 && j < 14) {
                 if (i & 1) acc0 += (uint64_t)q[i] * fp28_p(j);
-                else acc1 += (uint64_t)q[i] * fp28_p(j);
+                else FP_ACC1 += (uint64_t)q[i] * fp28_p(j);
             }
         }
-        uint64_t acc = acc0 + acc1;
+        uint64_t acc = FP_ACC_SUM;
         if (k < 14) {
             q[k] = ((uint32_t)acc * FP28_PINV) & FP28_MASK;
             acc += (uint64_t)q[k] * fp28_p(0);
