@@ -286,6 +286,11 @@ struct LaneHold {
         if (li2 < 0) li2 = lane_try_second(ctx, li);
         return li2 >= 0 ? &ctx->lane[li2] : nullptr;
     }
+    void drain() {   // wait for everything this call queued (what the destructor does for a call that did not end cleanly)
+        if (li >= 0) (void)hipStreamSynchronize(ctx->lane[li].stream);
+        if (li2 >= 0) (void)hipStreamSynchronize(ctx->lane[li2].stream);
+        (void)hipGetLastError();
+    }
     ~LaneHold() {
         if (li < 0) return;
         if (!clean) {
@@ -1487,6 +1492,7 @@ static int commit_open_host_cached(kzg_ctx* ctx, uint32_t i, const uint8_t* row_
     if (look >= 0) {          // hit: no upload, no INTT
         rc = commit_open_dev(ctx, H, i, nullptr, T, evaluation_form, alpha, c48, e32, p48,
                              ctx->rcache[look].coef.as<uint32_t>());
+        if (rc != KZG_OK) H.drain();            // queued kernels may still read the slot
         rcache_release(ctx, look, true, tag, T, evaluation_form);
         return rc;
     }
@@ -1499,6 +1505,7 @@ static int commit_open_host_cached(kzg_ctx* ctx, uint32_t i, const uint8_t* row_
     rc = L.coeffA.ensure(T * 32) == hipSuccess ? KZG_OK : fail(ctx, KZG_E_NOMEM, "row buffer");
     if (!rc) rc = upload_fr(ctx, L, row_be32, T, L.coeffA.as<uint32_t>(), 1);
     if (!rc) rc = commit_open_dev(ctx, H, i, L.coeffA.as<uint32_t>(), T, evaluation_form, alpha, c48, e32, p48, nullptr, dst);
+    if (rc != KZG_OK && slot >= 0) H.drain();   // a failed call may have kernels queued that still write the slot: not reusable before
     if (slot >= 0) rcache_release(ctx, slot, rc == KZG_OK && dst != nullptr, tag, T, evaluation_form);
     return rc;
 }
