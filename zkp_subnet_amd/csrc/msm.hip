@@ -657,6 +657,34 @@ __global__ void __launch_bounds__(256, KZG_TREE_MIN_WAVES) k_msm_tree_level(cons
     load_xyzz(a, pa);
     load_xyzz(b, pb);
     g1_add<true>(r, a, b);  // wide levels are throughput-bound: inlined products (-4 %, same-box A/B)
+    // A wave's 64 results are one contiguous 14-KB run of `out`, but a lane's own 224 bytes make every store instruction
+    // touch 64 different lines.  They go through a wave-private slice of LDS (240-byte slots: conflict-free b128 writes)
+    // and leave as 14 fully coalesced rows: -9 % on the two-round levels (`profiles/r03_exp_tree_coalescing.log`; the same
+    // treatment of the operand loads measured 0).  No barrier: a wave's LDS operations execute in order.
+    if ((n_out & 63u) == 0) {   // wave-uniform: all 64 lanes are live and share k
+        __shared__ uint4 stage[4][64 * 15];
+        const uint32_t lane = threadIdx.x & 63u;
+        uint4* mine = stage[threadIdx.x >> 6];
+        uint32_t t[56];
+        const fp_t* f[4] = {&r.x, &r.y, &r.zz, &r.zzz};
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int i = 0; i < 14; i++) t[14 * c + i] = f[c]->l[i];
+#pragma unroll
+        for (int i = 0; i < 14; i++) mine[lane * 15 + i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint4* wb = reinterpret_cast<uint4*>(&out[(uint64_t)k * n_out + (m - lane)]);
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            const uint32_t g = (uint32_t)i * 64u + lane;   // 16-byte piece of the run: piece g % 14 of result g / 14
+            const uint32_t pt = g / 14u;
+            wb[g] = mine[pt * 15 + (g - pt * 14u)];
+        }
+        return;
+    }
     store_xyzz(&out[(uint64_t)k * n_out + m], r);
 }
 
