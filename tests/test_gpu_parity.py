@@ -438,6 +438,19 @@ def test_ntt_kernel_variants_agree(env):
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("rounds", ["1", "2"])
+def test_sort_round_variants_agree(rounds):
+    """Both forms of the sort's level-1 partition (one / two rounds of scalars per workgroup; the library picks by size)
+    forced at sizes the oracle finishes quickly, incl. the skewed inputs that overflow a region and rerun in exact mode."""
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sort_variant_check.py")],
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, KZG_SORT_ROUNDS=rounds))
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
 def test_eval_reference_kat_on_gpu(hip, fr_kat):
     """The reference's only arithmetic known-answer vector (tests/test_miner.py:33-55), through the HIP path."""
     from zkp_subnet_amd import codec

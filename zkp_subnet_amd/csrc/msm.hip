@@ -3,6 +3,7 @@
 // published bucket method and checked bit-for-bit against oracle/ in tests/test_gpu_*.py.
 #include "msm.hip.h"
 #include "fp_lp.hip.h"
+#include <cstdlib>
 
 #define NONE_KEY 0xffffffffu
 
@@ -275,6 +276,133 @@ __global__ void __launch_bounds__(1024) k_sort_partition_staged(const uint32_t* 
         const uint2 v = stage[i];
         const uint32_t q = v.x >> 16;
         if (!((skip[q >> 5] >> (q & 31)) & 1u)) parted[h[q] + i] = make_uint2(v.x & 0xffffu, v.y);
+    }
+}
+
+// R scalars per lane (R rounds of `spb` scalars each, digits of all of them in registers): ONE reservation per partition
+// for the whole workgroup, so its runs are R times longer (at 2^22 points and 4096 partitions a round leaves 3.25 entries
+// = 26 bytes per partition, and 32-byte sectors written for 26 bytes cost twice the bytes) and the global atomics R times
+// fewer; the R x spb x nwin entries pass through the same stage in R slices of the partition-ordered sequence.
+template <int R, int MAXW>
+__global__ void __launch_bounds__(1024) k_sort_partition_staged_multi(const uint32_t* __restrict__ scalars, const SortShape ss,
+                                                                 const WinLayout lay, uint32_t spb,
+                                                                 const uint32_t* __restrict__ part_base,
+                                                                 uint32_t* __restrict__ part_cursor,
+                                                                 uint2* __restrict__ parted, uint32_t region_cap,
+                                                                 uint32_t* __restrict__ overflow) {
+    __shared__ uint32_t h[SORT_MAXPART];     // counts, then (global base - local offset) per partition
+    __shared__ uint32_t skip[SORT_MAXPART / 32];
+    __shared__ uint32_t loff[SORT_MAXPART];  // local exclusive offsets
+    __shared__ uint32_t wsum[1024];
+    __shared__ uint2 stage[SORT1_STAGE];  // .x = key_low (<= 12 bits) | partition << 16
+    const uint32_t t = threadIdx.x;
+    const uint32_t npart = 1u << ss.hbits;
+    for (uint32_t i = t; i < npart; i += 1024) h[i] = 0;
+    if (t < SORT_MAXPART / 32) skip[t] = 0;
+    __syncthreads();
+    // 1. digits -> registers, rank inside (workgroup, partition)
+    static_assert(R * SORT1_STAGE <= 65536, "ranks are kept in 16 bits");
+    static_assert(R == 1 || R % 2 == 0, "scalars are taken two at a time");
+    uint32_t keyn[R][MAXW], rkp[(R + 1) / 2][MAXW];   // ranks < R * SORT1_STAGE < 2^16: two per register
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int w = 0; w < MAXW; w++) {
+            keyn[r][w] = 0xffffffffu;
+            if (!(r & 1)) rkp[r / 2][w] = 0;
+        }
+    constexpr int PAIR = R == 1 ? 1 : 2;   // loads in flight together (all R of them would cost 8 registers each)
+#pragma unroll
+    for (int r0 = 0; r0 < R; r0 += PAIR) {
+        uint32_t sc[PAIR][8];
+        bool live[PAIR], second[PAIR];
+#pragma unroll
+        for (int u = 0; u < PAIR; u++) {
+            const uint64_t g = ((uint64_t)blockIdx.x * R + (r0 + u)) * spb + t;
+            live[u] = t < spb && g < ss.total;
+            second[u] = live[u] && g >= ss.n;
+            if (live[u]) load_scalar(sc[u], second[u] ? ss.scalars2 : scalars, second[u] ? g - ss.n : g, second[u] ? ss.mont2 : ss.mont);
+        }
+#pragma unroll
+        for (int u = 0; u < PAIR; u++) {
+            if (live[u]) {
+                const int r = r0 + u;
+                const uint32_t set_bit = second[u] ? 1u << ss.keybits : 0u;
+                uint32_t carry = 0, neg;
+#pragma unroll
+                for (int w = 0; w < MAXW; w++) {
+                    if (w < lay.nwin) {
+                        const uint32_t mag = signed_digit(sc[u], w, lay, carry, neg);
+                        if (mag) {
+                            const uint32_t key = (mag - 1) | set_bit;
+                            keyn[r][w] = key | (neg << 31);
+                            rkp[r / 2][w] |= lds_bump(h, key >> ss.lbits) << (16 * (r & 1));
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // 2. exclusive scan of the counts
+    const uint32_t per = (npart + 1023u) / 1024u;
+    const uint32_t b0 = t * per, b1 = min(b0 + per, npart);
+    uint32_t sum = 0;
+    for (uint32_t i = b0; i < b1; i++) sum += h[i];
+    wsum[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t x = (t >= d) ? wsum[t - d] : 0;
+        __syncthreads();
+        wsum[t] += x;
+        __syncthreads();
+    }
+    const uint32_t count = wsum[1023];
+    uint32_t run = wsum[t] - sum;
+    // 3. reserve the global run of every non-empty partition; h becomes (global position - local position)
+    for (uint32_t i = b0; i < b1; i++) {
+        const uint32_t c = h[i];
+        loff[i] = run;
+        if (c) {
+            const uint32_t old = atomicAdd(&part_cursor[i], c);
+            if (!region_cap) h[i] = part_base[i] + old - run;
+            else if (old + c <= region_cap) h[i] = i * region_cap + old - run;
+            else {
+                atomicOr(&skip[i >> 5], 1u << (i & 31));
+                atomicOr(overflow, 1u);
+            }
+        }
+        run += c;
+    }
+    __syncthreads();
+    const uint32_t lmask = (1u << ss.lbits) - 1u;
+    for (uint32_t p0 = 0; p0 < count; p0 += SORT1_STAGE) {   // one slice when R == 1
+        // 4. place the slice's entries at their local sorted position
+#pragma unroll
+        for (int r = 0; r < R; r++) {   // (a scalar that is not live has no digits)
+            const uint64_t g = ((uint64_t)blockIdx.x * R + r) * spb + t;
+            const uint64_t j = g >= ss.n ? g - ss.n : g;
+#pragma unroll
+            for (int w = 0; w < MAXW; w++) {
+                if (keyn[r][w] != 0xffffffffu) {
+                    const uint32_t key = keyn[r][w] & 0x7fffffffu;
+                    const uint32_t q = key >> ss.lbits;
+                    const uint32_t i = loff[q] + ((rkp[r / 2][w] >> (16 * (r & 1))) & 0xffffu) - p0;
+                    if (R == 1 || i < SORT1_STAGE)   // (unsigned: positions of earlier slices wrap far above)
+                        stage[i] = make_uint2((key & lmask) | (q << 16),
+                                              (uint32_t)((uint64_t)w * ss.srs_stride + ss.srs_offset + j) | (keyn[r][w] & 0x80000000u));
+                }
+            }
+        }
+        __syncthreads();
+        // 5. copy out: consecutive lanes -> consecutive addresses inside each partition's run
+        const uint32_t cnt = min(count - p0, (uint32_t)SORT1_STAGE);
+        for (uint32_t i = t; i < cnt; i += 1024) {
+            const uint2 v = stage[i];
+            const uint32_t q = v.x >> 16;
+            if (!((skip[q >> 5] >> (q & 31)) & 1u)) parted[h[q] + p0 + i] = make_uint2(v.x & 0xffffu, v.y);
+        }
+        if (R > 1) __syncthreads();
     }
 }
 
@@ -1639,6 +1767,29 @@ uint64_t msm_sort_parted_entries(const MsmShape& sh, bool fast) {  // capacity o
     sort_shape(sh, nullptr, 0, 0, ss);
     return msm_sort_region_cap(entries, 1u << ss.hbits) << ss.hbits;
 }
+// rounds per workgroup of the staged level-1 partition (A/B knob KZG_SORT_ROUNDS = 1 | 2): two from 2^20 scalars up
+// (sort 0.146 -> 0.138 ms at 2^20, 0.72 -> 0.58 at 2^22, 2.89 -> 2.25 at 2^24; four rounds spill their digits and lose:
+// `profiles/r03_ab_sort_two_rounds.log`); needs the digits of both scalars in registers (<= 16 windows)
+static int sort_rounds(uint64_t total, int nwin) {
+    static const int forced = [] {
+        const char* e = getenv("KZG_SORT_ROUNDS");
+        return e ? atoi(e) : 0;
+    }();
+    if (nwin > 16) return 1;
+    if (forced == 1 || forced == 2) return forced;
+    return total >= (1u << 20) ? 2 : 1;
+}
+static void launch_partition_staged(hipStream_t s, const uint32_t* scalars, const SortShape& ss, const WinLayout& lay,
+                                    uint32_t spb2, const uint32_t* part_base, uint32_t* part_cursor, uint2* parted,
+                                    uint32_t cap, uint32_t* overflow_word) {
+    const int rounds = sort_rounds(ss.total, lay.nwin);
+    if (rounds == 2)
+        k_sort_partition_staged_multi<2, 16><<<nblk(ss.total, 2 * spb2), 1024, 0, s>>>(scalars, ss, lay, spb2, part_base,
+                                                                                        part_cursor, parted, cap, overflow_word);
+    else
+        k_sort_partition_staged<<<nblk(ss.total, spb2), 1024, 0, s>>>(scalars, ss, lay, spb2, part_base, part_cursor,
+                                                                     parted, cap, overflow_word);
+}
 // FAST mode (uniform-ish scalars: the common case): no count pass -- partition straight into fixed-capacity regions, scan
 // the cursors, level 2 reads the regions.  If a region overflows (skewed scalars) *overflow_word is raised, the offsets
 // come out all zero (the queued accumulate sees an empty MSM) and the caller reruns in EXACT mode: count pass, exact
@@ -1658,8 +1809,7 @@ void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars,
     if (spb2 > 1024) spb2 = 1024;
     if (fast) {
         const uint32_t cap = (uint32_t)msm_sort_region_cap(entries, npart);
-        k_sort_partition_staged<<<nblk(ss.total, spb2), 1024, 0, s>>>(scalars, ss, sh.lay, spb2, part_base, part_cursor,
-                                                                     parted, cap, overflow_word);
+        launch_partition_staged(s, scalars, ss, sh.lay, spb2, part_base, part_cursor, parted, cap, overflow_word);
         k_sort_part_scan<<<1, 1024, 0, s>>>(part_cursor, npart, cap, part_base, max_len_word, nullptr);
         k_sort_buckets<<<npart, 1024, 0, s>>>(parted, part_base, ss.lbits, offsets, sorted, npart, cap, overflow_word,
                                               part_cursor);
@@ -1670,8 +1820,7 @@ void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars,
     else k_sort_count<1><<<nblk(ss.total, 1024), 1024, 0, s>>>(scalars, ss, sh.lay, part_count);
     k_sort_part_scan<<<1, 1024, 0, s>>>(part_count, npart, 0xffffffffu, part_base, max_len_word, overflow_word);
     if (sh.nwin <= SORT1_MAXW)
-        k_sort_partition_staged<<<nblk(ss.total, spb2), 1024, 0, s>>>(scalars, ss, sh.lay, spb2, part_base, part_cursor,
-                                                                     parted, 0u, overflow_word);
+        launch_partition_staged(s, scalars, ss, sh.lay, spb2, part_base, part_cursor, parted, 0u, overflow_word);
     else
         k_sort_partition<<<blocks, 256, 0, s>>>(scalars, ss, sh.lay, part_base, part_cursor, parted);
     k_sort_buckets<<<npart, 1024, 0, s>>>(parted, part_base, ss.lbits, offsets, sorted, npart, 0u, overflow_word, part_cursor);
