@@ -20,7 +20,7 @@ for lg in sizes:
     T = 1 << lg
     cl = Client(seed=3, workers=[0])
     cl.start(scale=lg, machines_scale=0)
-    polys = [codec.be32_to_fr_list(uniform_fr(T, 10 + k)) for k in range(4)]
+    polys = [codec.be32_to_fr_list(uniform_fr(T, 10 + k)) for k in range(8)]
     x = codec.be32_to_fr(uniform_fr(1, 2))
     want = []
     for p in polys:
@@ -29,12 +29,12 @@ for lg in sizes:
             want.append(r.json())
     reps = 24 if lg <= 16 else 8
     out = {"log2_T": lg}
-    for threads in (4, 1, 2, 4):          # the first pass (4 threads) only warms every lane's workspace
+    for threads in (8, 1, 2, 4, 8):       # the first pass only warms every lane's workspace
         bad = []
 
         def work(tid):
             for it in range(reps):
-                k = (tid + it) % 4
+                k = (tid + it) % 8
                 with cl.worker_commit_and_open(0, polys[k], x) as r:
                     if r.json() != want[k]:
                         bad.append((tid, it))

@@ -30,7 +30,9 @@
 
 #define KZG_VERSION "kzg_mi355x 0.2 (gfx950)"
 #define N_SLOTS 4
+#ifndef N_LANES
 #define N_LANES 4
+#endif
 #define N_STAGE 4
 #define KZG_MAX_GATHER 4096   // partials one kzg_msm_sharded_finish can sum (ranks of a job)
 
