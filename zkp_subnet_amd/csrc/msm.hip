@@ -67,6 +67,30 @@ KZG_DEV uint32_t lds_bump(uint32_t* h, uint32_t key) {
     }
     return atomicAdd(&h[key], 1u);
 }
+// inclusive scan of one value per thread over a 1024-thread workgroup: six shuffle steps inside each wave, the 16 wave
+// totals through LDS (two barriers in all; the ten-step LDS scan this replaces had twenty -- 2-4 us of a short row's
+// single-workgroup sort kernels).  Returns the inclusive prefix; `total` = sum over the workgroup.  wtot: 16 words of LDS.
+KZG_DEV uint32_t block_scan_1024(uint32_t v, uint32_t* wtot, uint32_t& total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t x = __shfl_up(inc, d, 64);
+        if (lane >= (uint32_t)d) inc += x;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; w++) {
+        const uint32_t x = wtot[w];
+        if (w < wave) base += x;
+        tot += x;
+    }
+    total = tot;
+    __syncthreads();   // wtot may be reused by the next scan
+    return base + inc;
+}
 template <class F>
 KZG_DEV void for_each_entry(const uint32_t* __restrict__ scalars, const SortShape& ss, const WinLayout& lay, F&& f) {
     const uint64_t base = (uint64_t)blockIdx.x * ss.spb;
@@ -127,27 +151,21 @@ __global__ void __launch_bounds__(1024) k_sort_part_scan(uint32_t* __restrict__ 
                                                           uint32_t* __restrict__ part_base,
                                                           uint32_t* __restrict__ max_len_word,
                                                           uint32_t* __restrict__ overflow_word_or_null) {
-    __shared__ uint32_t part[1024];
+    __shared__ uint32_t part[16];
     const uint32_t t = threadIdx.x;
     const uint32_t per = (npart + 1023u) / 1024u;
     const uint32_t lo = t * per, hi = min(lo + per, npart);
     uint32_t v = 0;
     for (uint32_t i = lo; i < hi; i++) v += min(counts[i], clamp);
-    part[t] = v;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t x = (t >= d) ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += x;
-        __syncthreads();
-    }
-    uint32_t run = part[t] - v;
+    uint32_t all;
+    const uint32_t incl = block_scan_1024(v, part, all);
+    uint32_t run = incl - v;
     for (uint32_t i = lo; i < hi; i++) {
         part_base[i] = run;
         run += min(counts[i], clamp);
         counts[i] = 0;
     }
-    if (t == 1023) part_base[npart] = part[1023];
+    if (t == 1023) part_base[npart] = all;
     if (t == 0) {
         *max_len_word = 0;
         if (overflow_word_or_null) *overflow_word_or_null = 0;
@@ -192,7 +210,7 @@ __global__ void __launch_bounds__(1024) k_sort_partition_staged(const uint32_t* 
     __shared__ uint32_t h[SORT_MAXPART];     // counts, then (global base - local offset) per partition
     __shared__ uint32_t skip[SORT_MAXPART / 32];
     __shared__ uint32_t loff[SORT_MAXPART];  // local exclusive offsets
-    __shared__ uint32_t wsum[1024];
+    __shared__ uint32_t wsum[16];
     __shared__ uint2 stage[SORT1_STAGE];  // .x = key_low (<= 12 bits) | partition << 16
     const uint32_t t = threadIdx.x;
     const uint32_t npart = 1u << ss.hbits;
@@ -230,16 +248,8 @@ __global__ void __launch_bounds__(1024) k_sort_partition_staged(const uint32_t* 
     const uint32_t b0 = t * per, b1 = min(b0 + per, npart);
     uint32_t sum = 0;
     for (uint32_t i = b0; i < b1; i++) sum += h[i];
-    wsum[t] = sum;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t x = (t >= d) ? wsum[t - d] : 0;
-        __syncthreads();
-        wsum[t] += x;
-        __syncthreads();
-    }
-    const uint32_t count = wsum[1023];
-    uint32_t run = wsum[t] - sum;
+    uint32_t count;
+    uint32_t run = block_scan_1024(sum, wsum, count) - sum;
     // 3. reserve the global run of every non-empty partition; h becomes (global position - local position)
     for (uint32_t i = b0; i < b1; i++) {
         const uint32_t c = h[i];
@@ -293,7 +303,7 @@ __global__ void __launch_bounds__(1024) k_sort_partition_staged_multi(const uint
     __shared__ uint32_t h[SORT_MAXPART];     // counts, then (global base - local offset) per partition
     __shared__ uint32_t skip[SORT_MAXPART / 32];
     __shared__ uint32_t loff[SORT_MAXPART];  // local exclusive offsets
-    __shared__ uint32_t wsum[1024];
+    __shared__ uint32_t wsum[16];
     __shared__ uint2 stage[SORT1_STAGE];  // .x = key_low (<= 12 bits) | partition << 16
     const uint32_t t = threadIdx.x;
     const uint32_t npart = 1u << ss.hbits;
@@ -349,16 +359,8 @@ __global__ void __launch_bounds__(1024) k_sort_partition_staged_multi(const uint
     const uint32_t b0 = t * per, b1 = min(b0 + per, npart);
     uint32_t sum = 0;
     for (uint32_t i = b0; i < b1; i++) sum += h[i];
-    wsum[t] = sum;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t x = (t >= d) ? wsum[t - d] : 0;
-        __syncthreads();
-        wsum[t] += x;
-        __syncthreads();
-    }
-    const uint32_t count = wsum[1023];
-    uint32_t run = wsum[t] - sum;
+    uint32_t count;
+    uint32_t run = block_scan_1024(sum, wsum, count) - sum;
     // 3. reserve the global run of every non-empty partition; h becomes (global position - local position)
     for (uint32_t i = b0; i < b1; i++) {
         const uint32_t c = h[i];
@@ -420,7 +422,7 @@ __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__
     __shared__ uint32_t h[4096];
     __shared__ uint32_t th[4096];   // per-tile histogram / cursors of the oversized-partition path
     __shared__ uint32_t longb[SORT_STAGE / SORT_LONG_RUN + 1], nlong, maxc;
-    __shared__ uint32_t wsum[1024];
+    __shared__ uint32_t wsum[16];
     // a partition of up to SORT_STAGE entries is scattered inside LDS and leaves as whole lines (the 4-byte scatter
     // straight to HBM wrote 3.7x the bytes: lines left L2 partly filled); larger (long inputs, skewed scalars) partitions go through it tile by tile
     __shared__ uint32_t stage[SORT_STAGE];
@@ -453,15 +455,8 @@ __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__
     const uint32_t b0 = t * per, b1 = min(b0 + per, nb);
     uint32_t s = 0;
     for (uint32_t i = b0; i < b1; i++) s += h[i];
-    wsum[t] = s;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t x = (t >= d) ? wsum[t - d] : 0;
-        __syncthreads();
-        wsum[t] += x;
-        __syncthreads();
-    }
-    uint32_t run = lo + wsum[t] - s, cmax = 0;
+    uint32_t all;
+    uint32_t run = lo + block_scan_1024(s, wsum, all) - s, cmax = 0;
     for (uint32_t i = b0; i < b1; i++) {
         const uint32_t c = h[i];
         offsets[((uint64_t)q << lbits) + i] = run;
@@ -523,15 +518,8 @@ __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__
             __syncthreads();
             uint32_t ts_sum = 0;
             for (uint32_t i = b0; i < b1; i++) ts_sum += th[i];
-            wsum[t] = ts_sum;
-            __syncthreads();
-            for (uint32_t d = 1; d < 1024; d <<= 1) {
-                uint32_t x = (t >= d) ? wsum[t - d] : 0;
-                __syncthreads();
-                wsum[t] += x;
-                __syncthreads();
-            }
-            uint32_t trun = wsum[t] - ts_sum;
+            uint32_t tile_all;
+            uint32_t trun = block_scan_1024(ts_sum, wsum, tile_all) - ts_sum;
             if (t == 0) nlong = 0;
             __syncthreads();
             for (uint32_t i = b0; i < b1; i++) {
