@@ -493,16 +493,26 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
     HIPCHK(ctx, L.carry_key.ensure((size_t)nchunks * 4));
     uint32_t* max_len_d = L.flags() + 2;
     uint32_t* max_len_h = reinterpret_cast<uint32_t*>(L.pin + PIN_MAXLEN);
+    auto sort_and_publish = [&](bool fast_mode, bool ws_clean) {
+        static const bool separate = getenv("KZG_SORT_SEPARATE_TAIL") != nullptr;   // A/B knob: the two extra launches
+        const SortTail tail{(uint32_t)sh.chunk, L.bufA.as<g1_xyzz_t>(), reinterpret_cast<uint32_t*>(L.pin_dev + PIN_MAXLEN),
+                            reinterpret_cast<uint32_t*>(L.pin_dev + PIN_SEQ_SORT), ++L.sort_seq};
+        launch_msm_sort(s, sh, scalars, mont, scalars2, mont2, L.hist.as<uint32_t>(), ws_clean, L.rank.as<uint2>(),
+                        L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(), max_len_d, fast_mode, max_len_d + 1,
+                        separate ? nullptr : &tail);
+        if (separate) {
+            launch_fold_maxlen(s, L.offsets.as<uint32_t>(), sh.nbuckets, (uint32_t)sh.chunk, max_len_d, L.bufA.as<g1_xyzz_t>());
+            launch_publish(s, max_len_d, L.pin_dev + PIN_MAXLEN, 8, nullptr,
+                           reinterpret_cast<uint32_t*>(L.pin_dev + PIN_SEQ_SORT), tail.seq);
+        }
+    };
     {
         Span sp(ctx, L, KZG_T_DIGITS);
-        launch_msm_sort(s, sh, scalars, mont, scalars2, mont2, L.hist.as<uint32_t>(), L.sort_ws_clean, L.rank.as<uint2>(),
-                        L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(), max_len_d, fast, max_len_d + 1);
-        L.sort_ws_clean = true;
         // the longest run of carries decides how many fold steps are launched; it depends on the offsets only, so
-        // its read-back (with the sort's overflow word) completes while the accumulate kernel runs and costs no bubble
-        launch_fold_maxlen(s, L.offsets.as<uint32_t>(), sh.nbuckets, (uint32_t)sh.chunk, max_len_d, L.bufA.as<g1_xyzz_t>());
-        launch_publish(s, max_len_d, L.pin_dev + PIN_MAXLEN, 8, nullptr,
-                       reinterpret_cast<uint32_t*>(L.pin_dev + PIN_SEQ_SORT), ++L.sort_seq);
+        // its read-back (with the sort's overflow word) completes while the accumulate kernel runs and costs no bubble.
+        // The sort's last kernel takes that maximum, marks the empty buckets and publishes both words itself (SortTail).
+        sort_and_publish(fast, L.sort_ws_clean);
+        L.sort_ws_clean = true;
         HIPCHK(ctx, hipEventRecord(L.ev_sorted, s));
     }
     if (acc_wait) HIPCHK(ctx, hipStreamWaitEvent(s, acc_wait, 0));
@@ -525,11 +535,7 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
         L.skew_hint = 16;
         {
             Span sp(ctx, L, KZG_T_DIGITS);
-            launch_msm_sort(s, sh, scalars, mont, scalars2, mont2, L.hist.as<uint32_t>(), true, L.rank.as<uint2>(),
-                            L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(), max_len_d, false, max_len_d + 1);
-            launch_fold_maxlen(s, L.offsets.as<uint32_t>(), sh.nbuckets, (uint32_t)sh.chunk, max_len_d, L.bufA.as<g1_xyzz_t>());
-            launch_publish(s, max_len_d, L.pin_dev + PIN_MAXLEN, 8, nullptr,
-                           reinterpret_cast<uint32_t*>(L.pin_dev + PIN_SEQ_SORT), ++L.sort_seq);
+            sort_and_publish(false, true);
             HIPCHK(ctx, hipEventRecord(L.ev_sorted, s));
         }
         {

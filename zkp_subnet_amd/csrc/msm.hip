@@ -408,6 +408,35 @@ __global__ void __launch_bounds__(1024) k_sort_partition_staged_multi(const uint
     }
 }
 
+// End of k_sort_buckets when it carries the MSM's SortTail (all threads of the workgroup call it): the workgroup's longest
+// carry run goes into *max_len, and the LAST workgroup to arrive (device-scope ticket) hands {max_len, overflow} to the
+// host page and then sets its sequence word -- what a k_publish launch behind the sort did.
+KZG_DEV void sort_tail_publish(const SortTail& tail, uint32_t npart, uint32_t blk_len, uint32_t* max_len,
+                               const uint32_t* overflow, uint32_t* done) {
+    __syncthreads();   // every thread's part of this workgroup is done
+    if (threadIdx.x == 0) {
+        // No fences here: a release fence is a write-back of the XCD's whole L2, which the sort has just filled with
+        // dirty lines -- once per workgroup that cost more than the two launches this replaces (+17 us on a 2^12 row).
+        // Only atomics have to be ordered, and a RETURNED device-scope atomic has been performed: the maximum is waited
+        // for before the ticket is taken, the ticket's value decides who publishes, and the last workgroup reads both
+        // words with device-scope atomic loads.
+        if (blk_len > 1) {
+            const uint32_t old = atomicMax(max_len, blk_len);
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"(old) : "memory");
+        }
+        if (atomicAdd(done, 1u) == npart - 1u) {
+            atomicExch(done, 0u);   // the next sort finds the ticket counter clean
+            const uint32_t ml = __hip_atomic_load(max_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t ov = __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the host page is uncached on the device side: the two words are written through, acknowledged
+            // (vmcnt), and only then the sequence word follows them over the same ordered path
+            __hip_atomic_store(&tail.pin_dst[0], ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&tail.pin_dst[1], ov, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(tail.seq_word, tail.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
 #define SORT_LONG_RUN 256
 #define SORT_STAGE 28672  // 112 KB: one 1024-thread workgroup per CU; fewer, larger partitions keep level 1's runs longer (A/B)
 // one workgroup per partition: LDS histogram of the low bits -> bucket offsets -> scatter inside the partition
@@ -418,8 +447,10 @@ __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__
                                                         int lbits, uint32_t* __restrict__ offsets,
                                                         uint32_t* __restrict__ sorted, uint32_t npart, uint32_t region_cap,
                                                         const uint32_t* __restrict__ overflow,
-                                                        uint32_t* __restrict__ part_cursor) {
+                                                        uint32_t* __restrict__ part_cursor, const SortTail tail,
+                                                        uint32_t* __restrict__ max_len, uint32_t* __restrict__ done) {
     __shared__ uint32_t h[4096];
+    __shared__ uint32_t blk_len;   // longest carry run among this partition's buckets (fused k_fold_maxlen)
     __shared__ uint32_t th[4096];   // per-tile histogram / cursors of the oversized-partition path
     __shared__ uint32_t longb[SORT_STAGE / SORT_LONG_RUN + 1], nlong, maxc;
     __shared__ uint32_t wsum[16];
@@ -433,12 +464,13 @@ __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__
     if (region_cap && *overflow) {
         for (uint32_t i = t; i < nb; i += 1024) offsets[((uint64_t)q << lbits) + i] = 0;
         if (q == npart - 1 && t == 0) offsets[(uint64_t)npart << lbits] = 0;
+        if (tail.buckets) sort_tail_publish(tail, npart, 0u, max_len, overflow, done);
         return;
     }
     // entry e of the output range [lo, hi) lies at parted[e] (exact mode) or at its region's start + (e - lo)
     const uint2* parted = region_cap ? parted_in + ((uint64_t)q * region_cap - lo) : parted_in;
     for (uint32_t i = t; i < nb; i += 1024) h[i] = 0;
-    if (t == 0) maxc = 0;
+    if (t == 0) maxc = blk_len = 0;
     __syncthreads();
     // four independent loads in flight per lane: the loop is otherwise a chain of dependent global-load latencies
     {
@@ -456,14 +488,24 @@ __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__
     uint32_t s = 0;
     for (uint32_t i = b0; i < b1; i++) s += h[i];
     uint32_t all;
-    uint32_t run = lo + block_scan_1024(s, wsum, all) - s, cmax = 0;
+    uint32_t run = lo + block_scan_1024(s, wsum, all) - s, cmax = 0, lmax = 0;
     for (uint32_t i = b0; i < b1; i++) {
         const uint32_t c = h[i];
         offsets[((uint64_t)q << lbits) + i] = run;
         h[i] = run;  // becomes the scatter cursor
+        if (tail.buckets) {   // what k_fold_maxlen does for this bucket
+            if (!c) {
+                uint4* z = reinterpret_cast<uint4*>(&tail.buckets[((uint64_t)q << lbits) + i]);
+#pragma unroll
+                for (int k = 0; k < 14; k++) z[k] = make_uint4(0u, 0u, 0u, 0u);
+            } else {
+                lmax = max(lmax, (run + c - 1u) / tail.chunk - run / tail.chunk);
+            }
+        }
         run += c;
         cmax = max(cmax, c);
     }
+    if (lmax > 1) atomicMax(&blk_len, lmax);
     if (cmax * 4u > hi - lo) atomicMax(&maxc, cmax);   // only a dominant bucket matters (see below)
     if (q == npart - 1 && t == 1023) offsets[(uint64_t)npart << lbits] = hi;
     __syncthreads();
@@ -568,6 +610,7 @@ __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__
             __syncthreads();
         }
     }
+    if (tail.buckets) sort_tail_publish(tail, npart, blk_len, max_len, overflow, done);
 }
 
 // ------------------------------------------------------------------------------------------------ accumulate
@@ -1784,7 +1827,11 @@ static void launch_partition_staged(hipStream_t s, const uint32_t* scalars, cons
 // bases, no overflow possible.  Both leave the partition counts / cursors zero for the next sort.
 void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars, int scalars_mont,
                      const uint32_t* scalars2, int scalars2_mont, uint32_t* part_ws, bool part_ws_clean, uint2* parted,
-                     uint32_t* offsets, uint32_t* sorted, uint32_t* max_len_word, bool fast, uint32_t* overflow_word) {
+                     uint32_t* offsets, uint32_t* sorted, uint32_t* max_len_word, bool fast, uint32_t* overflow_word,
+                     const SortTail* tail) {
+    SortTail tl{0u, nullptr, nullptr, nullptr, 0u};
+    if (tail) tl = *tail;
+    uint32_t* done = part_ws + 3 * SORT_MAXPART + 16;   // k_sort_buckets' ticket counter (zero between sorts)
     SortShape ss;
     sort_shape(sh, scalars2, scalars_mont, scalars2_mont, ss);
     const uint64_t entries = ss.total * (uint64_t)sh.nwin;
@@ -1800,7 +1847,7 @@ void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars,
         launch_partition_staged(s, scalars, ss, sh.lay, spb2, part_base, part_cursor, parted, cap, overflow_word);
         k_sort_part_scan<<<1, 1024, 0, s>>>(part_cursor, npart, cap, part_base, max_len_word, nullptr);
         k_sort_buckets<<<npart, 1024, 0, s>>>(parted, part_base, ss.lbits, offsets, sorted, npart, cap, overflow_word,
-                                              part_cursor);
+                                              part_cursor, tl, max_len_word, done);
         return;
     }
     const uint32_t blocks = nblk(ss.total, ss.spb);
@@ -1811,7 +1858,8 @@ void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars,
         launch_partition_staged(s, scalars, ss, sh.lay, spb2, part_base, part_cursor, parted, 0u, overflow_word);
     else
         k_sort_partition<<<blocks, 256, 0, s>>>(scalars, ss, sh.lay, part_base, part_cursor, parted);
-    k_sort_buckets<<<npart, 1024, 0, s>>>(parted, part_base, ss.lbits, offsets, sorted, npart, 0u, overflow_word, part_cursor);
+    k_sort_buckets<<<npart, 1024, 0, s>>>(parted, part_base, ss.lbits, offsets, sorted, npart, 0u, overflow_word, part_cursor,
+                                          tl, max_len_word, done);
 }
 void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t* table, const uint32_t* offsets,
                            const uint32_t* sorted, g1_xyzz_t* buckets, g1_xyzz_t* carries, uint32_t* carry_key,

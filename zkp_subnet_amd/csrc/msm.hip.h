@@ -41,9 +41,21 @@ struct MsmShape {
 // MSM's fold-depth word, reset here (launch_fold_maxlen accumulates into it).  fast: no count pass, fixed-capacity
 // partition regions (parted must hold msm_sort_parted_entries(sh, true) entries); when a region overflows,
 // *overflow_word is raised, the offsets come out all zero, and the caller reruns with fast = false (which clears the word).
+// tail != null: the sort's last kernel also does what launch_fold_maxlen + launch_publish would do behind it (two launches
+// less in front of the accumulate): marks the empty buckets, takes the maximum of the carry-run lengths into
+// *max_len_word, and the LAST workgroup to finish writes {max_len, overflow} to pin_dst (device-visible host memory) and
+// then `seq` to seq_word.
+struct SortTail {
+    uint32_t chunk;          // sorted entries per accumulate lane
+    g1_xyzz_t* buckets;      // [nbuckets * nbatch]
+    uint32_t* pin_dst;       // two words of the lane's pinned page
+    uint32_t* seq_word;      // the page's sequence word
+    uint32_t seq;
+};
 void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars, int scalars_mont,
                      const uint32_t* scalars2, int scalars2_mont, uint32_t* part_ws, bool part_ws_clean, uint2* parted,
-                     uint32_t* offsets, uint32_t* sorted, uint32_t* max_len_word, bool fast, uint32_t* overflow_word);
+                     uint32_t* offsets, uint32_t* sorted, uint32_t* max_len_word, bool fast, uint32_t* overflow_word,
+                     const SortTail* tail = nullptr);
 bool msm_sort_fast_ok(const MsmShape& sh);
 uint64_t msm_sort_parted_entries(const MsmShape& sh, bool fast);
 // bytes (multiple of 4) from device memory to a device-visible host pointer, by a kernel
