@@ -111,7 +111,7 @@ enum {
 struct Lane {
     int index = 0;
     hipStream_t stream = nullptr;
-    DevBuf rank, sorted, hist, offsets, bufA, bufB, bufC, carries, carry_key;      // MSM workspace
+    DevBuf rank, sorted, hist, offsets, bufA, bufB, bufC, bufD, carries, carry_key;      // MSM workspace
     DevBuf ntt_mid;               // the vector between the passes of an NTT (9 words per element)
     DevBuf gather;                // kzg_msm_sharded_finish: the gathered partials, unpacked (own buffer: the MSM may still run)
     DevBuf in_be, scal, coeffA, coeffB, qbuf, hbuf, hnext, out_be;                 // request buffers
@@ -489,6 +489,7 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
     HIPCHK(ctx, L.bufA.ensure(B * sizeof(g1_xyzz_t) + 16384));
     HIPCHK(ctx, L.bufB.ensure(B * sizeof(g1_xyzz_t) / 2 + 16384));  // level arrays: n/2^L nodes x L components <= B/2
     HIPCHK(ctx, L.bufC.ensure(B * sizeof(g1_xyzz_t) / 2 + 16384));
+    HIPCHK(ctx, L.bufD.ensure((size_t)(LP_MAX_OPS + 64) * sizeof(g1_xyzz_t) + 16384));   // fourth buffer of the two-level launches
     HIPCHK(ctx, L.carries.ensure((size_t)nchunks * sizeof(g1_xyzz_t)));
     HIPCHK(ctx, L.carry_key.ensure((size_t)nchunks * 4));
     uint32_t* max_len_d = L.flags() + 2;
@@ -561,12 +562,27 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
     {
         Span sp(ctx, L, KZG_T_TREE);
         uint32_t n_in = sh.nbuckets;
-        for (int level = 0; n_in > (uint32_t)nbatch; level++, n_in >>= 1) {
+        g1_xyzz_t* extra = L.bufD.as<g1_xyzz_t>();
+        for (int level = 0; n_in > (uint32_t)nbatch;) {
+            if ((n_in >> 2) >= (uint32_t)nbatch && msm_tree_level2_ok(n_in, level)) {
+                // two narrow levels per launch: the level + 1 P array goes to `out`, the level + 2 array to `extra`
+                launch_msm_tree_level2(s, in, prev, out, extra, n_in, level);
+                g1_xyzz_t *old_in = in, *old_prev = prev;
+                in = extra;
+                prev = out;
+                out = old_prev;
+                extra = old_in;
+                level += 2;
+                n_in >>= 2;
+                continue;
+            }
             launch_msm_tree_level(s, in, prev, out, n_in, level);
             g1_xyzz_t* recycled = prev;
             prev = in;
             in = out;
             out = recycled;
+            level++;
+            n_in >>= 1;
         }
     }
     {
@@ -1048,7 +1064,7 @@ void kzg_destroy(kzg_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (Lane& L : ctx->lane) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
-        for (DevBuf* b : {&L.rank, &L.sorted, &L.hist, &L.offsets, &L.bufA, &L.bufB, &L.bufC, &L.carries, &L.carry_key,
+        for (DevBuf* b : {&L.rank, &L.sorted, &L.hist, &L.offsets, &L.bufA, &L.bufB, &L.bufC, &L.bufD, &L.carries, &L.carry_key,
                           &L.in_be, &L.scal, &L.coeffA, &L.coeffB, &L.qbuf, &L.hbuf, &L.hnext, &L.out_be, &L.ntt_mid, &L.gather})
             b->release();
         for (hipEvent_t e : L.ev_pool) (void)hipEventDestroy(e);

@@ -1112,6 +1112,37 @@ __global__ void __launch_bounds__(64) k_msm_tree_level_lp(const g1_xyzz_t* __res
     tree_operands(in, prev, n_in, level, c, m, pa, pb);
     lp_add(sm, &out[(uint64_t)c * n_out + m], pa, pb, k);
 }
+// TWO consecutive narrow levels in one launch (a short row's tail is a chain of ~6-us launches of which the addition is
+// 2 us): a 2-wave workgroup per (component c, node j of level + 2).  Wave w merges the pair (2j + w) of level `level`
+// into LDS, a barrier, wave 0 merges the two results.  Component level + 1 is born at the second merge (T_{level} of a
+// level + 2 node = P[4j + 1] + P[4j + 3] of `in`): one addition by wave 0.  Only the P array of the skipped level is kept
+// (mid_p, n_in / 2 nodes): the merge after the next reads its odd entries.
+__global__ void __launch_bounds__(128) k_msm_tree_level2_lp(const g1_xyzz_t* __restrict__ in,
+                                                             const g1_xyzz_t* __restrict__ prev,
+                                                             g1_xyzz_t* __restrict__ mid_p, g1_xyzz_t* __restrict__ out,
+                                                             uint32_t n_in, int level) {
+    tail_priority();
+    __shared__ LpScratch sm[2];
+    __shared__ __align__(16) g1_xyzz_t mid[2];
+    const LpLane k = lp_lane();
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t n2 = n_in >> 2;
+    const uint32_t c = blockIdx.x / n2, j = blockIdx.x - c * n2;   // c in [0, level + 1]
+    const bool late = c == (uint32_t)level + 1u;
+    g1_xyzz_t* dst = &out[(uint64_t)c * n2 + j];
+    if (late) {
+        if (w == 0) lp_add(sm[0], dst, &in[4 * (uint64_t)j + 1], &in[4 * (uint64_t)j + 3], k);
+    } else {
+        const g1_xyzz_t *pa, *pb;
+        tree_operands(in, prev, n_in, level, c, 2 * j + w, pa, pb);
+        lp_add(sm[w], &mid[w], pa, pb, k);
+    }
+    __syncthreads();
+    if (late) return;
+    if (c == 0 && threadIdx.x < 112)
+        reinterpret_cast<uint32_t*>(&mid_p[2 * (uint64_t)j])[threadIdx.x] = reinterpret_cast<const uint32_t*>(mid)[threadIdx.x];
+    if (w == 0) lp_add(sm[0], dst, &mid[0], &mid[1], k);
+}
 // P + sum_i 2^i T_i for `nodes` roots, two launches.  (1) k_msm_final_dbl_lp: one wave per (root m, component l):
 // pts[m][l] = 2^l T_l (l doublings; the P entry, index nbits, is copied) -- the chains run on different SIMDs, the
 // longest (nbits - 1 doublings, ~1.4 us each) sets the time.  (2) k_msm_final_sum_lp: tree sum of the nbits + 1 points of
@@ -1910,6 +1941,19 @@ void launch_msm_tree_level(hipStream_t s, const g1_xyzz_t* in, const g1_xyzz_t* 
     else if (ops <= LP_MAX_OPS) k_msm_tree_level_lp<<<ops, 64, 0, s>>>(in, prev, out, n_in_nodes, level);
 #endif
     else k_msm_tree_level_coop<<<nblk(ops, 64), 256, 0, s>>>(in, prev, out, n_in_nodes, level);
+}
+bool msm_tree_level2_ok(uint32_t n_in_nodes, int level) {
+#if defined(KZG_NO_LP) || defined(KZG_NO_TREE_PAIRS)
+    (void)n_in_nodes; (void)level;
+    return false;
+#else
+    static const bool off = getenv("KZG_TREE_NO_PAIRS") != nullptr;   // A/B knob
+    return !off && n_in_nodes >= 4 && (n_in_nodes >> 1) * (uint32_t)(level + 1) <= LP_MAX_OPS;
+#endif
+}
+void launch_msm_tree_level2(hipStream_t s, const g1_xyzz_t* in, const g1_xyzz_t* prev, g1_xyzz_t* mid_p, g1_xyzz_t* out,
+                            uint32_t n_in_nodes, int level) {
+    k_msm_tree_level2_lp<<<(n_in_nodes >> 2) * (uint32_t)(level + 2), 128, 0, s>>>(in, prev, mid_p, out, n_in_nodes, level);
 }
 void launch_msm_final(hipStream_t s, const g1_xyzz_t* node, const g1_xyzz_t* prev, int nbits, int nodes,
                       g1_xyzz_t* out_xyzz, g1_xyzz_t* scratch) {

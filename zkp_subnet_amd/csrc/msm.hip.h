@@ -81,6 +81,12 @@ void launch_fold_heads(hipStream_t s, const uint32_t* offsets, const uint32_t* c
 // level + 1 array.  in, prev and out must be three different buffers.
 void launch_msm_tree_level(hipStream_t s, const g1_xyzz_t* in, const g1_xyzz_t* prev, g1_xyzz_t* out,
                            uint32_t n_in_nodes, int level);
+// two merge levels in one launch (narrow levels only: msm_tree_level2_ok): `out` = the level + 2 array, `mid_p` = the P
+// array of level + 1 (n_in_nodes / 2 nodes; the next merge's `prev`).  in, prev, mid_p and out: four different buffers;
+// mid_p and out need (LP_MAX_OPS + 64) points at most.
+bool msm_tree_level2_ok(uint32_t n_in_nodes, int level);
+void launch_msm_tree_level2(hipStream_t s, const g1_xyzz_t* in, const g1_xyzz_t* prev, g1_xyzz_t* mid_p, g1_xyzz_t* out,
+                            uint32_t n_in_nodes, int level);
 // node = [P, T_0 .. T_{nbits-1}] ; out_xyzz = P + sum 2^i T_i
 // nodes: the bucket tree stopped at `nodes` roots (component-major: component k of root m at node[k * nodes + m];
 // T_{nbits-1} of root m is P[2m + 1] of the level below, `prev`); out_xyzz[m] = P_m + sum_i 2^i T_{i,m}
