@@ -549,11 +549,16 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
     }
     {
         Span sp(ctx, L, KZG_T_FIXUP);
-        for (uint32_t d = 1; d < *max_len_h; d <<= 1)
-            launch_fold_step(s, L.offsets.as<uint32_t>(), L.carry_key.as<uint32_t>(), (uint32_t)sh.chunk, nchunks, d,
-                             L.carries.as<g1_xyzz_t>());
-        launch_fold_heads(s, L.offsets.as<uint32_t>(), L.carry_key.as<uint32_t>(), (uint32_t)sh.chunk, nchunks,
-                          L.carries.as<g1_xyzz_t>(), L.bufA.as<g1_xyzz_t>());
+        if (nchunks && msm_fold_bucket_ok(sh.nbuckets, *max_len_h)) {
+            launch_fold_bucket(s, L.offsets.as<uint32_t>(), (uint32_t)sh.chunk, sh.nbuckets, L.carries.as<g1_xyzz_t>(),
+                               L.bufA.as<g1_xyzz_t>());
+        } else {
+            for (uint32_t d = 1; d < *max_len_h; d <<= 1)
+                launch_fold_step(s, L.offsets.as<uint32_t>(), L.carry_key.as<uint32_t>(), (uint32_t)sh.chunk, nchunks, d,
+                                 L.carries.as<g1_xyzz_t>());
+            launch_fold_heads(s, L.offsets.as<uint32_t>(), L.carry_key.as<uint32_t>(), (uint32_t)sh.chunk, nchunks,
+                              L.carries.as<g1_xyzz_t>(), L.bufA.as<g1_xyzz_t>());
+        }
     }
     // three buffers in rotation: a level reads its own array and the P array of the level below, writes the next
     g1_xyzz_t* in = L.bufA.as<g1_xyzz_t>();

@@ -1081,6 +1081,31 @@ __global__ void __launch_bounds__(64) k_fold_step_lp(const uint32_t* __restrict_
     lp_add(sm, &carries[t], &carries[t], &carries[t + d], lp_lane());
 }
 
+// Short rows (few buckets, short carry runs): ONE launch instead of ceil(log2 max run) fold steps + the heads -- one wave
+// per BUCKET adds its carries (chunks t0 + 1 .. t1 of its run: every one of them begins inside the run, so each holds a
+// carry of this bucket) one after the other and then the sum to the bucket.  Serial in the run length, hence only
+// behind the host's check of the fold-depth word (msm_fold_bucket_ok); a 2^12 row has <= 4096 buckets of ~5 carries.
+__global__ void __launch_bounds__(64) k_fold_bucket_lp(const uint32_t* __restrict__ offsets, uint32_t chunk,
+                                                        const g1_xyzz_t* __restrict__ carries,
+                                                        g1_xyzz_t* __restrict__ buckets) {
+    tail_priority();
+    __shared__ LpScratch sm;
+    __shared__ __align__(16) g1_xyzz_t acc;
+    const uint32_t b = blockIdx.x;
+    const uint32_t lo = offsets[b], hi = offsets[b + 1];
+    if (hi == lo) return;
+    const uint32_t t0 = lo / chunk, t1 = (hi - 1u) / chunk;
+    if (t1 == t0) return;
+    const LpLane k = lp_lane();
+    const g1_xyzz_t* src = &carries[t0 + 1];
+    for (uint32_t t = t0 + 2; t <= t1; t++) {
+        lp_add(sm, &acc, src, &carries[t], k);
+        lp_sync();
+        src = &acc;
+    }
+    lp_add(sm, &buckets[b], &buckets[b], src, k);
+}
+
 // same merge as k_msm_tree_level, 64 operations per 256-thread workgroup, for the narrow (latency-bound) levels
 __global__ void __launch_bounds__(256) k_msm_tree_level_coop(const g1_xyzz_t* __restrict__ in,
                                                               const g1_xyzz_t* __restrict__ prev,
@@ -1919,6 +1944,25 @@ void launch_fold_step(hipStream_t s, const uint32_t* offsets, const uint32_t* ca
     else if (nchunks / (2 * d) <= KZG_FOLD_LP_MAX) k_fold_step_lp<<<nchunks, 64, 0, s>>>(offsets, carry_key, chunk, d, carries);
 #endif
     else k_fold_step_coop<<<nblk(nchunks, 64), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, d, carries);
+}
+#ifndef KZG_FOLD_BUCKET_MAX
+#define KZG_FOLD_BUCKET_MAX 4096   // buckets (one wave each)
+#endif
+#ifndef KZG_FOLD_BUCKET_RUN
+#define KZG_FOLD_BUCKET_RUN 24     // carries of the longest run: the chain one wave walks
+#endif
+bool msm_fold_bucket_ok(uint32_t nbuckets, uint32_t max_run) {
+#if defined(KZG_NO_LP) || defined(KZG_NO_FOLD_LP)
+    (void)nbuckets; (void)max_run;
+    return false;
+#else
+    static const bool off = getenv("KZG_FOLD_NO_BUCKET") != nullptr;   // A/B knob
+    return !off && nbuckets <= KZG_FOLD_BUCKET_MAX && max_run <= KZG_FOLD_BUCKET_RUN;
+#endif
+}
+void launch_fold_bucket(hipStream_t s, const uint32_t* offsets, uint32_t chunk, uint32_t nbuckets, const g1_xyzz_t* carries,
+                        g1_xyzz_t* buckets) {
+    if (nbuckets) k_fold_bucket_lp<<<nbuckets, 64, 0, s>>>(offsets, chunk, carries, buckets);
 }
 void launch_fold_heads(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
                        uint32_t nchunks, const g1_xyzz_t* carries, g1_xyzz_t* buckets) {

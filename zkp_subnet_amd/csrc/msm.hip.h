@@ -71,6 +71,11 @@ void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t*
 // (also marks the empty buckets as infinity: the bucket array needs no memset)
 void launch_fold_maxlen(hipStream_t s, const uint32_t* offsets, uint32_t nbuckets, uint32_t chunk, uint32_t* max_len,
                         g1_xyzz_t* buckets);
+// short rows: the whole fold (steps + heads) as ONE launch, one wave per bucket walking its run of carries; only when
+// msm_fold_bucket_ok(buckets, longest run as published by the sort) -- the chain is serial in the run length
+bool msm_fold_bucket_ok(uint32_t nbuckets, uint32_t max_run);
+void launch_fold_bucket(hipStream_t s, const uint32_t* offsets, uint32_t chunk, uint32_t nbuckets, const g1_xyzz_t* carries,
+                        g1_xyzz_t* buckets);
 void launch_fold_step(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
                       uint32_t nchunks, uint32_t d, g1_xyzz_t* carries);
 void launch_fold_heads(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
