@@ -1840,6 +1840,14 @@ static void sort_shape(const MsmShape& sh, const uint32_t* scalars2, int scalars
     // level 2 can stage in LDS (SORT_STAGE entries; ~13 k on average at 2^20 / 1024, ~27 k at 2^22 / 2048 and 2^23 / 4096)
     const uint64_t entries = ss.total * (uint64_t)sh.nwin;
     int hbits = 10;
+    // short inputs: fewer partitions (down to 64) as long as one holds < 4096 entries --
+    // 1024 workgroups of 1024 threads for ~200 entries each were four rounds of launch overhead (A/B knob KZG_SORT_MIN_HBITS)
+    static const int min_hbits = [] {
+        const char* e = getenv("KZG_SORT_MIN_HBITS");
+        const int v = e ? atoi(e) : 6;
+        return v < 4 ? 4 : v > 10 ? 10 : v;
+    }();
+    while (hbits > min_hbits && (entries >> hbits) < 4096) hbits--;
     while (hbits < 12 && (entries >> hbits) > 24576) hbits++;
     if (hbits > keybits) hbits = keybits;
     if (keybits - hbits > 12) hbits = keybits - 12;  // level 2 histograms at most 4096 buckets
