@@ -404,8 +404,11 @@ void spec_window(TableSpec& sp, int c) {
 // lanes (2 waves per SIMD on 256 CUs: the second wave hides the point loads) so that the last round is not a partially
 // filled tail; chunks stay <= 512 entries.  Small MSMs (latency-bound: one wave already saturates a SIMD's integer
 // issue, ~10.5 us per mixed addition): 65536 lanes = one wave per SIMD, which halves the number of carries to fold.
+// (the shortest chunk: 8 until the short rows' fold became one launch that is linear in the carries per bucket; with it
+// 6 is the optimum -- 2^12 row 0.334 -> 0.328 ms, 2^10 0.275 -> 0.268; 4 gives the fold back what the accumulate gains:
+// `profiles/r03_ab_min_chunk.log`)
 #ifndef KZG_MIN_CHUNK
-#define KZG_MIN_CHUNK 8
+#define KZG_MIN_CHUNK 6
 #endif
 int pick_chunk(uint64_t entries) {
     const uint64_t lanes = 131072;
