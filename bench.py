@@ -314,6 +314,68 @@ def dist_extra_workloads(args, torch, dist, HipEngine, lagrange_factor, rank, lo
     return res
 
 
+def visible_gpus():
+    """Devices a rank could be given, counted in a throw-away child (`torch.cuda.device_count()` honours
+    HIP_/ROCR_/CUDA_VISIBLE_DEVICES and does not create a HIP context); None when the count cannot be taken."""
+    import subprocess
+
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                             capture_output=True, text=True, timeout=600)
+        return int(out.stdout.strip().splitlines()[-1])
+    except (OSError, ValueError, IndexError, subprocess.TimeoutExpired):
+        return None
+
+
+def free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """The N > 1 launch line of the bench contract (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py <same args>`) run as a child process; returns its exit code."""
+    import subprocess
+
+    one_gpu = os.environ.get("BENCH_ONE_GPU") == "1"       # self-test: every rank on device 0 (gloo)
+    have = 1 if one_gpu else visible_gpus()
+    if not one_gpu and have is not None and n > have:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible to this process "
+              "(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES respected)", file=sys.stderr)
+        return 2
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this pool
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    last_json = None
+    try:
+        for line in proc.stdout:
+            if line.lstrip().startswith("{") and '"metric"' in line:
+                last_json = line                           # held back: printed after everything else the ranks wrote
+            else:
+                sys.stdout.write(line)
+        rc = proc.wait()
+    except BaseException:
+        proc.terminate()                                   # the exact child we started, never a pattern
+        try:
+            proc.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+        raise
+    if last_json is not None:
+        sys.stdout.write(last_json if last_json.endswith("\n") else last_json + "\n")
+    sys.stdout.flush()
+    if rc == 0 and last_json is None:
+        print("bench.py: the ranks exited cleanly but printed no result line", file=sys.stderr)
+        return 3
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -348,9 +410,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` with no launcher: start the driver's own launch line as a CHILD and relay it.  Nothing
+        # in this parent has touched torch or HIP (a process that has initialised the GPU must never be replaced or forked
+        # into ranks); the child is fresh, its stdout is relayed line by line so the JSON line stays the last one.
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
 
     import torch
@@ -558,6 +623,16 @@ def main():
             dist.all_gather_into_tensor(allr, src)
             allr = allr.cpu().numpy().tobytes()
             assert all(allr[48 * i:48 * i + 48] == results[0] for i in range(world)), "ranks disagree on the MSM result"
+    # inputs of the CPU baseline (rank 0, every N): a bounded sample of THIS rank's segment and the GPU's answer on it,
+    # taken before the engine is closed; the CPU itself is timed after every timed region of the launch
+    cpu_in = None
+    if rank == 0 and not args.no_cpu_baseline:
+        if is_msm:
+            m = 1 << min(args.cpu_sample_log, lg)
+            cpu_in = (m, eng.srs_read(0, m), eng.msm(scal[: 32 * m], 0))
+        else:
+            m = min(n, 1 << 17)
+            cpu_in = (m, eng.srs_read(0, m), results[0] if m == n else eng.commit_open(0, scal[: 32 * m], alpha, True))
     if use_dist and args.workload == "msm20" and not args.no_dist_extra:
         # free this workload's tables first (2^26 / world points per rank come next); rank 0 needs nothing more from `eng`
         eng.close()
@@ -667,46 +742,63 @@ def main():
                     eng.msm_resident(1, n, 0)
                 adv[name] = {"ms_per_msm": round((time.perf_counter() - ta) / 5 * 1e3, 4)}
             out["adversarial"] = adv
-        # ---- CPU baseline: the oracle's C port on a bounded sample of the same inputs
+        # ---- CPU baseline: the oracle's C port on a bounded sample of the same inputs (rank 0's segment when N > 1)
         threads = thread_counts(args.cpu_threads)
-        if not args.no_cpu_baseline and world == 1:
+        if cpu_in is not None:
             from oracle import cpu as oc     # the checker / reported baseline: only this leg touches oracle/
 
             oc.build()
             threads = thread_counts(args.cpu_threads, oc.usable_cpus())
-        if world == 1 and not args.no_cpu_baseline and is_msm and eng is not None:
-            from oracle import cpu as oc
-
-            m = 1 << min(args.cpu_sample_log, lg)
-            srs = eng.srs_read(0, m)
-            per = {}
-            cpu_res = None
-            for th in threads:
-                mm = m if th > 1 else min(m, 1 << 18)          # one thread: 2^18 points (~1-2 s)
-                prep = oc.PreparedMsm(srs[: 96 * mm], scal[: 32 * mm])
-                tc = time.perf_counter()
-                r = prep.run(th)
-                per[th] = (mm, time.perf_counter() - tc)
-                prep.close()
-                if mm == m:
-                    cpu_res = r
-            if cpu_res is None:
-                cpu_res = oc.msm(srs, scal[: 32 * m], threads=max(threads))
-            gpu_same = eng.msm(scal[: 32 * m], 0)
-            rates = {th: mm / s for th, (mm, s) in per.items()}
-            best = max(rates, key=rates.get)
-            out["cpu_baseline"] = {
-                "value": rates[best], "unit": "points/s", "cores": best, "kind": "port",
-                "sample": f"first 2^{m.bit_length() - 1} points/scalars of the same workload, one Pippenger MSM split over "
-                          f"the threads ({host_cores()} host cores visible, {oc.usable_cpus()} usable under the cgroup quota, "
-                          f"{cpu_model()}); points/s by thread count: "
-                          + ", ".join(f"{th}: {r:.0f} (2^{per[th][0].bit_length() - 1} pts, {per[th][1]:.2f} s)"
-                                      for th, r in sorted(rates.items())),
-                "points_per_s_by_threads": {str(th): r for th, r in sorted(rates.items())},
-                "single_thread_points_per_s": rates.get(1),
-                "matches_gpu_bit_exact": cpu_res == gpu_same,
-            }
-            assert cpu_res == gpu_same, "GPU MSM differs from the CPU oracle on the baseline sample"
+            m, srs, gpu_same = cpu_in
+            where = "" if world == 1 else f" of rank 0's segment (the other {world - 1} rank(s) idle at a barrier meanwhile)"
+            hw = (f"{host_cores()} host cores visible, {oc.usable_cpus()} usable under the cgroup quota, {cpu_model()}")
+            if is_msm:
+                per = {}
+                cpu_res = None
+                for th in threads:
+                    mm = m if th > 1 else min(m, 1 << 18)          # one thread: 2^18 points (~1-2 s)
+                    prep = oc.PreparedMsm(srs[: 96 * mm], scal[: 32 * mm])
+                    tc = time.perf_counter()
+                    r = prep.run(th)
+                    per[th] = (mm, time.perf_counter() - tc)
+                    prep.close()
+                    if mm == m:
+                        cpu_res = r
+                if cpu_res is None:
+                    cpu_res = oc.msm(srs, scal[: 32 * m], threads=max(threads))
+                rates = {th: mm / s for th, (mm, s) in per.items()}
+                best = max(rates, key=rates.get)
+                out["cpu_baseline"] = {
+                    "value": rates[best], "unit": "points/s", "cores": best, "kind": "port",
+                    "sample": f"first 2^{m.bit_length() - 1} points/scalars of the same workload{where}, one Pippenger MSM "
+                              f"split over the threads ({hw}); points/s by thread count: "
+                              + ", ".join(f"{th}: {r:.0f} (2^{per[th][0].bit_length() - 1} pts, {per[th][1]:.2f} s)"
+                                          for th, r in sorted(rates.items())),
+                    "points_per_s_by_threads": {str(th): r for th, r in sorted(rates.items())},
+                    "single_thread_points_per_s": rates.get(1),
+                    "matches_gpu_bit_exact": cpu_res == gpu_same,
+                }
+                assert cpu_res == gpu_same, "GPU MSM differs from the CPU oracle on the baseline sample"
+            else:
+                sample = scal[: 32 * m]
+                per = {}
+                cpu_res = None
+                for th in threads:
+                    if th == 1 and m > (1 << 14):
+                        continue             # one thread on a long row would take minutes
+                    tc = time.perf_counter()
+                    c = oc.commit(srs, sample, True, threads=th)
+                    ev, pf = oc.open_(srs, sample, alpha, True, threads=th)
+                    per[th] = time.perf_counter() - tc
+                    cpu_res = (c, ev, pf)
+                best = min(per, key=per.get)
+                out["cpu_baseline"] = {
+                    "value": m / per[best], "unit": "coefficients/s", "cores": best, "kind": "port",
+                    "sample": f"commit+open of the first 2^{m.bit_length() - 1} coefficients of the same row{where} "
+                              f"(oracle/kzg_cpu.c; {hw}); seconds by thread count: "
+                              + ", ".join(f"{th}: {s:.3f}" for th, s in sorted(per.items())),
+                    "matches_gpu_bit_exact": cpu_res == tuple(gpu_same)}
+                assert cpu_res == tuple(gpu_same), "GPU commit+open differs from the CPU oracle on the baseline sample"
         if dist_extra:
             out.update(dist_extra)      # `msm26` (configs[3]) and `pianist_kzg22` (configs[4]) of the same launch
         if eng is not None:

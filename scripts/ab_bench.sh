@@ -5,11 +5,8 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 ARGS=${1:---headline-only --steps 15}
 ROUNDS=${2:-3}
-cp zkp_subnet_amd/libkzg_mi355x.so /tmp/_orig.so
 for r in $(seq $ROUNDS); do
   for v in ${VARIANTS:-A B}; do
-    cp zkp_subnet_amd/ab/$v.so zkp_subnet_amd/libkzg_mi355x.so
-    echo -n "$v "; python bench.py $ARGS 2>&1 | tail -1 | grep -o "ms_per_step[^,]*\|\"accumulate[^,]*\|\"digits[^,]*\|\"tree[^,]*\|single_request_latency_ms[^,]*\|pipelined\": {[^}]*}" | tr "\n" " "; echo
+    echo -n "$v "; KZG_MI355X_LIB=$PWD/zkp_subnet_amd/ab/$v.so python bench.py $ARGS 2>&1 | tail -1 | grep -o "ms_per_step[^,]*\|\"accumulate[^,]*\|\"digits[^,]*\|\"tree[^,]*\|single_request_latency_ms[^,]*\|pipelined\": {[^}]*}" | tr "\n" " "; echo
   done
 done
-cp /tmp/_orig.so zkp_subnet_amd/libkzg_mi355x.so

@@ -2,11 +2,9 @@
 # Same-box A/B of two library builds on the commit+open rows and the headline MSM (see scripts/ab_bench.sh).
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 ROUNDS=${1:-2}
-cp zkp_subnet_amd/libkzg_mi355x.so /tmp/_orig.so
 for r in $(seq $ROUNDS); do
   for v in ${VARIANTS:-A B}; do
-    cp zkp_subnet_amd/ab/$v.so zkp_subnet_amd/libkzg_mi355x.so
-    python bench.py --no-adversarial --no-cpu-baseline --no-pipelined --steps 20 --kzg-rows ${ROWS:-22,20,16,12} 2>/dev/null | tail -1 | python -c "
+    KZG_MI355X_LIB=$PWD/zkp_subnet_amd/ab/$v.so python bench.py --no-adversarial --no-cpu-baseline --no-pipelined --steps 20 --kzg-rows ${ROWS:-22,20,16,12} 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 s=d['stages_ms']
@@ -14,4 +12,3 @@ print('$v msm20 %.3f ms  acc %.3f tree %.3f final %.3f digits %.3f |' % (d['ms_p
 "
   done
 done
-cp /tmp/_orig.so zkp_subnet_amd/libkzg_mi355x.so

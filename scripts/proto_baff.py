@@ -1,5 +1,5 @@
 """A/B of the batched-affine prototype (csrc/baff_proto.hip) against k_msm_accumulate on the same sorted entries
-(dev tool; needs the GPU and a library built with `KZG_WITH_PROTO=1 python -m zkp_subnet_amd.build`).  Prints one JSON line per (size, lanes).   python scripts/proto_baff.py [log2_n ...]"""
+(dev tool; needs the GPU and `KZG_WITH_PROTO=1 python -m zkp_subnet_amd.build`, then KZG_MI355X_LIB=zkp_subnet_amd/libkzg_mi355x_proto.so).  Prints one JSON line per (size, lanes).   python scripts/proto_baff.py [log2_n ...]"""
 import ctypes
 import json
 import os

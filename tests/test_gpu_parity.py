@@ -1268,12 +1268,29 @@ def test_bench_two_ranks_on_one_gpu_exercises_the_multi_rank_logic(hip):
     from zkp_subnet_amd.engine import lagrange_factor
 
     env = dict(os.environ, BENCH_ONE_GPU="1", BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    args = ["--gpus", "2", "--log-n", "13", "--steps", "3", "--warmup", "1", "--msm26-log", "15", "--kzg22-log", "11",
+            "--cpu-sample-log", "12"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29561", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-n", "13", "--steps", "3",
-           "--warmup", "1", "--msm26-log", "15", "--kzg22-log", "11"]
+           "--master-port", "29561", os.path.join(ROOT, "bench.py")] + args
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][-1])
+    # ... and the SAME line from `python bench.py --gpus 2` with NO launcher: the parent starts that launch line itself
+    # as a child before anything touches the GPU, relays it, and the JSON line is the last line of stdout
+    env2 = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                          timeout=900, cwd=ROOT, env=env2)
+    assert out2.returncode == 0, out2.stderr[-3000:]
+    rec2 = json.loads([ln for ln in out2.stdout.splitlines() if ln.strip()][-1])
+    assert rec2["n_gpus"] == 2 and rec2["config"]["world_size"] == 2
+    for k in ("result_hex", "metric", "unit", "scaling", "steps", "warmup"):
+        assert rec2[k] == rec[k], k
+    assert rec2["msm26"]["result_hex"] == rec["msm26"]["result_hex"]
+    assert rec2["pianist_kzg22"]["results_hex_by_rank"] == rec["pianist_kzg22"]["results_hex_by_rank"]
+    for r_ in (rec, rec2):                          # rule (d) on an N > 1 line: roofline AND cpu_baseline
+        cb = r_["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["matches_gpu_bit_exact"] is True
+        assert r_["roofline"]["achieved"] > 0
     assert rec["n_gpus"] == 2 and rec["config"]["world_size"] == 2 and rec["scaling"] == "weak"
     assert abs(rec["value"] - 2 * (1 << 13) * 3 / (rec["ms_per_step"] * 3e-3)) / rec["value"] < 1e-6
     e = hip()

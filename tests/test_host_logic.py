@@ -3,6 +3,7 @@ validator mirrors, and the config-1 plumbing loop (degree-2^12 commit through th
 miner/validator loop, BASELINE.json configs[0]).  The engine is the oracle-backed stand-in (tests/oracle_engine.py);
 the same tests run against the HIP engine in tests/test_gpu_parity.py."""
 import base64
+import os
 import random
 
 import pytest
@@ -269,3 +270,32 @@ def test_native_random_rows_and_fused_challenge_step_match_the_two_call_form():
     got = verify_all(c, ch, responses, threads=3)
     assert got == [True, True, True, False] == [reward(c, ch, responses[i], i, 0.0) > 0 for i in range(4)]
     assert verify_all(c, ch, [None, responses[1]], threads=1) == [False, True]
+    # one MALFORMED miner answer (not base64 / wrong length / not a curve point) is an invalid row, not an exception that
+    # loses the whole step's results
+    for bad in ("not-base64!!", responses[1].proof[:-4], base64.b64encode(b"\xff" * 48).decode()):
+        resp = list(responses[:3]) + [responses[3].model_copy(update={"commitment": responses[3].commitment})]
+        resp[1] = resp[1].model_copy(update={"proof": bad})
+        assert verify_all(c, ch, resp, threads=3) == [True, False, True, False], bad
+        assert verify_all(c, ch, resp, threads=1) == [True, False, True, False], bad
+
+
+def test_bench_gpus_n_without_a_launcher_self_launches_or_refuses_cleanly():
+    """`python bench.py --gpus N` (N > 1, no torch.distributed.run in front) must never end in a bare SystemExit: more
+    ranks than visible GPUs -> rc 2 with a message; otherwise the parent starts the launch line as a child and returns
+    ITS exit code (here the ranks stop because this container has no GPU)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_ONE_GPU")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "1"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 2 and "GPU(s) are visible" in out.stderr, (out.returncode, out.stderr[-500:])
+    import torch
+
+    if torch.cuda.device_count() == 0:              # the relay path: ranks are started, fail, and the code comes back
+        env["BENCH_ONE_GPU"] = "1"
+        env["BENCH_BACKEND"] = "gloo"
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
+                             capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode not in (0, 2) and "needs an MI355X" in out.stderr, (out.returncode, out.stderr[-500:])

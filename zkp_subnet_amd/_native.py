@@ -6,7 +6,9 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libkzg_mi355x.so")
+# KZG_MI355X_LIB: another BUILD of the same library (A/B candidates under zkp_subnet_amd/ab/, the prototype build): dev
+# scripts point at it instead of overwriting the shipped file.  Never a different implementation, never a fallback.
+LIB_PATH = os.environ.get("KZG_MI355X_LIB") or os.path.join(HERE, "libkzg_mi355x.so")
 
 KZG_OK, KZG_E_ARG, KZG_E_SCALAR, KZG_E_POINT, KZG_E_HIP, KZG_E_NOMEM, KZG_E_BUSY = 0, -1, -2, -3, -4, -5, -6
 STATUS_NAMES = {0: "OK", -1: "E_ARG", -2: "E_SCALAR", -3: "E_POINT", -4: "E_HIP", -5: "E_NOMEM", -6: "E_BUSY"}

@@ -54,20 +54,32 @@ def build_wire(force: bool = False) -> str:
 
 
 def build(force: bool = False, extra_flags=()) -> str:
+    """The shipped library.  Objects are rebuilt when a source, a header OR the flag set changes (the flags of the last
+    build are kept in build/flags.stamp).  KZG_WITH_PROTO=1 builds the dev prototypes into their OWN directory and
+    library (build_proto/, libkzg_mi355x_proto.so; load it with KZG_MI355X_LIB=...): it never touches the shipped one."""
     build_wire(force)
     hipcc = _hipcc()
     extra_flags = tuple(extra_flags) + tuple(os.environ.get("KZG_EXTRA_HIPCC_FLAGS", "").split())
-    os.makedirs(OBJ, exist_ok=True)
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
-    jobs = []
     sources = list(SOURCES)
+    obj_dir, lib = OBJ, LIB
     if os.environ.get("KZG_WITH_PROTO") == "1":
         sources += PROTO_SOURCES
         extra_flags += ("-DKZG_WITH_PROTO",)
-        force = True
+        obj_dir, lib = os.path.join(HERE, "build_proto"), os.path.join(HERE, "libkzg_mi355x_proto.so")
+    os.makedirs(obj_dir, exist_ok=True)
+    stamp = os.path.join(obj_dir, "flags.stamp")
+    flag_key = " ".join([*FLAGS, *extra_flags])
+    try:
+        with open(stamp) as f:
+            if f.read() != flag_key:
+                force = True
+    except OSError:
+        force = force or any(f.endswith(".o") for f in os.listdir(obj_dir))   # objects of unknown flags
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    jobs = []
     for src in sources:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, os.path.splitext(os.path.basename(src))[0] + ".o")
+        o = os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o")
         if force or _stale(o, [s] + hdrs):
             jobs.append([hipcc, *FLAGS, *extra_flags, "-c", s, "-o", o])
     if jobs:
@@ -75,13 +87,15 @@ def build(force: bool = False, extra_flags=()) -> str:
             for res in ex.map(lambda cmd: subprocess.run(cmd, capture_output=True, text=True), jobs):
                 if res.returncode != 0:
                     raise RuntimeError("hipcc failed:\n" + " ".join(res.args) + "\n" + res.stderr[-4000:])
-    objs = [os.path.join(OBJ, os.path.splitext(os.path.basename(s))[0] + ".o") for s in sources]
-    if force or jobs or _stale(LIB, objs):
-        res = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs],
+    with open(stamp, "w") as f:
+        f.write(flag_key)
+    objs = [os.path.join(obj_dir, os.path.splitext(os.path.basename(s))[0] + ".o") for s in sources]
+    if force or jobs or _stale(lib, objs):
+        res = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs],
                              capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("link failed:\n" + res.stderr[-4000:])
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

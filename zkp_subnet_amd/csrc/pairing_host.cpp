@@ -10,9 +10,12 @@
 // inversion, hard part as five exponentiations by the curve parameter + Frobenius maps (final_exp_fast; the exact
 // one-exponent form final_exp is kept for the test hook, which also cross-checks the two).  Checked against the independent pure-Python pairing of
 // oracle/pairing.py (direct degree-12 extension) in tests/test_verify.py.
+#include <cerrno>
 #include <cstdint>
 #include <cstring>
 #include <mutex>
+#include <new>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -533,16 +536,26 @@ int kzg_vk_verify_batch(const kzg_vk* vk, uint32_t n, const uint32_t* idx, const
         if (!fr_from_be32(y, evals_be32 + 32 * (size_t)i)) return KZG_E_SCALAR;
     }
     if (n == 0) { *out_all_valid = 1; return KZG_OK; }
+    // nothing may cross the C boundary: a failed thread creation (std::system_error) or allocation (std::bad_alloc) is a
+    // status code, not std::terminate of the validator process
+    try {
     std::vector<u64> w(2 * (size_t)n);                       // the weights: 128 random bits per row
     {
         size_t need = w.size() * sizeof(u64), got = 0;
         while (got < need) {
             const ssize_t r = getrandom(reinterpret_cast<uint8_t*>(w.data()) + got, need - got, 0);
-            if (r <= 0) return KZG_E_HIP;                    // no randomness, no batch check
+            if (r < 0 && errno == EINTR) continue;
+            if (r <= 0) return KZG_E_NOMEM;                  // no randomness, no batch check (a host resource failure)
             got += (size_t)r;
         }
     }
     if (threads < 1) threads = 1;
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        if (hw == 0) hw = 16;
+        if (hw > 64) hw = 64;
+        if ((unsigned)threads > hw) threads = (int)hw;       // a thread per row of a 256-row step helps nobody
+    }
     if ((uint32_t)threads > n) threads = (int)n;
     std::vector<Jac<Fp>> accA((size_t)threads, jac_inf<Fp>()), accB((size_t)threads, jac_inf<Fp>());
     std::vector<int> bad((size_t)threads, 0);
@@ -564,8 +577,14 @@ int kzg_vk_verify_batch(const kzg_vk* vk, uint32_t n, const uint32_t* idx, const
     };
     {
         std::vector<std::thread> th;
-        for (int t = 1; t < threads; t++) th.emplace_back(work, t);
+        th.reserve((size_t)threads);
+        int started = 1;                                     // slice 0 runs on the caller
+        try {
+            for (int t = 1; t < threads; t++, started++) th.emplace_back(work, t);
+        } catch (const std::system_error&) {                 // out of threads: the caller takes the slices nobody got
+        }
         work(0);
+        for (int t = started; t < threads; t++) work(t);
         for (auto& x : th) x.join();
     }
     Jac<Fp> A = jac_inf<Fp>(), B = jac_inf<Fp>();
@@ -579,6 +598,11 @@ int kzg_vk_verify_batch(const kzg_vk* vk, uint32_t n, const uint32_t* idx, const
     const Fp12 f = miller_loop(to_aff(A), aff_neg(vk->k.g2)) * miller_loop(to_aff(B), rhs_q);
     *out_all_valid = is_one(final_exp_fast(f)) ? 1 : 0;
     return KZG_OK;
+    } catch (const std::bad_alloc&) {
+        return KZG_E_NOMEM;
+    } catch (...) {
+        return KZG_E_NOMEM;
+    }
 }
 
 /* test hook: out = final_exp(miller(P, Q)) as 12 x 48 bytes in tower order

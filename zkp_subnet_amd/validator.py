@@ -63,8 +63,14 @@ def verify_all(client, challenge: Challenge, responses: Sequence[Optional[Prove]
         r = responses[i]
         if r is None or r.commitment is None or r.proof is None:
             return False
-        return bool(_ok(client.worker_verify(i, r.proof, challenge.alpha, challenge.evals[i], r.commitment), "valid",
-                        "verify the proof"))
+        # 400 = the MINER's bytes are unusable (not base64, wrong length, off-curve / non-canonical): an invalid row, never
+        # a reason to lose the other rows.  Only a failing verifier (5xx / 501 / 503) raises, as in the reference.
+        with client.worker_verify(i, r.proof, challenge.alpha, challenge.evals[i], r.commitment) as resp:
+            if resp.status_code == 400:
+                return False
+            if resp.status_code != 200:
+                raise Exception("Failed to verify the proof.")
+            return bool(resp.json().get("valid"))
 
     if n <= 1 or threads <= 1:
         return [one(i) for i in range(n)]

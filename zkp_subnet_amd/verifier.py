@@ -45,6 +45,8 @@ class Verifier:
     def verify(self, i: int, proof48: bytes, alpha32: bytes, eval32: bytes, commitment48: bytes) -> bool:
         if len(proof48) != 48 or len(commitment48) != 48:
             return False
+        if len(alpha32) != 32 or len(eval32) != 32:          # the C side reads exactly 32 bytes of each
+            raise KzgError(_native.KZG_E_ARG, "kzg_vk_verify: alpha / eval must be 32 bytes")
         ok = ctypes.c_int(0)
         rc = self._lib.kzg_vk_verify(self._h, i, proof48, alpha32, eval32, commitment48, ctypes.byref(ok))
         if rc != 0:
@@ -58,6 +60,8 @@ class Verifier:
         n = len(indices)
         if not (n == len(proofs48) == len(evals32) == len(commitments48)):
             raise ValueError("verify_batch: ragged input")
+        if len(alpha32) != 32 or any(len(e) != 32 for e in evals32):   # a short eval would have the C side read past
+            raise KzgError(_native.KZG_E_ARG, "kzg_vk_verify_batch: alpha / evals must be 32 bytes each")   # the joined buffer
         if any(len(p) != 48 for p in proofs48) or any(len(c) != 48 for c in commitments48):
             return False
         idx = (ctypes.c_uint32 * max(n, 1))(*indices)
