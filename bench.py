@@ -107,6 +107,21 @@ def measured_copy_peak_gbs(torch):
     return gbs
 
 
+def sysfs_sclk_mhz(device):
+    """Current shader clock from the amdgpu sysfs node (the `*` line of pp_dpm_sclk), when the container exposes it."""
+    import glob
+
+    try:
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        with open(cards[device]) as f:
+            for line in f:
+                if line.rstrip().endswith("*"):
+                    return float(line.split(":")[1].strip().split("M")[0])
+    except (OSError, IndexError, ValueError):
+        pass
+    return None
+
+
 def host_cores():
     try:
         return len(os.sched_getaffinity(0))
@@ -580,6 +595,15 @@ def main():
     run_steps(args.steps, live_level == 2)
     barrier()
     elapsed = time.perf_counter() - t0
+    # the bound of the dominant kernel, measured NOW on this box at the clocks the timed region left behind (~2 ms: a
+    # v_mad_u64_u32 chain at 2 waves per SIMD on every SIMD, csrc/calibrate.hip): mad_issue.frac is a same-run ratio
+    calib = None
+    if is_msm:
+        try:
+            calib = eng.calibrate(2)
+            calib["sclk_mhz_sysfs"] = sysfs_sclk_mhz(local_rank)
+        except Exception as e:                 # noqa: BLE001 -- a measurement aid must never cost the bench line
+            calib = {"error": f"{type(e).__name__}: {e}"}
     acc_live_ms = stage_sum.get("accumulate", 0.0) / args.steps if live_level == 2 else None
     stage_sum.clear()
     timed_step_ms = list(step_ms)
@@ -677,7 +701,9 @@ def main():
                 mads = pmc.get("wave_mads_per_launch")
         except (OSError, KeyError, ValueError):
             pass
-        mad_peak = SIMDS / MAD_NS
+        mad_peak_file = SIMDS / MAD_NS             # the committed ubench figure: kept as a cross-check only
+        live = calib is not None and "gmad_per_s" in calib
+        mad_peak = calib["gmad_per_s"] if live else mad_peak_file
         out = {
             "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -703,9 +729,17 @@ def main():
             "mad_issue": ({"wave_mads_per_launch": mads, "wave_valu_insts_per_launch": valu_insts,
                            "achieved_gmad_s": mads / per_launch_s / 1e9, "peak_gmad_s": mad_peak,
                            "frac": mads / per_launch_s / 1e9 / mad_peak,
-                           "peak_basis": f"{SIMDS} SIMDs / {MAD_NS} ns per v_mad_u64_u32 wave-instruction "
-                                         "(profiles/ubench_valu_rates.txt, 2 and 4 waves per SIMD); mads per launch from "
-                                         "the ISA (profiles/isa_counts.json) x additions per lane x waves",
+                           "peak_source": "kzg_calibrate in this run, right after the timed region" if live else
+                                          "profiles/ubench_valu_rates.txt (another box: treat frac as +-14 %)",
+                           "calibration": calib,
+                           "peak_gmad_s_committed_ubench": mad_peak_file,
+                           "live_vs_committed_peak": (mad_peak / mad_peak_file) if live else None,
+                           "peak_basis": (f"{calib['simds']} SIMDs / {calib['ns_per_mad_per_simd']:.3f} ns per v_mad_u64_u32 "
+                                          f"wave-instruction per SIMD at 2 waves per SIMD, measured in this run" if live else
+                                          f"{SIMDS} SIMDs / {MAD_NS} ns per v_mad_u64_u32 wave-instruction "
+                                          "(profiles/ubench_valu_rates.txt, 2 and 4 waves per SIMD)")
+                                         + "; mads per launch from the ISA (profiles/isa_counts.json) x additions per lane "
+                                           "x waves",
                            "simd32_full_rate_ginst_s": VALU_FULL_RATE_GINST_S}
                           if mads and acc_ms else None),
             "result_hex": results[0].hex() if isinstance(results[0], (bytes, bytearray)) else b"".join(results[0]).hex(),

@@ -63,8 +63,9 @@ int kzg_load_srs(kzg_ctx* ctx, const uint8_t* g1_affine_be96, uint64_t n_points,
 int kzg_load_srs_compressed(kzg_ctx* ctx, const uint8_t* g1_c48, uint64_t n_points, int scale, int machines_scale);
 /* The reference's own start path: Client(setup_path=...).start(scale, machines_scale) gives the prover a FILE
  * (base/miner.py:75-84; Makefile:63-74 starts mainnet from setup_24_8.uncompressed: 2^24 points, 1.6 GB).  The file
- * (96-byte records, or 48-byte compressed ones with compressed=1) is memory-mapped and streamed through two pinned
- * tiles: host copy, upload and GPU decode overlap.  All three loaders build the new tables aside and swap them in only
+ * (96-byte records, or 48-byte compressed ones with compressed=1) is read with pread(2) straight into two pinned
+ * tiles: host read, upload and GPU decode overlap, and a file truncated or replaced during the load is KZG_E_ARG (a
+ * mapping would have raised SIGBUS).  All three loaders build the new tables aside and swap them in only
  * when the whole load has succeeded: after a failure (bad point, I/O, memory) the previously loaded SRS keeps serving. */
 int kzg_load_srs_file(kzg_ctx* ctx, const char* path, int compressed, int scale, int machines_scale);
 /* seconds spent by the last successful load: [0] host copies into the pinned tiles, [1] host waiting for upload + decode
@@ -72,7 +73,9 @@ int kzg_load_srs_file(kzg_ctx* ctx, const char* path, int compressed, int scale,
 int kzg_get_load_stats(kzg_ctx* ctx, double out_s[4]);
 /* The loaders check every point: coordinates reduced, on the curve, AND in the prime-order subgroup G1 (E(Fp) has a
  * cofactor of ~2^126; the test is the endomorphism identity [z^2]P == -sigma(P), ~0.3 s for 2^24 points).  A failure is
- * KZG_E_POINT.  enable = 0 skips the membership part for a file whose provenance is already established. */
+ * KZG_E_POINT.  enable = 0 skips the membership part for a file whose provenance is already established: it applies to
+ * the NEXT load only (whether that load succeeds or not) and the check is armed again afterwards -- a sticky switch
+ * would silently cover later loads from caller memory too. */
 int kzg_set_srs_subgroup_check(kzg_ctx* ctx, int enable);
 
 /* synthetic SRS with known discrete logs (tests / benches; stands in for `fourier setup --generate-setup`,
@@ -142,8 +145,6 @@ int kzg_vk_verify(const kzg_vk* vk, uint32_t i, const uint8_t proof48[48], const
 int kzg_vk_verify_batch(const kzg_vk* vk, uint32_t n, const uint32_t* idx, const uint8_t* proofs48,
                         const uint8_t alpha_be32[32], const uint8_t* evals_be32, const uint8_t* commitments48, int threads,
                         int* out_all_valid);
-/* test hook: final_exp(miller(P, Q)) as 12 x 48 B in tower order (Fp12 = Fp6[w], Fp6 = Fp2[v], Fp2 = Fp[u]) */
-int kzg_vk_pairing(const uint8_t p_be96[96], const uint8_t q_be192[192], uint8_t out_fp12[576]);
 
 /* ---- multi-GPU: each rank reduces its SRS shard to ONE partial sum; the 192-byte partials are exchanged by
  *      the caller (RCCL all_gather over xGMI in zkp_subnet_amd.distributed) and summed on any rank. */
@@ -208,12 +209,6 @@ int kzg_staging_release(kzg_ctx* ctx, int token);
  *      inversion) + ZCash compression -- a few microseconds instead of a ~140 us single-lane GPU kernel.
  *      0: encode on the GPU (k_g1_compress).  Results are identical; the *_dev entry points always stay on the GPU. */
 int kzg_set_host_finish(kzg_ctx* ctx, int enable);
-/* the host encoder itself (no GPU): 4 x 14 limbs of 28 bits (X, Y, ZZ, ZZZ; lazy limbs < 2^32; residues with
- * R = 2^392) -> 48-byte compressed point / 192-byte partial record.  Test hooks. */
-int kzg_host_xyzz_to_c48(const uint32_t xyzz_limbs28[56], uint8_t out48[48]);
-int kzg_host_xyzz_pair_to_c48(const uint32_t a_limbs28[56], const uint32_t b_limbs28[56], uint8_t out_a48[48],
-                              uint8_t out_b48[48]); /* two points, one shared inversion (commit + open) */
-int kzg_host_xyzz_to_partial192(const uint32_t xyzz_limbs28[56], uint8_t out192[192]);
 
 /* ---- per-stage HIP-event timings of the last hot-path call (events recorded on the ctx's own stream) */
 enum {
@@ -226,18 +221,19 @@ int kzg_set_profiling(kzg_ctx* ctx, int enable);
 int kzg_get_timings(kzg_ctx* ctx, float* out_ms, int count); /* accumulated over the last call's MSMs */
 /* fixed-size MSM plan facts for roofline bookkeeping: entries per lane, lanes, buckets, windows */
 int kzg_msm_plan(kzg_ctx* ctx, uint64_t n, int32_t out[4]);
+/* The bound of the dominant kernel as a measurement of THIS device at THIS moment (SURVEY 8d "confirm on the box"):
+ * k_msm_accumulate is bound by the issue rate of v_mad_u64_u32, and boxes of one pool differ by up to
+ * 14 % in it.  Runs a chain of that one instruction with `waves_per_simd` waves on every SIMD for ~1.5 ms (exclusive:
+ * waits for the lanes to be idle; KZG_E_BUSY while tickets are out).  out[0] ns per wave-instruction per SIMD, out[1]
+ * G wave-instructions/s of the whole chip, out[2] s_memtime ticks per ns over the launch (the clock the SIMDs ran at, in
+ * GHz, when s_memtime counts shader clocks), out[3] kernel ms, out[4] SIMDs, out[5] ticks per instruction of one wave.
+ * bench.py calls it right after its timed region; nothing on the serving path does. */
+int kzg_calibrate(kzg_ctx* ctx, int waves_per_simd, double out[6]);
 
 /* ---- host-side wire codec (Prove.poly is a list of 43-char unpadded base64 strings, reference
  *      base/protocol.py:35-40).  packed: n x 43 chars, no separators.  Pure host code. */
 int kzg_b64_decode_fr(const char* packed43, uint64_t n, uint8_t* out_be32);
 int kzg_b64_encode_fr(const uint8_t* be32, uint64_t n, char* out_packed43);
-
-/* ---- unit-op hooks for the parity tests (tests/test_gpu_parity.py); not part of the serving surface */
-int kzg_test_field(kzg_ctx* ctx, int field /*0 Fp,1 Fr*/, int op /*0 mul,1 add,2 sub,3 mul(plain C ref),4 sqr*/,
-                   const uint8_t* a_be, const uint8_t* b_be, uint8_t* out_be, uint64_t n);
-int kzg_test_g1(kzg_ctx* ctx, int op /*0 a+b mixed,1 2a+b full,2 2a,3 4a,4 a+20a+20b chain; lane-parallel forms: 5 2a+b,
-                                         6 4a, 7 ten rounds r <- 2r+b from a*/, const uint8_t* a_be96,
-                const uint8_t* b_be96, uint8_t* out_be96, uint64_t n);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,9 @@ import json
 import os
 import sys
 
-src, out_csv = sys.argv[1], sys.argv[2]
+accept = "--accept" in sys.argv      # a deliberate change of the kernel's traffic: take the new value without the drift gate
+argv = [a for a in sys.argv[1:] if a != "--accept"]
+src, out_csv = argv[0], argv[1]
 acc = {}
 for path in glob.glob(os.path.join(src, "*", "*counter_collection.csv")):
     for r in csv.DictReader(open(path)):
@@ -36,12 +38,27 @@ if fs and ws:
         wave_mads = isa["mads_per_mixed_add"] * cfg["entries_per_lane"] * cfg["lanes"] / 64.0
     except (OSError, KeyError):
         wave_mads = None
+    # staleness gate: bench.py quotes roofline.traffic from the COMMITTED file; a fresh pass that disagrees with it by more
+    # than 2 % means the committed figure no longer describes the kernel (exit 3, file still rewritten from this pass)
+    traffic_path = os.path.join(os.path.dirname(out_csv), "pmc_traffic.json")
+    drift = None
+    try:
+        old_rec = json.load(open(traffic_path))
+        if (old_rec.get("points_per_gpu"), old_rec.get("window_bits")) == (cfg["points_per_gpu"], cfg["window_bits"]):
+            drift = (2 * fkb * 1024 + wkb * 1024) / old_rec["traffic_bytes_per_launch"] - 1.0
+    except (OSError, KeyError, ValueError):
+        pass
     json.dump({"workload": "msm20", "sq_insts_valu_per_launch": (sum(iv.values()) / len(iv)) if iv else None,
                "wave_mads_per_launch": wave_mads, "points_per_gpu": cfg["points_per_gpu"], "window_bits": cfg["window_bits"],
                "kernel": "k_msm_accumulate", "fetch_size_kb_raw": fkb, "write_size_kb_raw": wkb,
                "traffic_bytes_per_launch": 2 * fkb * 1024 + wkb * 1024,
                "correction": "2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE counts 128-B requests as 64 B; "
                              "MI355X_MICROARCH.md HBM section)",
+               "drift_vs_previous_committed_value": drift,
                "source": os.path.relpath(out_csv)},
-              open(os.path.join(os.path.dirname(out_csv), "pmc_traffic.json"), "w"), indent=1)
-    print("traffic bytes/launch", 2 * fkb * 1024 + wkb * 1024)
+              open(traffic_path, "w"), indent=1)
+    print("traffic bytes/launch", 2 * fkb * 1024 + wkb * 1024, "drift vs committed",
+          "n/a" if drift is None else f"{drift * 100:+.2f} %")
+    if drift is not None and abs(drift) > 0.02 and not accept:
+        print("pmc_traffic.json was STALE: traffic per launch moved by more than 2 % (rerun with --accept if the kernel changed)")
+        sys.exit(3)

@@ -140,6 +140,9 @@ def test_load_srs_roundtrip_and_rejects_bad_points(hip):
         e2.set_srs_subgroup_check(False)
         e2.load_srs(data, 4, 0, compressed=comp)
         assert e2.srs_read(7, 1) == o.g1_to_be96((5, y5))
+        with pytest.raises(KzgError):                          # the opt-out covered ONE load: the check is armed again
+            e2.load_srs(data, 4, 0, compressed=comp)
+        assert e2.srs_read(7, 1) == o.g1_to_be96((5, y5))      # ... and the refused load left the installed SRS serving
     with pytest.raises(KzgError):
         hip().load_srs(o.P.to_bytes(48, "big") * 2 + srs[96:], 4, 0)   # unreduced coordinate
 
@@ -1317,3 +1320,198 @@ def test_bench_two_ranks_on_one_gpu_exercises_the_multi_rank_logic(hip):
         assert bytes.fromhex(pk["results_hex_by_rank"][r]) == want, r
         comms.append(want[:48])
     assert bytes.fromhex(pk["aggregate_commitment_hex"]) == e.g1_sum_compressed(b"".join(comms))
+
+
+# ------------------------------------------------------------------ seeded fuzz slice + the reference's fault scenarios
+def test_seeded_fuzz_slice():
+    """A fixed-seed slice of tests/fuzz_gpu.py inside the driver's `pytest -m gpu` run (the hours of fuzzing under
+    profiles/*_fuzz_*.log are builder-side evidence only): 14 engine rounds of random size / window / slice -- every MSM
+    through the blocking, resident and ticketed entry points on uniform / small / edge / equal / clustered scalars, NTT
+    against the oracle and its round trip, commit / open / fused commit+open incl. alpha = 0, 1, omega^k, r - 1, the text
+    path with row-cache hits and one-coefficient mutations, the fused transform + evaluation.  A mismatch raises inside
+    run() naming its case; the floors make sure every kind really ran."""
+    from tests import fuzz_gpu
+
+    stats = fuzz_gpu.run(budget=600.0, seed=20261201, rounds=14, max_log=17)
+    assert stats["rounds"] == 14 and stats["msm"] == 42 and stats["ntt"] == 14 and stats["kzg"] == 28
+    assert stats["cache_hits"] >= 6 and stats["cache_misses_after_mutation"] >= 6
+    assert stats["cache_hits"] + stats["cache_misses_after_mutation"] == 28
+
+
+@pytest.mark.parametrize("missing_info,too_late,invalid_proof,half_time,expected",
+                         [(False, False, False, False, [1.0, 1.0]), (True, False, False, False, [0.0, 1.0]),
+                          (False, True, False, False, [0.0, 1.0]), (False, False, True, False, [0.0, 1.0]),
+                          (False, False, False, True, [0.5, 1.0])])
+def test_reference_reward_scenarios_on_the_hip_engine(missing_info, too_late, invalid_proof, half_time, expected):
+    """The reference's whole notion of fault injection (tests/test_validator.py:60-121), scenario for scenario, with
+    every proof produced by the HIP engine and every check a real pairing: ok / commitment missing / answer late /
+    proof + 1 as a big-endian integer / half the timeout used.  timeout = 10 s as in the reference's test."""
+    from zkp_subnet_amd.client import Client
+    from zkp_subnet_amd.miner import Miner, default_config
+    from zkp_subnet_amd.validator import generate_challenge, reward
+
+    client = Client(seed=31)
+    client.start(scale=6, machines_scale=2)
+    miner = Miner(default_config(scale=6, machines_scale=2, seed=31), client=client)
+    try:
+        ch = generate_challenge(client, 2)
+        responses = [miner.forward(ch.to_synapse(i)) for i in range(2)]
+        times = [0.0, 0.0]
+        timeout = 10.0
+        if missing_info:
+            responses[0] = responses[0].model_copy(update={"commitment": None})
+        if too_late:
+            times[0] = 11.0
+        if invalid_proof:
+            raw = base64.b64decode(responses[0].proof)
+            bumped = (int.from_bytes(raw, "big") + 1) % (1 << (8 * len(raw)))
+            responses[0] = responses[0].model_copy(update={"proof": base64.b64encode(bumped.to_bytes(len(raw), "big")).decode()})
+        if half_time:
+            times[0] = 5.0
+        got = [reward(client, ch, responses[i], i, times[i], timeout) for i in range(2)]
+        assert got == expected
+    finally:
+        miner.stop()
+
+
+def test_lane_machinery_stress_eight_host_threads_one_context(hip, tmp_path):
+    """The reference's axon runs Miner.forward on worker threads and must never take the process down
+    (neurons/miner.py:106-135).  Eight host threads drive ONE context for ~20 s with a random mix of everything that
+    touches the lane machinery: worker_commit / worker_open through the row cache (hits, and misses after a one-coefficient
+    mutation), the fused call, plain and resident MSMs, tickets that are waited for and tickets that are cancelled,
+    kzg_upload_fr, and SRS reloads from a setup file -- one that fails (a point off the curve: the old tables must keep
+    serving) and one that succeeds (same points).  EVERY answer is compared with the oracle's; the only failures allowed
+    are the documented KZG_E_BUSY cases (include/kzg_mi355x.h: every lane parked under tickets, or a whole-context
+    operation while a ticket is out); no thread may hang."""
+    import threading
+    import time
+
+    from zkp_subnet_amd import codec
+    from zkp_subnet_amd._native import KZG_E_BUSY, KZG_E_POINT, KzgError
+
+    lg, ms = 11, 1
+    T = 1 << (lg - ms)
+    tx, ty = 0x5EED0001, 0x5EED0002
+    eng = hip()
+    eng.gen_srs(tx, ty, lg, ms)                                  # both slices resident: 2 x 2^10 points
+    flat = eng.srs_read(0, 2 * T)
+    good_file, bad_file = str(tmp_path / "setup_ok.uncompressed"), str(tmp_path / "setup_bad.uncompressed")
+    with open(good_file, "wb") as f:
+        f.write(flat)
+    broken = bytearray(flat)
+    broken[96 * 777 + 95] ^= 1                                   # y of point 777 leaves the curve
+    with open(bad_file, "wb") as f:
+        f.write(bytes(broken))
+    srs = [flat[:96 * T], flat[96 * T:]]
+    assert srs[0] == oc.srs_gen(tx.to_bytes(32, "big"), ty.to_bytes(32, "big"), lg, ms, 0)
+    # ---- the answer book (oracle only)
+    K = 4
+    rows = [rand_scalars_bytes(T, 900 + k) for k in range(K)]
+    alphas = [rand_scalars_bytes(1, 950 + k) for k in range(K)]
+    polys = [codec.be32_to_fr_list(r) for r in rows]
+    mut_rows, mut_polys = [], []
+    for k in range(K):                                           # the same row with ONE coefficient changed
+        j = 37 * (k + 1)
+        v = (int.from_bytes(rows[k][32 * j:32 * j + 32], "big") + 1) % o.R
+        mr = rows[k][:32 * j] + v.to_bytes(32, "big") + rows[k][32 * j + 32:]
+        mut_rows.append(mr)
+        mut_polys.append(codec.be32_to_fr_list(mr))
+    want_c = {(w, k): oc.commit(srs[w], rows[k], True) for w in range(2) for k in range(K)}
+    want_o = {(w, k): oc.open_(srs[w], rows[k], alphas[k], True) for w in range(2) for k in range(K)}
+    want_om = {(w, k): oc.open_(srs[w], mut_rows[k], alphas[k], True) for w in range(2) for k in range(K)}
+    slots = [rand_scalars_bytes(2 * T, 980), rand_scalars_bytes(T, 981)]       # resident scalar sets of slots 0 and 1
+    msm_cases = [(0, 2 * T, 0), (0, T, T), (0, 300, 123), (1, T, 0), (1, 512, 1024)]
+    want_m = {c: oc.msm(flat[96 * c[2]:96 * (c[2] + c[1])], slots[c[0]][:32 * c[1]]) for c in msm_cases}
+    for s, data in enumerate(slots):
+        eng.upload_fr(s, data, False)
+    # ---- the hammer
+    deadline = time.time() + 20.0
+    errors, counts, busy = [], {}, {}
+    lock = threading.Lock()
+
+    def note(table, key):
+        with lock:
+            table[key] = table.get(key, 0) + 1
+
+    def worker(tid):
+        rnd = random.Random(7000 + tid)
+        ops = ["commit", "open_hit", "open_miss", "fused", "msm", "msm_res", "ticket", "cancel", "upload", "reload_bad",
+               "reload_ok"]
+        weights = [6, 6, 3, 6, 4, 6, 6, 3, 2, 1, 1]
+        while time.time() < deadline and not errors:
+            op = rnd.choices(ops, weights)[0]
+            w, k = rnd.randrange(2), rnd.randrange(K)
+            try:
+                if op == "commit":
+                    ok = eng.commit_list(w, polys[k], True) == want_c[(w, k)]
+                elif op == "open_hit":                          # the unchanged miner's pair: the second call may hit
+                    ok = eng.commit_list(w, polys[k], True) == want_c[(w, k)] and \
+                        eng.open_list(w, polys[k], alphas[k], True) == want_o[(w, k)]
+                elif op == "open_miss":                         # commit one row, open its mutation: never the cached answer
+                    ok = eng.commit_list(w, polys[k], True) == want_c[(w, k)] and \
+                        eng.open_list(w, mut_polys[k], alphas[k], True) == want_om[(w, k)]
+                elif op == "fused":
+                    ok = eng.commit_open(w, rows[k], alphas[k], True) == (want_c[(w, k)],) + want_o[(w, k)]
+                elif op == "msm":
+                    c = rnd.choice(msm_cases)
+                    ok = eng.msm(slots[c[0]][:32 * c[1]], c[2]) == want_m[c]
+                elif op == "msm_res":
+                    c = rnd.choice(msm_cases)
+                    ok = eng.msm_resident(*c) == want_m[c]
+                elif op == "ticket":
+                    c = rnd.choice(msm_cases)
+                    part = rnd.random() < 0.5
+                    t = eng.msm_submit(c[0], c[1], c[2], partial=part)
+                    if rnd.random() < 0.5:
+                        time.sleep(rnd.random() * 0.002)        # others run into the parked lane meanwhile
+                    r = eng.msm_wait(t)
+                    ok = (eng.g1_sum(r) if part else r) == want_m[c]
+                elif op == "cancel":
+                    c = rnd.choice(msm_cases)
+                    t = eng.msm_submit(c[0], c[1], c[2])
+                    eng.msm_cancel(t)
+                    ok = True
+                elif op == "upload":                            # exclusive; same content, so the answer book holds
+                    s = rnd.randrange(2)
+                    eng.upload_fr(s, slots[s], False)
+                    ok = True
+                elif op == "reload_bad":
+                    try:
+                        eng.load_srs_file(bad_file, lg, ms)
+                        ok = False                              # must not load
+                    except KzgError as e:
+                        if e.code == KZG_E_BUSY:
+                            raise
+                        ok = e.code == KZG_E_POINT
+                else:
+                    eng.load_srs_file(good_file, lg, ms)
+                    ok = True
+                if not ok:
+                    errors.append((tid, op, w, k, "wrong answer"))
+                note(counts, op)
+            except KzgError as e:
+                if e.code == KZG_E_BUSY:
+                    note(busy, op)
+                else:
+                    errors.append((tid, op, w, k, repr(e)))
+            except Exception as e:                              # noqa: BLE001
+                errors.append((tid, op, w, k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,), daemon=True) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=max(1.0, deadline + 90.0 - time.time()))
+    hung = [i for i, t in enumerate(threads) if t.is_alive()]
+    assert not hung, f"threads {hung} never came back (deadlock in the lane machinery?) counts={counts} busy={busy}"
+    assert not errors, (errors[:5], counts, busy)
+    done = sum(counts.values())
+    assert done >= 200 and all(counts.get(op, 0) > 0 for op in ("commit", "open_hit", "open_miss", "fused", "msm", "msm_res",
+                                                                "ticket", "cancel", "upload", "reload_bad", "reload_ok")), (counts, busy)
+    assert sum(busy.values()) < done, (counts, busy)             # E_BUSY is the exception, not the rule
+    # after the storm: the context still answers, tickets all returned, results unchanged
+    assert eng.commit_open(1, rows[0], alphas[0], True) == (want_c[(1, 0)],) + want_o[(1, 0)]
+    assert eng.msm_resident(*msm_cases[0]) == want_m[msm_cases[0]]
+    hits, misses = eng.row_cache_stats()
+    assert hits > 0 and misses > 0
+    print("lane stress:", {"done": counts, "busy": busy, "cache": (hits, misses)})

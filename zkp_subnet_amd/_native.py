@@ -14,7 +14,8 @@ KZG_OK, KZG_E_ARG, KZG_E_SCALAR, KZG_E_POINT, KZG_E_HIP, KZG_E_NOMEM, KZG_E_BUSY
 STATUS_NAMES = {0: "OK", -1: "E_ARG", -2: "E_SCALAR", -3: "E_POINT", -4: "E_HIP", -5: "E_NOMEM", -6: "E_BUSY"}
 TIMING_NAMES = ["decode", "ntt", "digits", "scan", "scatter", "accumulate", "fixup", "tree", "final", "poly", "total"]
 
-# every symbol include/kzg_mi355x.h declares: name -> (restype, argtypes)
+# every symbol include/kzg_mi355x.h (serving surface) and include/kzg_mi355x_test.h (test hooks) declare:
+# name -> (restype, argtypes)
 _P = ctypes.c_void_p
 _B = ctypes.c_char_p
 _U64, _U32, _I = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
@@ -76,6 +77,7 @@ SYMBOLS = {
     "kzg_set_profiling": (_I, [_P, _I]),
     "kzg_get_timings": (_I, [_P, ctypes.POINTER(ctypes.c_float), _I]),
     "kzg_msm_plan": (_I, [_P, _U64, ctypes.POINTER(ctypes.c_int32)]),
+    "kzg_calibrate": (_I, [_P, _I, ctypes.POINTER(ctypes.c_double)]),
     "kzg_b64_decode_fr": (_I, [_B, _U64, _B]),
     "kzg_b64_encode_fr": (_I, [_B, _U64, _B]),
     "kzg_test_field": (_I, [_P, _I, _I, _B, _B, _B, _U64]),

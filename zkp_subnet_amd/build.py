@@ -14,11 +14,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libkzg_mi355x.so")
-SOURCES = ["msm.hip", "fr_kernels.hip", "api.hip", "pairing_host.cpp", "finish_host.cpp"]
+SOURCES = ["msm.hip", "fr_kernels.hip", "api.hip", "calibrate.hip", "pairing_host.cpp", "finish_host.cpp"]
 # dev-only prototypes (scripts/proto/), linked only when KZG_WITH_PROTO=1: never part of the shipped library
 PROTO_SOURCES = ["../../scripts/proto/baff_proto.hip"]
 HEADERS = ["bigint.hip.h", "field.hip.h", "fp28.hip.h", "fr29.hip.h", "g1.hip.h", "msm.hip.h", "fr_kernels.hip.h", "fp_lp.hip.h", "fp_host.h",
-           "../../include/kzg_mi355x.h"]
+           "../../include/kzg_mi355x.h", "../../include/kzg_mi355x_test.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 
 
@@ -43,10 +43,12 @@ def build_wire(force: bool = False) -> str:
     src = os.path.join(CSRC, "wire_py.c")
     out = os.path.join(HERE, "_wire" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
     if force or _stale(out, [src]):
-        cc = shutil.which("gcc") or shutil.which("cc")
+        # KZG_WIRE_CC / KZG_WIRE_CFLAGS: the sanitizer builds of scripts/sanitize_cpu.sh (clang + -fsanitize=...)
+        cc = os.environ.get("KZG_WIRE_CC") or shutil.which("gcc") or shutil.which("cc")
         if not cc:
             raise RuntimeError("gcc not found: cannot build the wire codec extension")
-        res = subprocess.run([cc, "-O3", "-shared", "-fPIC", "-pthread", "-I" + sysconfig.get_paths()["include"], src,
+        cflags = os.environ.get("KZG_WIRE_CFLAGS", "-O3").split()
+        res = subprocess.run([cc, *cflags, "-shared", "-fPIC", "-pthread", "-I" + sysconfig.get_paths()["include"], src,
                               "-o", out], capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("wire codec build failed:\n" + res.stderr[-4000:])
@@ -91,7 +93,8 @@ def build(force: bool = False, extra_flags=()) -> str:
         f.write(flag_key)
     objs = [os.path.join(obj_dir, os.path.splitext(os.path.basename(s))[0] + ".o") for s in sources]
     if force or jobs or _stale(lib, objs):
-        res = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs],
+        link_flags = [f for f in extra_flags if f.startswith("-fsanitize") or f in ("-shared-libsan", "-fno-gpu-sanitize")]
+        res = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *link_flags, "-o", lib, *objs],
                              capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("link failed:\n" + res.stderr[-4000:])

@@ -6,7 +6,6 @@
 
 #include <errno.h>
 #include <fcntl.h>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -18,12 +17,14 @@
 #include <atomic>
 #include <chrono>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <algorithm>
 #include <utility>
 #include <vector>
 
 #include "../../include/kzg_mi355x.h"
+#include "../../include/kzg_mi355x_test.h"
 #include "fr_kernels.hip.h"
 #include "msm.hip.h"
 #include "fp_lp.hip.h"
@@ -36,6 +37,8 @@
 #define N_STAGE 4
 #define KZG_MAX_GATHER 4096   // partials one kzg_msm_sharded_finish can sum (ranks of a job)
 
+void launch_calibrate_mad(hipStream_t s, uint64_t* out, uint32_t blocks, uint32_t iters);   // csrc/calibrate.hip
+int calibrate_unroll();
 namespace kzg_host {  // finish_host.cpp
 void xyzz_to_c48(const uint32_t* xyzz, uint8_t out48[48]);
 void xyzz_pair_to_c48(const uint32_t* xyzz0, const uint32_t* xyzz1, uint8_t out0[48], uint8_t out1[48]);
@@ -1137,12 +1140,55 @@ static void copy_parallel(uint8_t* dst, const uint8_t* src, size_t bytes) {
     memcpy(dst, src, std::min(piece, bytes));
     for (auto& t : th) t.join();
 }
+// reads [off, off + bytes) of `fd` into dst with up to four threads of pread(2): a setup file in the page cache arrives at
+// memory speed, and a file truncated or replaced under the load is a short read / errno here -- a status code -- where
+// a mapping would have raised SIGBUS in the miner process.  false: I/O error or end of file before `bytes`.
+static bool pread_full(int fd, uint8_t* dst, size_t bytes, off_t off) {
+    while (bytes) {
+        const ssize_t r = pread(fd, dst, bytes, off);
+        if (r < 0 && errno == EINTR) continue;
+        if (r <= 0) return false;
+        dst += r;
+        off += r;
+        bytes -= (size_t)r;
+    }
+    return true;
+}
+static bool read_parallel(int fd, uint8_t* dst, size_t bytes, off_t off) {
+    const size_t min_piece = (size_t)4 << 20;
+    const unsigned parts = (unsigned)std::min<size_t>(4, std::max<size_t>(1, bytes / min_piece));
+    if (parts <= 1) return pread_full(fd, dst, bytes, off);
+    const size_t piece = ((bytes / parts) + 4095) & ~(size_t)4095;
+    std::atomic<bool> ok{true};
+    std::vector<std::thread> th;
+    unsigned started = 1;
+    try {
+        for (unsigned t = 1; t < parts && (size_t)t * piece < bytes; t++, started++) {
+            const size_t o = (size_t)t * piece, len = std::min(piece, bytes - o);
+            th.emplace_back([=, &ok] { if (!pread_full(fd, dst + o, len, off + (off_t)o)) ok = false; });
+        }
+    } catch (const std::system_error&) {   // no thread to be had: the caller reads the rest itself
+    }
+    if (!pread_full(fd, dst, std::min(piece, bytes), off)) ok = false;
+    for (unsigned t = started; t < parts && (size_t)t * piece < bytes; t++) {
+        const size_t o = (size_t)t * piece;
+        if (!pread_full(fd, dst + o, std::min(piece, bytes - o), off + (off_t)o)) ok = false;
+    }
+    for (auto& t : th) t.join();
+    return ok;
+}
 // The points of a setup file / caller buffer -> a NEW window-0 table, tile by tile through two pinned staging buffers: the
-// host fills buffer b (from the mmapped file or the caller's memory) while the GPU still copies and decodes buffer 1 - b;
+// host fills buffer b (pread from the setup file, or a copy of the caller's memory) while the GPU still copies and decodes buffer 1 - b;
 // the only host waits are for a buffer to come free.  Then the window tables; then the swap.
-static int load_srs_common(kzg_ctx* ctx, const uint8_t* data, uint64_t n_points, int scale, int machines_scale,
+static int load_srs_common(kzg_ctx* ctx, const uint8_t* data, int fd, uint64_t n_points, int scale, int machines_scale,
                            bool compressed) {
-    if (!ctx || !data) return KZG_E_ARG;
+    if (!ctx || (!data && fd < 0)) return KZG_E_ARG;
+    bool subgroup_check;
+    {   // the opt-out is for ONE load: taken (and re-armed) here, whatever becomes of this call
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        subgroup_check = ctx->srs_subgroup_check;
+        ctx->srs_subgroup_check = true;
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     using clk = std::chrono::steady_clock;
     const auto t_begin = clk::now();
@@ -1193,7 +1239,13 @@ static int load_srs_common(kzg_ctx* ctx, const uint8_t* data, uint64_t n_points,
             if (err != hipSuccess) break;
         }
         const auto c0 = clk::now();
-        copy_parallel(pin.p[b], data + rec * first, cnt * rec);
+        if (data) copy_parallel(pin.p[b], data + rec * first, cnt * rec);
+        else if (!read_parallel(fd, pin.p[b], cnt * rec, (off_t)(rec * first))) {
+            const int e = errno;
+            (void)hipStreamSynchronize(L.stream);     // copies of the other buffer may still be in flight
+            return fail(ctx, KZG_E_ARG, std::string("setup file: read failed or the file shrank during the load") +
+                                            (e ? std::string(" (") + strerror(e) + ")" : std::string()));
+        }
         host_copy_s += std::chrono::duration<double>(clk::now() - c0).count();
         err = hipMemcpyAsync(dev_in[b].p, pin.p[b], cnt * rec, hipMemcpyHostToDevice, L.stream);
         if (err != hipSuccess) break;
@@ -1202,7 +1254,7 @@ static int load_srs_common(kzg_ctx* ctx, const uint8_t* data, uint64_t n_points,
         if (compressed) launch_srs_from_c48(L.stream, dev_in[b].as<uint8_t>(), table + first, cnt, L.flags() + 1);
         else launch_srs_from_be96(L.stream, dev_in[b].as<uint8_t>(), table + first, cnt, L.flags() + 1);
         // on the curve is not in G1 (cofactor ~2^126): every point of the file is put through the endomorphism test
-        if (ctx->srs_subgroup_check) launch_g1_subgroup_check_bulk(L.stream, table + first, cnt, L.flags() + 1);
+        if (subgroup_check) launch_g1_subgroup_check_bulk(L.stream, table + first, cnt, L.flags() + 1);
     }
     if (err != hipSuccess) {
         (void)hipStreamSynchronize(L.stream);
@@ -1229,14 +1281,15 @@ static int load_srs_common(kzg_ctx* ctx, const uint8_t* data, uint64_t n_points,
     return KZG_OK;
 }
 int kzg_load_srs(kzg_ctx* ctx, const uint8_t* g1_affine_be96, uint64_t n_points, int scale, int machines_scale) {
-    return load_srs_common(ctx, g1_affine_be96, n_points, scale, machines_scale, false);
+    return load_srs_common(ctx, g1_affine_be96, -1, n_points, scale, machines_scale, false);
 }
 int kzg_load_srs_compressed(kzg_ctx* ctx, const uint8_t* g1_c48, uint64_t n_points, int scale, int machines_scale) {
-    return load_srs_common(ctx, g1_c48, n_points, scale, machines_scale, true);
+    return load_srs_common(ctx, g1_c48, -1, n_points, scale, machines_scale, true);
 }
 // The reference's start path: `Client(setup_path=...).start(scale, machines_scale)` hands the prover a FILE
-// (base/miner.py:75-84, Makefile:63-74: setup_24_8.uncompressed = 2^24 points, 1.6 GB).  The file is mapped, not read:
-// its pages go from the page cache into the pinned tiles and nowhere else.
+// (base/miner.py:75-84, Makefile:63-74: setup_24_8.uncompressed = 2^24 points, 1.6 GB).  The file is read with pread(2)
+// straight into the pinned tiles (page cache -> pinned memory, one copy, as a mapping would give) so that a file that is
+// truncated or replaced while a multi-GB load runs fails the call instead of raising SIGBUS.
 int kzg_load_srs_file(kzg_ctx* ctx, const char* path, int compressed, int scale, int machines_scale) {
     if (!ctx || !path) return KZG_E_ARG;
     const int fd = open(path, O_RDONLY | O_CLOEXEC);
@@ -1251,14 +1304,10 @@ int kzg_load_srs_file(kzg_ctx* ctx, const char* path, int compressed, int scale,
         close(fd);
         return fail(ctx, KZG_E_ARG, "setup file must be a whole number of " + std::to_string(rec) + "-byte G1 points");
     }
-    void* map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    (void)posix_fadvise(fd, 0, st.st_size, POSIX_FADV_SEQUENTIAL);
+    (void)posix_fadvise(fd, 0, st.st_size, POSIX_FADV_WILLNEED);
+    const int rc = load_srs_common(ctx, nullptr, fd, (uint64_t)st.st_size / rec, scale, machines_scale, compressed != 0);
     close(fd);
-    if (map == MAP_FAILED) return fail(ctx, KZG_E_NOMEM, std::string("mmap(setup file): ") + strerror(errno));
-    (void)madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL);
-    (void)madvise(map, (size_t)st.st_size, MADV_WILLNEED);
-    const int rc = load_srs_common(ctx, static_cast<const uint8_t*>(map), (uint64_t)st.st_size / rec, scale, machines_scale,
-                                   compressed != 0);
-    munmap(map, (size_t)st.st_size);
     return rc;
 }
 // seconds of the last successful kzg_load_srs*: [0] host copies file/buffer -> pinned tiles, [1] host waits for the GPU
@@ -1267,6 +1316,49 @@ int kzg_set_srs_subgroup_check(kzg_ctx* ctx, int enable) {
     if (!ctx) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->srs_subgroup_check = enable != 0;
+    return KZG_OK;
+}
+// The rate that bounds the accumulate kernel, measured now, on this device (csrc/calibrate.hip).  Exclusive: waits for
+// the lanes to be idle so that nothing shares the SIMDs with the measurement.
+int kzg_calibrate(kzg_ctx* ctx, int waves_per_simd, double out[6]) {
+    if (!ctx || !out) return KZG_E_ARG;
+    if (waves_per_simd < 1 || waves_per_simd > 8) return fail(ctx, KZG_E_ARG, "waves_per_simd must be in [1, 8]");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    const uint32_t cus = (uint32_t)prop.multiProcessorCount, simds = 4 * cus;
+    LaneHold H(ctx);
+    if (int rc = H.take_all()) return rc;
+    Lane& L = H.L();
+    const uint32_t blocks = cus * (uint32_t)waves_per_simd;      // 256 threads = 4 waves = one per SIMD of a CU
+    HIPCHK(ctx, L.out_be.ensure((2 + (size_t)blocks * 256) * sizeof(uint64_t)));
+    uint64_t* d = L.out_be.as<uint64_t>();
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(ctx, hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(ctx, KZG_E_HIP, "hipEventCreate"); }
+    // ~1.5 ms at 2 waves per SIMD (2.3 ns per wave-instruction per SIMD); a short launch first pages the code in
+    const uint32_t iters = 40960u * 2u / (uint32_t)std::max(2, waves_per_simd);
+    launch_calibrate_mad(L.stream, d, blocks, iters / 16);
+    (void)hipEventRecord(e0, L.stream);
+    launch_calibrate_mad(L.stream, d, blocks, iters);
+    (void)hipEventRecord(e1, L.stream);
+    uint64_t ticks = 0;
+    hipError_t err = hipMemcpyAsync(&ticks, d, sizeof(ticks), hipMemcpyDeviceToHost, L.stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(L.stream);
+    float ms = 0;
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (err != hipSuccess) return fail(ctx, KZG_E_HIP, std::string("kzg_calibrate: ") + hipGetErrorString(err));
+    const double inst_per_wave = (double)iters * calibrate_unroll();
+    const double inst_per_simd = inst_per_wave * waves_per_simd;
+    out[0] = (double)ms * 1e6 / inst_per_simd;                   // ns per v_mad_u64_u32 wave-instruction per SIMD
+    out[1] = (double)simds / out[0];                             // G wave-mads per second, whole chip
+    out[2] = ms > 0 ? (double)ticks / ((double)ms * 1e6) : 0;    // s_memtime ticks per ns over the launch (wave 0)
+    out[3] = (double)ms;
+    out[4] = (double)simds;
+    out[5] = (double)ticks / inst_per_wave;                      // ticks per instruction of ONE wave
+    H.clean = true;
     return KZG_OK;
 }
 int kzg_get_load_stats(kzg_ctx* ctx, double out_s[4]) {

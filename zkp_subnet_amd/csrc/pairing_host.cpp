@@ -23,6 +23,7 @@
 #include <sys/types.h>
 
 #include "../../include/kzg_mi355x.h"
+#include "../../include/kzg_mi355x_test.h"
 
 #include "fp_host.h"
 

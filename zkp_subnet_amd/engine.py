@@ -95,14 +95,15 @@ class HipEngine:
         self.verifier = None
 
     def load_srs_file(self, path: str, scale: int, machines_scale: int, compressed: bool = False) -> None:
-        """The setup FILE the reference prover is started with (base/miner.py:75-84): mapped and streamed by the library
-        (pinned double-buffered tiles), never read into Python memory."""
+        """The setup FILE the reference prover is started with (base/miner.py:75-84): read by the library with
+        pread(2) straight into two pinned tiles (host read, upload and GPU decode overlap), never into Python memory."""
         self._chk(self._lib.kzg_load_srs_file(self._h, os.fsencode(path), int(compressed), scale, machines_scale))
         self.scale, self.machines_scale = scale, machines_scale
         self.verifier = None
 
     def set_srs_subgroup_check(self, enable: bool) -> None:
-        """Loaders test every SRS point for membership in G1 (default on); off for files of established provenance."""
+        """Loaders test every SRS point for membership in G1 (default on).  False skips it for the NEXT load only (a file
+        of established provenance); the library arms the check again after that load."""
         self._chk(self._lib.kzg_set_srs_subgroup_check(self._h, int(enable)))
 
     def load_stats(self) -> Dict[str, float]:
@@ -363,6 +364,13 @@ class HipEngine:
         arr = (ctypes.c_int32 * 4)()
         self._chk(self._lib.kzg_msm_plan(self._h, n, arr))
         return {"chunk": arr[0], "lanes": arr[1], "buckets": arr[2], "windows": arr[3]}
+
+    def calibrate(self, waves_per_simd: int = 2) -> Dict[str, float]:
+        """The v_mad_u64_u32 issue rate of THIS GPU right now (kzg_calibrate): what bounds k_msm_accumulate."""
+        arr = (ctypes.c_double * 6)()
+        self._chk(self._lib.kzg_calibrate(self._h, waves_per_simd, arr))
+        return {"ns_per_mad_per_simd": arr[0], "gmad_per_s": arr[1], "memtime_ticks_per_ns": arr[2], "kernel_ms": arr[3],
+                "simds": int(arr[4]), "ticks_per_mad_of_one_wave": arr[5], "waves_per_simd": waves_per_simd}
 
     # ------------------------------------------------------------------ unit-op hooks (parity tests)
     def test_field(self, field: int, op: int, a_be: bytes, b_be: bytes) -> bytes:
