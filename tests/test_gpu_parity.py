@@ -1515,3 +1515,37 @@ def test_lane_machinery_stress_eight_host_threads_one_context(hip, tmp_path):
     hits, misses = eng.row_cache_stats()
     assert hits > 0 and misses > 0
     print("lane stress:", {"done": counts, "busy": busy, "cache": (hits, misses)})
+
+
+def test_multi_device_client_two_contexts_on_one_gpu():
+    """MultiDeviceClient with G = 2 contexts (both on device 0: this box has one GPU; on a multi-GPU host the list names
+    different devices): worker index i is served by context i mod 2, each context generated only its own slices, the four
+    rows of a challenge run concurrently from host threads, and every commitment / evaluation / proof equals the C
+    oracle's on the same slice."""
+    from zkp_subnet_amd import MultiDeviceClient, codec
+    from zkp_subnet_amd.client import derive_taus
+    from zkp_subnet_amd.validator import generate_challenge, verify_all
+
+    lg, ms = 12, 2
+    multi = MultiDeviceClient(devices=[0, 0], seed=77)
+    multi.start(scale=lg, machines_scale=ms)
+    try:
+        assert [c.workers for c in multi.clients] == [[0, 2], [1, 3]]
+        ch = generate_challenge(multi, 4)
+        answers = multi.commit_and_open_rows(range(4), ch.polys, ch.alpha)
+        tx, ty = (t.to_bytes(32, "big") for t in derive_taus(77))
+        alpha = codec.fr_to_be32(ch.alpha)
+        for i, a in enumerate(answers):
+            assert a.status_code == 200, a.json()
+            srs = oc.srs_gen(tx, ty, lg, ms, i)
+            row = codec.fr_list_to_be32(ch.polys[i])
+            ev, pf = oc.open_(srs, row, alpha, True)
+            assert codec.g1_from_b64(a.json()["commitment"]) == oc.commit(srs, row, True), i
+            assert (codec.fr_to_be32(a.json()["eval"]), codec.g1_from_b64(a.json()["proof"])) == (ev, pf), i
+            assert a.json()["eval"] == ch.evals[i]                 # the validator's own evaluation, from the other path
+        from zkp_subnet_amd.protocol import Prove
+        responses = [Prove(index=i, poly=[], commitment=a.json()["commitment"], proof=a.json()["proof"], eval=a.json()["eval"])
+                     for i, a in enumerate(answers)]
+        assert verify_all(multi, ch, responses, threads=4) == [True] * 4
+    finally:
+        multi.stop()

@@ -299,3 +299,58 @@ def test_bench_gpus_n_without_a_launcher_self_launches_or_refuses_cleanly():
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
                              capture_output=True, text=True, timeout=600, env=env)
         assert out.returncode not in (0, 2) and "needs an MI355X" in out.stderr, (out.returncode, out.stderr[-500:])
+
+
+def test_multi_device_client_routes_rows_by_worker_index():
+    """MultiDeviceClient (SURVEY 8b's multi-device form, reference base/miner.py:73-84 builds one client per process):
+    G contexts, worker index i served by context i mod G, the rest of the surface on any of them.  With oracle-backed
+    engines standing in for the GPUs: every answer equals a single Client's, each engine only ever sees its own rows,
+    the Miner takes the router unchanged, and the challenge step spreads its rows over the devices."""
+    from zkp_subnet_amd import MultiDeviceClient
+    from zkp_subnet_amd.validator import verify_all
+
+    class Spy(OracleEngine):
+        def __init__(self):
+            super().__init__()
+            self.seen = []
+
+        def commit_open(self, i, row, alpha, evaluation_form=True):
+            self.seen.append(("commit_open", self.workers[i]))
+            return super().commit_open(i, row, alpha, evaluation_form)
+
+        def commit(self, i, row, evaluation_form=True):
+            self.seen.append(("commit", self.workers[i]))
+            return super().commit(i, row, evaluation_form)
+
+        def open(self, i, row, alpha, evaluation_form=True):
+            self.seen.append(("open", self.workers[i]))
+            return super().open(i, row, alpha, evaluation_form)
+
+    single = make_client(7, 2, seed=14)
+    engines = [Spy(), Spy(), Spy()]
+    multi = MultiDeviceClient(devices=[0, 1, 2], seed=14, engines=engines)
+    assert multi.worker_commit(0, ["x"]).status_code == 503             # not started yet, as Client
+    multi.start(scale=7, machines_scale=2)
+    assert [e.workers for e in engines] == [[0, 3], [1], [2]] and multi.device_of(3) == 0
+    ch = generate_challenge(multi, 4)                                    # fft_eval_rows: rows spread over the devices
+    for i in range(4):
+        with single.fft_eval(ch.polys[i], ch.alpha) as r:
+            assert r.json()["y"] == ch.evals[i]
+    answers = multi.commit_and_open_rows(range(4), ch.polys, ch.alpha)
+    for i, a in enumerate(answers):
+        with single.worker_commit_and_open(i, ch.polys[i], ch.alpha) as b:
+            assert a.status_code == 200 and a.json() == b.json()
+        with multi.worker_commit(i, ch.polys[i]) as c, multi.worker_open(i, ch.polys[i], ch.alpha) as d:
+            assert c.json()["commitment"] == a.json()["commitment"] and d.json()["proof"] == a.json()["proof"]
+    for g, e in enumerate(engines):                                      # every engine saw its own worker indices only
+        assert e.seen and all(w % 3 == g for _, w in e.seen), (g, e.seen)
+    miner = Miner(default_config(scale=7, machines_scale=2), client=multi)
+    responses = [miner.forward(ch.to_synapse(i)) for i in range(4)]
+    assert [r.commitment for r in responses] == [a.json()["commitment"] for a in answers]
+    assert verify_all(multi, ch, responses, threads=2) == [True] * 4
+    assert multi.worker_commit(9, ch.polys[0]).status_code == 400        # index outside 2^machines_scale, as Client
+    with multi.aggregate_commitments([r.commitment for r in responses]) as r, \
+            single.aggregate_commitments([r.commitment for r in responses]) as s:
+        assert r.status_code == s.status_code and r.json() == s.json()
+    multi.stop()
+    assert multi.worker_commit(0, ch.polys[0]).status_code == 503

@@ -1,0 +1,141 @@
+"""`MultiDeviceClient`: one host process, G MI355X -- one `Client` (= one kzg_ctx, its own lanes and streams) per GPU,
+requests routed by worker index, host threads only, NO collective.
+
+This is the in-process form of the reference's only distribution scheme: Pianist rows are independent, the validator
+sends row i to miner i (reference neurons/validator.py:194-222) and each miner process builds ONE prover client
+(base/miner.py:73-84).  A host with several GPUs can instead serve
+
+  * a miner's rows:      worker index i  ->  device devices[i mod G]   (`worker_commit` / `worker_open` /
+                         `worker_commit_and_open`: same signatures and responses as `Client`, so `Miner(client=...)`
+                         takes it unchanged), and `commit_and_open_rows` fans a batch of rows out over the devices;
+  * a validator's step:  the 2^machines_scale `eval(fft(poly[i], inverse), alpha)` rows of `generate_challenge`
+                         (neurons/validator.py:106-120) spread round-robin over the devices (`fft_eval_rows`).
+
+Every device holds the setup it needs: with a setup file each context loads the whole file (mainnet: 34 GB of tables
+per GPU, of 288); with a synthetic seed each context generates only the slices routed to it.  SURVEY 8b proposed
+`kzg_create(device_count, device_ids)`; the C-ABI keeps one ctx = one GPU and this class is the router above it."""
+from __future__ import annotations
+
+from concurrent.futures import ThreadPoolExecutor
+from typing import List, Optional, Sequence
+
+from .client import Client, Response
+
+
+class MultiDeviceClient:
+    def __init__(self, devices: Sequence[int], port: int = 1337, bin: str = "", uncompressed: bool = True,
+                 setup_path: str = "", precompute_path: str = "", seed: Optional[int] = None,
+                 synthetic: Optional[bool] = None, engines: Optional[Sequence[object]] = None):
+        if not devices:
+            raise ValueError("MultiDeviceClient needs at least one device")
+        if engines is not None and len(engines) != len(devices):
+            raise ValueError("one injected engine per device")
+        self.devices = list(devices)
+        self._kw = dict(port=port, bin=bin, uncompressed=uncompressed, setup_path=setup_path,
+                        precompute_path=precompute_path, seed=seed, synthetic=synthetic)
+        self._engines = list(engines) if engines is not None else None
+        self.clients: List[Client] = []
+        self.scale = self.machines_scale = 0
+        self._rr = 0
+        self._pool: Optional[ThreadPoolExecutor] = None
+
+    # ------------------------------------------------------------------ lifecycle
+    def start(self, scale: int = 18, machines_scale: int = 8) -> None:
+        G = len(self.devices)
+        M = 1 << machines_scale
+        self.scale, self.machines_scale = scale, machines_scale
+        started: List[Client] = []
+        try:
+            for g, dev in enumerate(self.devices):
+                kw = dict(self._kw)
+                synthetic = kw["synthetic"] if kw["synthetic"] is not None else kw["seed"] is not None
+                # a synthetic setup generates only the slices this device serves; a setup file is loaded whole
+                workers = [i for i in range(M) if i % G == g] if synthetic and not kw["setup_path"] else None
+                c = Client(device=dev, workers=workers, engine=self._engines[g] if self._engines else None, **kw)
+                c.start(scale, machines_scale)
+                started.append(c)
+        except BaseException:
+            for c in started:
+                c.stop()
+            raise
+        self.clients = started
+        self._pool = ThreadPoolExecutor(max_workers=4 * G, thread_name_prefix="kzg-multi")   # four lanes per context
+
+    def stop(self) -> None:
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+        for c in self.clients:
+            c.stop()
+        self.clients = []
+
+    # ------------------------------------------------------------------ routing
+    def device_of(self, i: int) -> int:
+        return self.devices[int(i) % len(self.devices)]
+
+    def _for(self, i: int) -> Client:
+        if not self.clients:
+            return _NOT_STARTED
+        return self.clients[int(i) % len(self.clients)]
+
+    def _any(self) -> Client:
+        if not self.clients:
+            return _NOT_STARTED
+        self._rr = (self._rr + 1) % len(self.clients)        # benign race: any client will do
+        return self.clients[self._rr]
+
+    # miner side (reference neurons/miner.py:38-61): same calls, routed by worker index
+    def worker_commit(self, i: int, poly: Sequence[str]):
+        return self._for(i).worker_commit(i, poly)
+
+    def worker_open(self, i: int, poly: Sequence[str], x: str):
+        return self._for(i).worker_open(i, poly, x)          # same device as the commit: its row cache serves the pair
+
+    def worker_commit_and_open(self, i: int, poly: Sequence[str], x: str):
+        return self._for(i).worker_commit_and_open(i, poly, x)
+
+    def commit_and_open_rows(self, indices: Sequence[int], polys: Sequence[Sequence[str]], x: str) -> List[Response]:
+        """Pianist rows of one challenge, all devices at once: row k runs on the device of indices[k]; responses in input
+        order.  Host threads only (ctypes releases the GIL inside every call); nothing is exchanged between devices."""
+        if len(indices) != len(polys):
+            raise ValueError("one polynomial per index")
+        if self._pool is None:
+            return [_NOT_STARTED.worker_commit_and_open(i, p, x) for i, p in zip(indices, polys)]
+        return list(self._pool.map(lambda t: self.worker_commit_and_open(t[0], t[1], x), zip(indices, polys)))
+
+    # validator side (reference neurons/validator.py:58-120)
+    def worker_verify(self, i: int, proof: str, alpha: str, eval: str, commitment: str):
+        return self._for(i).worker_verify(i, proof, alpha, eval, commitment)      # host-side pairing: any would do
+
+    def worker_verify_batch(self, indices, proofs, alpha, evals, commitments, threads: int = 16):
+        return (self.clients[0] if self.clients else _NOT_STARTED).worker_verify_batch(indices, proofs, alpha, evals,
+                                                                                       commitments, threads)
+
+    def fft(self, poly: Sequence[str], left: bool = True, inverse: bool = False):
+        return self._any().fft(poly, left, inverse)
+
+    def eval(self, poly: Sequence[str], x: str):
+        return self._any().eval(poly, x)
+
+    def fft_eval(self, poly: Sequence[str], x: str, left: bool = True, inverse: bool = True):
+        return self._any().fft_eval(poly, x, left, inverse)
+
+    def fft_eval_rows(self, polys: Sequence[Sequence[str]], x: str, left: bool = True, inverse: bool = True) -> List[Response]:
+        """The per-row challenge step eval(fft(poly[i], left, inverse), x) for many rows, row k on device k mod G."""
+        if self._pool is None:
+            return [_NOT_STARTED.fft_eval(p, x, left, inverse) for p in polys]
+        G = len(self.clients)
+        return list(self._pool.map(lambda t: self.clients[t[0] % G].fft_eval(t[1], x, left, inverse), enumerate(polys)))
+
+    def random_poly(self):
+        return self._any().random_poly()
+
+    def random_point(self):
+        return self._any().random_point()
+
+    def aggregate_commitments(self, commitments: Sequence[str]):
+        return (self.clients[0] if self.clients else _NOT_STARTED).aggregate_commitments(commitments)
+
+
+_NOT_STARTED = Client(engine=None)      # engine None -> every call answers 503 "prover not started", as Client does
+_NOT_STARTED._own_engine = False

@@ -30,6 +30,10 @@ def generate_challenge(client, machines_count: int) -> Challenge:  # reference n
     poly = _ok(client.random_poly(), "poly", "generate a random polynomial")
     alpha = _ok(client.random_point(), "point", "generate a random x")
     evals = []
+    rows = getattr(client, "fft_eval_rows", None)   # MultiDeviceClient: the rows of the step spread over the host's GPUs
+    if rows is not None:
+        return Challenge(polys=poly, alpha=alpha,
+                         evals=[_ok(r, "y", "evaluate the polynomial") for r in rows(poly[:machines_count], alpha, True, True)])
     fused = getattr(client, "fft_eval", None)       # this package's Client: both steps in one call, nothing through text
     for i in range(machines_count):
         if fused is not None:
