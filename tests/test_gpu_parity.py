@@ -441,6 +441,19 @@ def test_ntt_kernel_variants_agree(env):
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
 
 
+@pytest.mark.parametrize("env", [{}, {"KZG_POLY_NO_LDS": "1"}])
+def test_poly_kernel_variants_agree(env):
+    """Opening kernels of long rows: the LDS-staged level-0 fold / quotient (default from 2^18 coefficients) and the
+    strided forms they replace (KZG_POLY_NO_LDS=1) both give the oracle's evaluation, quotient commitment and eval() --
+    alpha = random, 0, 1, a root of unity, r - 1."""
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "poly_variant_check.py"), "18", "19"],
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("rounds", ["1", "2"])
 def test_sort_round_variants_agree(rounds):

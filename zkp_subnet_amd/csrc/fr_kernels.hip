@@ -342,8 +342,14 @@ KZG_DEV void bfly(fr9_t& u, fr9_t& v, const fr9_t& w) {     // (u, v) <- (u + v 
     fr9_sub4(v, u, t);
     fr9_add(u, u, t);
 }
+// A/B knob: -DKZG_NTT4_OCC4 asks for four waves per SIMD (<= 128 VGPRs; the non-first passes then spill 16 dwords)
+#ifdef KZG_NTT4_OCC4
+#define NTT4_BOUNDS(N) __launch_bounds__(N, 1024 / (N))
+#else
+#define NTT4_BOUNDS(N) __launch_bounds__(N)
+#endif
 template <uint32_t NT_, bool LAST>
-__global__ void __launch_bounds__(NT_) k_fr_ntt_pass4(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+__global__ void NTT4_BOUNDS(NT_) k_fr_ntt_pass4(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                        uint32_t* __restrict__ mid, int log_n, int s0, int S, int logC,
                                                        const uint32_t* __restrict__ tw,
                                                        const uint32_t* __restrict__ scale_or_null) {
@@ -681,6 +687,116 @@ __global__ void __launch_bounds__(256) k_poly_quotient(const uint32_t* __restric
     }
 }
 
+// ---- long rows (16 coefficients per lane): the same two kernels with the coefficients staged through LDS.
+// A lane of the kernels above walks ITS 512-byte chunk, so one wave load touches 64 pieces of 32 bytes at a 512-byte
+// stride (k_poly_quotient: 2.3 TB/s for 256 MB, with the caches reassembling the lines).  Here ONE WAVE per workgroup
+// takes 64 consecutive chunks (32 KB of the vector) in two halves of 8 coefficients per chunk: each half is moved
+// between HBM and LDS by the whole wave in 16-byte units -- a wave instruction covers four whole 256-byte segments --
+// and the lanes run their recurrences out of (and, for the quotient, back into) LDS rows padded to 272 bytes (17 units:
+// rows 4 banks apart, conflict-free for 16-byte accesses).  16.3 KB per wave: up to nine waves per CU.
+#define PQ_ROW 17   // 16-byte units per LDS row (16 + 1 of padding)
+KZG_DEV void pq_load_half(uint4 (*sm)[PQ_ROW], const uint4* __restrict__ src, uint32_t hoff, uint32_t lane) {
+    uint4 tmp[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {   // all sixteen loads in flight before the first LDS write
+        const uint32_t u = (uint32_t)i * 64 + lane;
+        tmp[i] = src[(uint64_t)(u >> 4) * 32 + hoff + (u & 15)];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t u = (uint32_t)i * 64 + lane;
+        sm[u >> 4][u & 15] = tmp[i];
+    }
+}
+KZG_DEV void pq_row_load(fr9_t& v, const uint4* row, int k) {
+    const uint4 a = row[2 * k], b = row[2 * k + 1];
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    fr9_from_words(v, w);
+}
+// h[t] = sum_k f[16 t + k] alpha^k for the 64 chunks of this workgroup; n a multiple of 1024
+template <bool ARG>
+__global__ void __launch_bounds__(64) k_poly_chunk_eval16_lds(const uint32_t* __restrict__ f,
+                                                               const uint32_t* __restrict__ alpha_mont,
+                                                               uint32_t* __restrict__ h, const FrArg arg,
+                                                               uint32_t* __restrict__ alpha_out, uint32_t* __restrict__ bad) {
+    __shared__ uint4 sm[64][PQ_ROW];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t chunk0 = (uint64_t)blockIdx.x * 64;
+    const uint4* src = reinterpret_cast<const uint4*>(f) + chunk0 * 32;
+    fr9_t a, s, c;
+    if constexpr (ARG) {
+        uint32_t w[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = bswap32(arg.w[7 - i]);
+        fr9_from_words(a, w);
+        fr9_to_mont(a, a);
+        if (chunk0 + lane == 0) {
+            if (fr_words_ge_r(w)) atomicOr(bad, 1u);
+            fr9_store(alpha_out, a);
+        }
+    } else {
+        fr9_load(a, alpha_mont);
+    }
+    fr9_canon(a, a);
+    fr9_zero(s);
+    for (int ph = 0; ph < 2; ph++) {
+        pq_load_half(sm, src, ph ? 0u : 16u, lane);   // the high half first: Horner runs from the top coefficient down
+        __syncthreads();
+#pragma unroll 2
+        for (int k = 7; k >= 0; k--) {
+            pq_row_load(c, sm[lane], k);
+            fr9_mul(s, s, a);
+            fr9_add(s, s, c);
+        }
+        __syncthreads();
+    }
+    fr9_reduce(s, s);
+    fr9_store(h + 8 * (chunk0 + lane), s);
+}
+// q[j-1] = sum_{k>=j} f_k alpha^(k-j), canonical, for the 1024 coefficients of this workgroup; q[n-1] = 0
+__global__ void __launch_bounds__(64) k_poly_quotient16_lds(const uint32_t* __restrict__ f, uint64_t n,
+                                                             const uint32_t* __restrict__ alpha_mont,
+                                                             const uint32_t* __restrict__ hnext,
+                                                             uint32_t* __restrict__ q_canon) {
+    __shared__ uint4 sm[64][PQ_ROW];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t chunk0 = (uint64_t)blockIdx.x * 64;
+    const uint4* src = reinterpret_cast<const uint4*>(f) + chunk0 * 32;
+    uint4* dst = reinterpret_cast<uint4*>(q_canon);
+    fr9_t a, s, c, o;
+    fr9_load(a, alpha_mont);
+    fr9_load(s, hnext + 8 * (chunk0 + lane));
+    for (int ph = 0; ph < 2; ph++) {
+        const uint32_t hoff = ph ? 0u : 16u;
+        pq_load_half(sm, src, hoff, lane);
+        __syncthreads();
+#pragma unroll 2
+        for (int k = 7; k >= 0; k--) {
+            pq_row_load(c, sm[lane], k);
+            fr9_mul(s, s, a);
+            fr9_add(s, s, c);
+            fr9_from_mont(o, s);
+            uint32_t w[8];
+            fr9_to_words(w, o);
+            sm[lane][2 * k] = make_uint4(w[0], w[1], w[2], w[3]);       // in place: the slot the coefficient came from
+            sm[lane][2 * k + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+        __syncthreads();
+        // the value computed at coefficient j is q[j - 1]: the whole half moves down by one coefficient (two units)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint32_t u = (uint32_t)i * 64 + lane;
+            const uint64_t gu = (chunk0 + (u >> 4)) * 32 + hoff + (u & 15);
+            if (gu >= 2) dst[gu - 2] = sm[u >> 4][u & 15];
+        }
+        __syncthreads();
+    }
+    if ((chunk0 + lane + 1) * 16 == n) {  // slot n - 1: a zero, so that the n - 1 coefficients ride as a length-n scalar set
+        dst[2 * (n - 1)] = make_uint4(0u, 0u, 0u, 0u);
+        dst[2 * (n - 1) + 1] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 void launch_fr_from_be(hipStream_t s, const uint8_t* be, uint32_t* out, uint64_t n, int to_mont, uint32_t* bad) {
     if (n) k_fr_from_be<<<nblk(n, 256), 256, 0, s>>>(be, out, n, to_mont, bad);
@@ -808,7 +924,16 @@ void launch_poly_open(hipStream_t s, const uint32_t* f_mont, uint64_t n, uint32_
     int K = 1;
     lv_l[0] = l0; lv_sq[0] = 0; lv_n[0] = n; lv_off[0] = 0;           // level 0 = f itself (offset unused)
     lv_n[1] = (n + ((uint64_t)1 << l0) - 1) >> l0; lv_sq[1] = l0; lv_off[1] = 0;
-    if (alpha_be32_host)
+    // long rows: the level-0 fold and the quotient with their coefficients staged through LDS (KZG_POLY_NO_LDS=1: the
+    // strided forms, kept for the A/B and as the reference of test_poly_kernel_variants_agree)
+    static const bool no_lds = getenv("KZG_POLY_NO_LDS") != nullptr;
+    const bool lds = !no_lds && l0 == 4 && (n & 1023) == 0;
+    if (lds) {
+        if (alpha_be32_host)
+            k_poly_chunk_eval16_lds<true><<<(uint32_t)(n >> 10), 64, 0, s>>>(f_mont, alpha_mont, h, arg, alpha_mont, bad);
+        else
+            k_poly_chunk_eval16_lds<false><<<(uint32_t)(n >> 10), 64, 0, s>>>(f_mont, alpha_mont, h, arg, nullptr, nullptr);
+    } else if (alpha_be32_host)
         k_poly_chunk_eval<true><<<nblk(lv_n[1], 256), 256, 0, s>>>(f_mont, n, l0, alpha_mont, 0, h, arg, alpha_mont, bad);
     else
         k_poly_chunk_eval<false><<<nblk(lv_n[1], 256), 256, 0, s>>>(f_mont, n, l0, alpha_mont, 0, h, arg, nullptr, nullptr);
@@ -833,6 +958,8 @@ void launch_poly_open(hipStream_t s, const uint32_t* f_mont, uint64_t n, uint32_
         k_poly_chunk_expand<<<nblk(lv_n[k + 1], 256), 256, 0, s>>>(h + 8 * lv_off[k], lv_n[k], lv_l[k], alpha_mont,
                                                                    lv_sq[k], hnext + 8 * lv_off[k + 1],
                                                                    hnext + 8 * lv_off[k]);
-    if (q_canon_or_null)
-        k_poly_quotient<<<nblk(lv_n[1], 256), 256, 0, s>>>(f_mont, n, l0, alpha_mont, hnext, q_canon_or_null);
+    if (q_canon_or_null) {
+        if (lds) k_poly_quotient16_lds<<<(uint32_t)(n >> 10), 64, 0, s>>>(f_mont, n, alpha_mont, hnext, q_canon_or_null);
+        else k_poly_quotient<<<nblk(lv_n[1], 256), 256, 0, s>>>(f_mont, n, l0, alpha_mont, hnext, q_canon_or_null);
+    }
 }
