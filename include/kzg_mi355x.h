@@ -102,9 +102,11 @@ int kzg_commit_open(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t 
 /* The UNCHANGED reference miner makes two calls per request with the same row -- worker_commit(i, poly), then
  * worker_open(i, poly, x) (neurons/miner.py:56-61).  These forms take a 128-bit content tag identifying the row's bytes
  * (the host codec computes it while decoding the text); the coefficient vectors of the last four rows stay on the
- * device, and a call whose (tag, T, evaluation_form) is cached skips upload + INTT.  A miss behaves exactly like
- * kzg_commit / kzg_open and leaves its own coefficients behind.  Results are identical either way.  The caller vouches
- * that equal tags mean equal rows. */
+ * device, and a call whose (tag, T, evaluation_form) is cached skips the INTT and keeps the row's upload off its critical
+ * path.  A miss behaves exactly like kzg_commit / kzg_open and leaves its own coefficients behind.  Results are
+ * identical either way, whatever the tags: a tag is a HINT -- on a hit the library uploads row_be32 beside the request
+ * and compares it bit for bit with the row the slot was filled from; two different rows under one tag each get their
+ * own answer (the colliding slot is dropped and the call recomputed), so a fast non-cryptographic tag is safe. */
 int kzg_commit_cached(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
                       const uint8_t content_tag[16], uint8_t out_commitment48[48]);
 int kzg_open_cached(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,

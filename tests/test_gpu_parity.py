@@ -441,11 +441,11 @@ def test_ntt_kernel_variants_agree(env):
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
 
 
-@pytest.mark.parametrize("env", [{}, {"KZG_POLY_NO_LDS": "1"}])
+@pytest.mark.parametrize("env", [{"KZG_POLY_LDS_MIN_LOG": "18"}, {"KZG_POLY_NO_LDS": "1"}])
 def test_poly_kernel_variants_agree(env):
-    """Opening kernels of long rows: the LDS-staged level-0 fold / quotient (default from 2^18 coefficients) and the
-    strided forms they replace (KZG_POLY_NO_LDS=1) both give the oracle's evaluation, quotient commitment and eval() --
-    alpha = random, 0, 1, a root of unity, r - 1."""
+    """Opening kernels of long rows: the LDS-staged level-0 fold / quotient (default from 2^22 coefficients; forced from
+    2^18 here) and the strided forms they replace (KZG_POLY_NO_LDS=1) both give the oracle's evaluation, quotient
+    commitment and eval() -- alpha = random, 0, 1, a root of unity, r - 1."""
     import subprocess
     import sys
 
@@ -1562,3 +1562,42 @@ def test_multi_device_client_two_contexts_on_one_gpu():
         assert verify_all(multi, ch, responses, threads=4) == [True] * 4
     finally:
         multi.stop()
+
+
+def test_row_cache_hit_is_verified_against_the_row_not_trusted_to_the_tag(hip):
+    """kzg_commit_cached / kzg_open_cached take a 128-bit content tag from the caller (the codec's keyed hash: fast, but
+    with no cryptographic analysis -- ADVICE r3).  The tag is only a hint: on a hit the caller's row is uploaded beside
+    the request and compared bit for bit with the row the slot was filled from.  TWO DIFFERENT rows under the SAME tag
+    must each get their own, oracle-equal answers -- never the other row's proof -- and the colliding slot is dropped."""
+    import ctypes
+
+    eng = hip()
+    lg = 10
+    T = 1 << lg
+    eng.gen_srs(0xC0111DE, 1, lg, 0)
+    srs = eng.srs_read(0, T)
+    row_a, row_b = rand_scalars_bytes(T, 1201), rand_scalars_bytes(T, 1202)
+    row_b2 = row_a[:32 * 500] + row_b[32 * 500:32 * 501] + row_a[32 * 501:]       # differs from A in ONE element
+    alpha = rand_scalars_bytes(1, 1203)
+    tag = bytes(range(16))
+
+    def commit(row):
+        out = ctypes.create_string_buffer(48)
+        eng._chk(eng._lib.kzg_commit_cached(eng._h, 0, row, T, 1, tag, out))
+        return out.raw
+
+    def open_(row):
+        ev, pf = ctypes.create_string_buffer(32), ctypes.create_string_buffer(48)
+        eng._chk(eng._lib.kzg_open_cached(eng._h, 0, row, T, 1, tag, alpha, ev, pf))
+        return ev.raw, pf.raw
+
+    h0, m0 = eng.row_cache_stats()
+    assert commit(row_a) == oc.commit(srs, row_a, True)                        # miss: fills the slot under `tag`
+    assert open_(row_a) == oc.open_(srs, row_a, alpha, True)                   # genuine hit
+    assert eng.row_cache_stats() == (h0 + 1, m0 + 1)
+    for other in (row_b, row_b2):
+        assert open_(other) == oc.open_(srs, other, alpha, True)               # same tag, different row: recomputed
+        assert commit(other) == oc.commit(srs, other, True)
+        assert open_(row_a) == oc.open_(srs, row_a, alpha, True)               # ... and A is still A
+    hits, misses = eng.row_cache_stats()
+    assert hits == h0 + 1 and misses >= m0 + 5                                 # no collision was ever counted as a hit

@@ -102,7 +102,8 @@ enum { LANE_FREE = 0, LANE_CALL, LANE_TICKET, LANE_WAITING };
 enum {
     TB_RES0 = 0, TB_RES1 = 224,   // result points, XYZZ working form (2 x 224 B)
     TB_EVAL = 448,                // y = f(alpha), 32 B big-endian
-    TB_FLAGS = 480,               // u32 x 4: [0] bad scalar, [1] bad point, [2] longest carry run, [3] spare
+    TB_FLAGS = 480,               // u32 x 4: [0] bad scalar, [1] bad point, [2] longest carry run, [3] sort overflow
+    TB_VERIFY = 496,              // u32: a row-cache hit whose uploaded bytes differ from the cached row's (kzg_*_cached)
     TB_C48 = 512, TB_P48 = 576,   // GPU-side encodings (host_finish off)
     TB_PART = 640,                // 192-byte partial (GPU-side packing)
     TB_COPY = 832,
@@ -129,6 +130,9 @@ struct Lane {
     bool sort_ws_clean = false;   // the sort's partition counts are zero (left so by every completed sort)
     int skew_hint = 0;            // > 0: the last fast sort overflowed (skewed scalars): go straight to the exact sort
     hipEvent_t ev_sorted = nullptr, ev_done = nullptr, ev_coeffs = nullptr, ev_ext = nullptr, ev_acc = nullptr;
+    hipStream_t vstream = nullptr;   // row-cache hits: upload of the caller's row + its comparison with the cached one,
+    hipEvent_t ev_verify = nullptr;  // beside the request's own kernels (the lane's publish waits for this event)
+    DevBuf vbuf;
     int state = LANE_FREE;
     bool partial = false;         // outstanding ticket wants the 192-byte partial
     // profiling spans of the call running on this lane
@@ -187,8 +191,9 @@ struct kzg_ctx {
         int eval_form = 0;
         bool valid = false, busy = false;
         DevBuf coef;
+        DevBuf raw;        // the row's 32-byte big-endian elements as they were uploaded: what a hit is verified against
     } rcache[N_LANES];
-    uint64_t rc_clock = 0, rc_hits = 0, rc_misses = 0;
+    uint64_t rc_clock = 0, rc_hits = 0, rc_misses = 0, rc_tag_collisions = 0;
 };
 
 namespace {
@@ -293,6 +298,7 @@ struct LaneHold {
     }
     void drain() {   // wait for everything this call queued (what the destructor does for a call that did not end cleanly)
         if (li >= 0) (void)hipStreamSynchronize(ctx->lane[li].stream);
+        if (li >= 0) (void)hipStreamSynchronize(ctx->lane[li].vstream);
         if (li2 >= 0) (void)hipStreamSynchronize(ctx->lane[li2].stream);
         (void)hipGetLastError();
     }
@@ -300,6 +306,7 @@ struct LaneHold {
         if (li < 0) return;
         if (!clean) {
             (void)hipStreamSynchronize(ctx->lane[li].stream);
+            (void)hipStreamSynchronize(ctx->lane[li].vstream);
             ctx->lane[li].sort_ws_clean = false;
             if (li2 >= 0) {
                 (void)hipStreamSynchronize(ctx->lane[li2].stream);
@@ -745,7 +752,7 @@ int upload_fr(kzg_ctx* ctx, Lane& L, const uint8_t* be32, uint64_t n, uint32_t* 
 #endif
 int commit_open_dev(kzg_ctx* ctx, LaneHold& H, uint32_t i, const uint32_t* row_dev, uint64_t T, int evaluation_form,
                     const uint8_t* alpha_be32, uint8_t* out_c48, uint8_t* out_eval32, uint8_t* out_p48,
-                    const uint32_t* coeffs_ready = nullptr, uint32_t* coeffs_dst = nullptr) {
+                    const uint32_t* coeffs_ready = nullptr, uint32_t* coeffs_dst = nullptr, hipEvent_t before_publish = nullptr) {
     Lane& A = H.L();
     hipStream_t s = A.stream;
     const uint32_t* coeffs = coeffs_ready;     // row cache hit: the coefficient vector is already on the device
@@ -797,6 +804,7 @@ int commit_open_dev(kzg_ctx* ctx, LaneHold& H, uint32_t i, const uint32_t* row_d
         }
     }
     queue_encode(ctx, A, out_c48 != nullptr, out_p48 != nullptr);
+    if (before_publish) HIPCHK(ctx, hipStreamWaitEvent(s, before_publish, 0));   // the record must carry TB_VERIFY's final value
     rc = finish(ctx, A);
     if (rc) return rc;
     if (out_c48 && out_p48 && ctx->host_finish)     // both points, one shared inversion
@@ -1060,7 +1068,9 @@ int kzg_create(int device_id, kzg_ctx** out) {
              hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&L.ev_coeffs, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&L.ev_ext, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&L.ev_acc, hipEventDisableTiming) == hipSuccess;
+             hipEventCreateWithFlags(&L.ev_acc, hipEventDisableTiming) == hipSuccess &&
+             hipStreamCreateWithFlags(&L.vstream, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&L.ev_verify, hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) {
         kzg_destroy(ctx);
@@ -1075,12 +1085,14 @@ void kzg_destroy(kzg_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (Lane& L : ctx->lane) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
-        for (DevBuf* b : {&L.rank, &L.sorted, &L.hist, &L.offsets, &L.bufA, &L.bufB, &L.bufC, &L.bufD, &L.carries, &L.carry_key,
+        if (L.vstream) (void)hipStreamSynchronize(L.vstream);
+        for (DevBuf* b : {&L.vbuf, &L.rank, &L.sorted, &L.hist, &L.offsets, &L.bufA, &L.bufB, &L.bufC, &L.bufD, &L.carries, &L.carry_key,
                           &L.in_be, &L.scal, &L.coeffA, &L.coeffB, &L.qbuf, &L.hbuf, &L.hnext, &L.out_be, &L.ntt_mid, &L.gather})
             b->release();
         for (hipEvent_t e : L.ev_pool) (void)hipEventDestroy(e);
-        for (hipEvent_t e : {L.ev_sorted, L.ev_done, L.ev_coeffs, L.ev_ext, L.ev_acc})
+        for (hipEvent_t e : {L.ev_sorted, L.ev_done, L.ev_coeffs, L.ev_ext, L.ev_acc, L.ev_verify})
             if (e) (void)hipEventDestroy(e);
+        if (L.vstream) (void)hipStreamDestroy(L.vstream);
         if (L.tail) (void)hipFree(L.tail);
         if (L.pin) (void)hipHostFree(L.pin);
         if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -1559,9 +1571,10 @@ static int commit_open_host(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, u
 // ---- the UNCHANGED reference miner (neurons/miner.py:56-61) calls worker_commit(i, poly) and then worker_open(i, poly, x)
 // with the same row: the second call used to decode, upload and inverse-transform it all over again.  With a content tag
 // (a 128-bit keyed hash the codec folds into its decode pass) the coefficient vector of the last few rows stays on the
-// device: a call whose (tag, T, form) is cached skips upload + INTT; anything else behaves exactly like the untagged call
-// and leaves its own coefficients behind.  The library trusts the tag to identify the row's content -- that is the
-// caller's contract (zkp_subnet_amd/csrc/wire_py.c computes it over the decoded bytes with a per-process random key).
+// device: a call whose (tag, T, form) is cached skips the INTT and keeps the upload off its critical path; anything else
+// behaves exactly like the untagged call and leaves its own coefficients behind.  The tag (zkp_subnet_amd/csrc/wire_py.c:
+// a keyed multiply-fold over the decoded bytes, fast but with no cryptographic analysis) is a HINT, not a proof of
+// identity: every hit is verified bit for bit on the GPU against the row the slot was filled from.
 static int rcache_lookup(kzg_ctx* ctx, const uint8_t tag[16], uint64_t T, int ef) {
     std::lock_guard<std::mutex> lk(ctx->mu);
     for (int k = 0; k < N_LANES; k++) {
@@ -1612,22 +1625,55 @@ static int commit_open_host_cached(kzg_ctx* ctx, uint32_t i, const uint8_t* row_
     prof_begin(ctx, L);
     rc = clear_flags(ctx, L);
     if (rc) return rc;
-    const int look = rcache_lookup(ctx, tag, T, evaluation_form);
-    if (look >= 0) {          // hit: no upload, no INTT
-        rc = commit_open_dev(ctx, H, i, nullptr, T, evaluation_form, alpha, c48, e32, p48,
-                             ctx->rcache[look].coef.as<uint32_t>());
+    int look = rcache_lookup(ctx, tag, T, evaluation_form);
+    if (look >= 0) {
+        // hit: no INTT, and nothing of the row on the request's critical path.  The tag is only a HINT: the caller's row
+        // is uploaded on a side stream while the MSM runs and compared, bit for bit, with the row this slot was filled
+        // from; the publish waits for that verdict.  A colliding tag costs one wasted pass, never a wrong answer.
+        auto& e = ctx->rcache[look];
+        hipError_t he = L.vbuf.ensure(T * 32);
+        uint32_t* vflag = reinterpret_cast<uint32_t*>(L.tail + TB_VERIFY);
+        if (he == hipSuccess) he = hipMemsetAsync(vflag, 0, 4, L.vstream);
+        if (he == hipSuccess) he = hipMemcpyAsync(L.vbuf.p, row_be32, T * 32, hipMemcpyHostToDevice, L.vstream);
+        if (he == hipSuccess) {
+            launch_words_differ(L.vstream, L.vbuf.as<uint32_t>(), e.raw.as<uint32_t>(), T * 8, vflag);
+            he = hipEventRecord(L.ev_verify, L.vstream);
+        }
+        if (he != hipSuccess) {
+            (void)hipStreamSynchronize(L.vstream);
+            rcache_release(ctx, look, true, tag, T, evaluation_form);
+            return fail(ctx, he == hipErrorOutOfMemory ? KZG_E_NOMEM : KZG_E_HIP, std::string("row cache verification: ") + hipGetErrorString(he));
+        }
+        rc = commit_open_dev(ctx, H, i, nullptr, T, evaluation_form, alpha, c48, e32, p48, e.coef.as<uint32_t>(), nullptr,
+                             L.ev_verify);
         if (rc != KZG_OK) H.drain();            // queued kernels may still read the slot
-        rcache_release(ctx, look, true, tag, T, evaluation_form);
-        return rc;
+        const bool same = rc != KZG_OK || *reinterpret_cast<const volatile uint32_t*>(L.pin + TB_VERIFY) == 0;
+        rcache_release(ctx, look, same, tag, T, evaluation_form);   // a slot whose tag collided is dropped
+        if (same) return rc;
+        {   // equal tags, different rows: the answer just computed belongs to the OTHER row -- discard it, take the miss path
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            ctx->rc_hits--;
+            ctx->rc_misses++;
+            ctx->rc_tag_collisions++;
+        }
+        H.clean = false;
+        prof_begin(ctx, L);
+        rc = clear_flags(ctx, L);
+        if (rc) return rc;
+        look = -1;                              // no caching for this call (its tag is known to be ambiguous)
     }
     const int slot = look <= -2 ? -2 - look : -1;
     uint32_t* dst = nullptr;
     if (slot >= 0) {
-        if (ctx->rcache[slot].coef.ensure(T * 32) == hipSuccess) dst = ctx->rcache[slot].coef.as<uint32_t>();
+        auto& e = ctx->rcache[slot];
+        if (e.coef.ensure(T * 32) == hipSuccess && e.raw.ensure(T * 32) == hipSuccess) dst = e.coef.as<uint32_t>();
         else (void)hipGetLastError();
     }
     rc = L.coeffA.ensure(T * 32) == hipSuccess ? KZG_OK : fail(ctx, KZG_E_NOMEM, "row buffer");
     if (!rc) rc = upload_fr(ctx, L, row_be32, T, L.coeffA.as<uint32_t>(), 1);
+    if (!rc && dst)   // the uploaded bytes themselves stay with the slot: what a later hit is verified against
+        rc = hipMemcpyAsync(ctx->rcache[slot].raw.p, L.in_be.p, T * 32, hipMemcpyDeviceToDevice, L.stream) == hipSuccess
+                 ? KZG_OK : fail(ctx, KZG_E_HIP, "row cache: copy of the uploaded row");
     if (!rc) rc = commit_open_dev(ctx, H, i, L.coeffA.as<uint32_t>(), T, evaluation_form, alpha, c48, e32, p48, nullptr, dst);
     if (rc != KZG_OK && slot >= 0) H.drain();   // a failed call may have kernels queued that still write the slot: not reusable before
     if (slot >= 0) rcache_release(ctx, slot, rc == KZG_OK && dst != nullptr, tag, T, evaluation_form);

@@ -3,6 +3,7 @@
 // Replaces what the external prover does behind fft(poly,left,inverse) / eval / the implicit IFFT + synthetic
 // division of worker_commit / worker_open (reference neurons/validator.py:59-65,98-104; neurons/miner.py:39,48).
 // Domain convention: w_n = 7^((r-1)/n), natural order in and out, inverse carries 1/n.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -797,6 +798,23 @@ __global__ void __launch_bounds__(64) k_poly_quotient16_lds(const uint32_t* __re
     }
 }
 
+// *flag |= 1 when the two word arrays differ anywhere (row-cache hits: the caller's row against the cached row's bytes)
+__global__ void __launch_bounds__(256) k_words_differ(const uint4* __restrict__ a, const uint4* __restrict__ b, uint64_t n16,
+                                                       uint32_t* __restrict__ flag) {
+    uint32_t d = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 x = a[i], y = b[i];
+        d |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
+    }
+    if (__any(d != 0) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+void launch_words_differ(hipStream_t s, const uint32_t* a, const uint32_t* b, uint64_t n_words, uint32_t* flag) {
+    const uint64_t n16 = n_words / 4;   // rows are whole 32-byte elements
+    if (!n16) return;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n16 + 255) / 256, 2048);
+    k_words_differ<<<blocks, 256, 0, s>>>(reinterpret_cast<const uint4*>(a), reinterpret_cast<const uint4*>(b), n16, flag);
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 void launch_fr_from_be(hipStream_t s, const uint8_t* be, uint32_t* out, uint64_t n, int to_mont, uint32_t* bad) {
     if (n) k_fr_from_be<<<nblk(n, 256), 256, 0, s>>>(be, out, n, to_mont, bad);
@@ -927,7 +945,10 @@ void launch_poly_open(hipStream_t s, const uint32_t* f_mont, uint64_t n, uint32_
     // long rows: the level-0 fold and the quotient with their coefficients staged through LDS (KZG_POLY_NO_LDS=1: the
     // strided forms, kept for the A/B and as the reference of test_poly_kernel_variants_agree)
     static const bool no_lds = getenv("KZG_POLY_NO_LDS") != nullptr;
-    const bool lds = !no_lds && l0 == 4 && (n & 1023) == 0;
+    // from 2^22 coefficients: same-box A/B (profiles/r04_ab_opening_lds_staging.log) 2^22 0.284 -> 0.253 ms, 2^20 0.160 ->
+    // 0.172 (one wave per SIMD there: the LDS hop is pure latency), 2^18 equal.  KZG_POLY_LDS_MIN_LOG moves the threshold.
+    static const int lds_min_log = getenv("KZG_POLY_LDS_MIN_LOG") ? atoi(getenv("KZG_POLY_LDS_MIN_LOG")) : 22;
+    const bool lds = !no_lds && l0 == 4 && (n & 1023) == 0 && n >= ((uint64_t)1 << lds_min_log);
     if (lds) {
         if (alpha_be32_host)
             k_poly_chunk_eval16_lds<true><<<(uint32_t)(n >> 10), 64, 0, s>>>(f_mont, alpha_mont, h, arg, alpha_mont, bad);

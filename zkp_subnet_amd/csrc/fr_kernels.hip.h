@@ -23,3 +23,5 @@ void launch_fr_ntt(hipStream_t s, const uint32_t* in, uint32_t* out, int log_n, 
 void launch_poly_open(hipStream_t s, const uint32_t* f_mont, uint64_t n, uint32_t* alpha_mont, uint32_t* h,
                       uint32_t* hnext, uint32_t* y_mont, uint32_t* q_canon_or_null,
                       const uint8_t* alpha_be32_host = nullptr, uint32_t* bad = nullptr, uint8_t* y_be_or_null = nullptr);
+// *flag |= 1 when a[0, n_words) and b[0, n_words) differ (n_words a multiple of 4): verification of a row-cache hit
+void launch_words_differ(hipStream_t s, const uint32_t* a, const uint32_t* b, uint64_t n_words, uint32_t* flag);

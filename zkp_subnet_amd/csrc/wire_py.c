@@ -135,7 +135,9 @@ typedef struct {
 /* ---- content tag: identifies the decoded row for the prover's coefficient cache (the unchanged reference miner sends the
  * same row in worker_commit and worker_open, neurons/miner.py:56-61).  tag = sum over elements of a keyed 128-bit hash
  * of (index, 32 bytes), mod 2^128: independent of how the list is split over threads, bound to positions, and keyed with
- * 512 random bits drawn once per process, so equal tags cannot be arranged without the key.  Four 64x64->128 multiplies
+ * 512 random bits drawn once per process.  It is a fast keyed multiply-fold with NO cryptographic analysis (a zero
+ * multiplicand drops a word from a term, single lanes admit position swaps): the prover therefore treats it as a hint and
+ * verifies every cache hit against the cached row's bytes on the GPU (csrc/api.hip, commit_open_host_cached).  Four 64x64->128 multiplies
  * per element, folded into the decode pass (the bytes are still in the vector registers). */
 static uint64_t TAG_KEY[8];
 static inline uint64_t mum64(uint64_t a, uint64_t b) {
@@ -614,7 +616,7 @@ PyMODINIT_FUNC PyInit__wire(void) {
         if (e && *e == '1') have_avx2 = 0;
     }
 #endif
-    {   /* the tag key: 256 random bits per process (getrandom; /dev/urandom semantics) */
+    {   /* the tag key: 512 random bits per process (getrandom; /dev/urandom semantics) */
         ssize_t got = getrandom(TAG_KEY, sizeof(TAG_KEY), 0);
         if (got != (ssize_t)sizeof(TAG_KEY)) {
             PyErr_SetString(PyExc_OSError, "getrandom failed: cannot key the content tag");
