@@ -750,9 +750,14 @@ int upload_fr(kzg_ctx* ctx, Lane& L, const uint8_t* be32, uint64_t n, uint32_t* 
 #ifndef KZG_BATCHED_ROW_MAX
 #define KZG_BATCHED_ROW_MAX ((uint64_t)1 << 18)
 #endif
+struct VerifyJob {   // a row-cache hit's evidence: the caller's row (host) against the bytes the slot was filled from (device)
+    const uint8_t* row_be32;
+    uint64_t T;
+    const uint32_t* cached_raw;
+};
 int commit_open_dev(kzg_ctx* ctx, LaneHold& H, uint32_t i, const uint32_t* row_dev, uint64_t T, int evaluation_form,
                     const uint8_t* alpha_be32, uint8_t* out_c48, uint8_t* out_eval32, uint8_t* out_p48,
-                    const uint32_t* coeffs_ready = nullptr, uint32_t* coeffs_dst = nullptr, hipEvent_t before_publish = nullptr) {
+                    const uint32_t* coeffs_ready = nullptr, uint32_t* coeffs_dst = nullptr, const VerifyJob* verify = nullptr) {
     Lane& A = H.L();
     hipStream_t s = A.stream;
     const uint32_t* coeffs = coeffs_ready;     // row cache hit: the coefficient vector is already on the device
@@ -804,7 +809,16 @@ int commit_open_dev(kzg_ctx* ctx, LaneHold& H, uint32_t i, const uint32_t* row_d
         }
     }
     queue_encode(ctx, A, out_c48 != nullptr, out_p48 != nullptr);
-    if (before_publish) HIPCHK(ctx, hipStreamWaitEvent(s, before_publish, 0));   // the record must carry TB_VERIFY's final value
+    if (verify) {   // row-cache hit: queued LAST, so that its few runtime calls cost host time while the GPU is busy with the
+        // request's own kernels; the copy and the comparison run beside them, the publish waits for the verdict
+        uint32_t* vflag = reinterpret_cast<uint32_t*>(A.tail + TB_VERIFY);
+        HIPCHK(ctx, A.vbuf.ensure(verify->T * 32));
+        HIPCHK(ctx, hipMemsetAsync(vflag, 0, 4, A.vstream));
+        HIPCHK(ctx, hipMemcpyAsync(A.vbuf.p, verify->row_be32, verify->T * 32, hipMemcpyHostToDevice, A.vstream));
+        launch_words_differ(A.vstream, A.vbuf.as<uint32_t>(), verify->cached_raw, verify->T * 8, vflag);
+        HIPCHK(ctx, hipEventRecord(A.ev_verify, A.vstream));
+        HIPCHK(ctx, hipStreamWaitEvent(s, A.ev_verify, 0));   // the record must carry TB_VERIFY's final value
+    }
     rc = finish(ctx, A);
     if (rc) return rc;
     if (out_c48 && out_p48 && ctx->host_finish)     // both points, one shared inversion
@@ -1631,21 +1645,8 @@ static int commit_open_host_cached(kzg_ctx* ctx, uint32_t i, const uint8_t* row_
         // is uploaded on a side stream while the MSM runs and compared, bit for bit, with the row this slot was filled
         // from; the publish waits for that verdict.  A colliding tag costs one wasted pass, never a wrong answer.
         auto& e = ctx->rcache[look];
-        hipError_t he = L.vbuf.ensure(T * 32);
-        uint32_t* vflag = reinterpret_cast<uint32_t*>(L.tail + TB_VERIFY);
-        if (he == hipSuccess) he = hipMemsetAsync(vflag, 0, 4, L.vstream);
-        if (he == hipSuccess) he = hipMemcpyAsync(L.vbuf.p, row_be32, T * 32, hipMemcpyHostToDevice, L.vstream);
-        if (he == hipSuccess) {
-            launch_words_differ(L.vstream, L.vbuf.as<uint32_t>(), e.raw.as<uint32_t>(), T * 8, vflag);
-            he = hipEventRecord(L.ev_verify, L.vstream);
-        }
-        if (he != hipSuccess) {
-            (void)hipStreamSynchronize(L.vstream);
-            rcache_release(ctx, look, true, tag, T, evaluation_form);
-            return fail(ctx, he == hipErrorOutOfMemory ? KZG_E_NOMEM : KZG_E_HIP, std::string("row cache verification: ") + hipGetErrorString(he));
-        }
-        rc = commit_open_dev(ctx, H, i, nullptr, T, evaluation_form, alpha, c48, e32, p48, e.coef.as<uint32_t>(), nullptr,
-                             L.ev_verify);
+        const VerifyJob job{row_be32, T, e.raw.as<uint32_t>()};
+        rc = commit_open_dev(ctx, H, i, nullptr, T, evaluation_form, alpha, c48, e32, p48, e.coef.as<uint32_t>(), nullptr, &job);
         if (rc != KZG_OK) H.drain();            // queued kernels may still read the slot
         const bool same = rc != KZG_OK || *reinterpret_cast<const volatile uint32_t*>(L.pin + TB_VERIFY) == 0;
         rcache_release(ctx, look, same, tag, T, evaluation_form);   // a slot whose tag collided is dropped
