@@ -1602,3 +1602,30 @@ def test_row_cache_hit_is_verified_against_the_row_not_trusted_to_the_tag(hip):
     # accounting: round 1 -- open(B) collides (counted as a miss, slot dropped), commit(B) misses and fills the slot,
     # open(A) collides with it; round 2 -- open(B2) misses and fills, commit(B2) is a GENUINE hit, open(A) collides
     assert eng.row_cache_stats() == (h0 + 2, m0 + 6)                           # no collision was ever counted as a hit
+
+
+def test_calibrate_reports_a_plausible_mad_rate(hip):
+    """kzg_calibrate (what bench.py's mad_issue.peak comes from): the v_mad_u64_u32 issue rate of this GPU, measured on
+    the spot.  Plausibility only -- 1.5 .. 4 ns per wave-instruction per SIMD at >= 2 waves per SIMD (2.30 - 2.36 measured
+    on this pool), about twice that for a lone wave, 1024 SIMDs, a clock between 1 and 3 GHz -- and the documented
+    failures: bad argument, and KZG_E_BUSY while a ticket is out (it needs the whole context)."""
+    from zkp_subnet_amd._native import KZG_E_ARG, KZG_E_BUSY, KzgError
+
+    eng = hip()
+    two, one = eng.calibrate(2), eng.calibrate(1)
+    assert two["simds"] == 1024 and 1.5 < two["ns_per_mad_per_simd"] < 4.0, two
+    assert abs(two["gmad_per_s"] - 1024 / two["ns_per_mad_per_simd"]) < 1e-6
+    assert 1.4 * two["ns_per_mad_per_simd"] < one["ns_per_mad_per_simd"] < 3.0 * two["ns_per_mad_per_simd"], (one, two)
+    assert 1.0 < two["memtime_ticks_per_ns"] < 3.0 and 0.5 < two["kernel_ms"] < 10.0
+    with pytest.raises(KzgError) as ei:
+        eng.calibrate(9)
+    assert ei.value.code == KZG_E_ARG
+    eng.gen_srs(0x77, 1, 8, 0)
+    eng.upload_fr(0, rand_scalars_bytes(256, 5), False)
+    t = eng.msm_submit(0, 256, 0)
+    with pytest.raises(KzgError) as ei:
+        eng.calibrate(2)
+    assert ei.value.code == KZG_E_BUSY
+    got = eng.msm_wait(t)
+    assert got == eng.msm_resident(0, 256, 0)
+    assert 1.5 < eng.calibrate(2)["ns_per_mad_per_simd"] < 4.0
