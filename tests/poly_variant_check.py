@@ -24,5 +24,11 @@ for lg in [int(a) for a in sys.argv[1:]]:
         alpha = a.to_bytes(32, "big")
         assert eng.open(0, row, alpha, False) == oc.open_(srs, row, alpha, False, threads=8), ("open", lg, hex(a))
         assert eng.eval(row, alpha) == oc.fr_eval(row, alpha), ("eval", lg, hex(a))
+    # eval of a coefficient vector whose length is NOT a power of two: a multiple of 1024 (the staged form's granularity)
+    # and one that is not (falls back to the strided form whatever the knob says)
+    for n in (T + 3 * 1024, T + 3 * 1024 + 7):
+        ext = (row * 2)[:32 * n]
+        alpha = (0xFEDCBA9876543210 % o.R).to_bytes(32, "big")
+        assert eng.eval(ext, alpha) == oc.fr_eval(ext, alpha), ("eval ragged", lg, n)
     eng.close()
 print("ok")
