@@ -29,7 +29,7 @@
 #include "msm.hip.h"
 #include "fp_lp.hip.h"
 
-#define KZG_VERSION "kzg_mi355x 0.2 (gfx950)"
+#define KZG_VERSION "kzg_mi355x 0.4 (gfx950)"
 #define N_SLOTS 4
 #ifndef N_LANES
 #define N_LANES 4
