@@ -441,7 +441,8 @@ def test_ntt_kernel_variants_agree(env):
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
 
 
-@pytest.mark.parametrize("env", [{"KZG_POLY_LDS_MIN_LOG": "18"}, {"KZG_POLY_NO_LDS": "1"}])
+@pytest.mark.parametrize("env", [{"KZG_POLY_LDS_MIN_LOG": "18"}, {"KZG_POLY_LDS_MIN_LOG": "18", "KZG_POLY_EVAL_LDS": "1"},
+                                 {"KZG_POLY_NO_LDS": "1"}])
 def test_poly_kernel_variants_agree(env):
     """Opening kernels of long rows: the LDS-staged level-0 fold / quotient (default from 2^22 coefficients; forced from
     2^18 here) and the strided forms they replace (KZG_POLY_NO_LDS=1) both give the oracle's evaluation, quotient

@@ -688,25 +688,33 @@ __global__ void __launch_bounds__(256) k_poly_quotient(const uint32_t* __restric
     }
 }
 
-// ---- long rows (16 coefficients per lane): the same two kernels with the coefficients staged through LDS.
-// A lane of the kernels above walks ITS 512-byte chunk, so one wave load touches 64 pieces of 32 bytes at a 512-byte
-// stride (k_poly_quotient: 2.3 TB/s for 256 MB, with the caches reassembling the lines).  Here ONE WAVE per workgroup
-// takes 64 consecutive chunks (32 KB of the vector) in two halves of 8 coefficients per chunk: each half is moved
-// between HBM and LDS by the whole wave in 16-byte units -- a wave instruction covers four whole 256-byte segments --
-// and the lanes run their recurrences out of (and, for the quotient, back into) LDS rows padded to 272 bytes (17 units:
-// rows 4 banks apart, conflict-free for 16-byte accesses).  16.3 KB per wave: up to nine waves per CU.
-#define PQ_ROW 17   // 16-byte units per LDS row (16 + 1 of padding)
-KZG_DEV void pq_load_half(uint4 (*sm)[PQ_ROW], const uint4* __restrict__ src, uint32_t hoff, uint32_t lane) {
-    uint4 tmp[16];
+// ---- long rows (16 coefficients per lane): the quotient (and, as an A/B form, the level-0 fold) with the coefficients
+// staged through LDS.  A lane of the kernels above walks ITS 512-byte chunk, so one wave load touches 64 pieces of 32
+// bytes at a 512-byte stride (k_poly_quotient: 2.3 TB/s for 256 MB, with the caches reassembling the lines).  Here ONE
+// WAVE per workgroup takes 64 consecutive chunks (32 KB of the vector) in PHASES of PQ_CO coefficients per chunk: each
+// part is moved between HBM and LDS by the whole wave in 16-byte units -- a wave instruction covers whole 128-byte
+// segments -- and the lanes run their recurrences out of (and, for the quotient, back into) padded LDS rows.  With four
+// coefficients per phase a wave holds 9 KB of LDS and 8 staged loads: enough waves per SIMD to overlap one wave's
+// transfers with another's products (uncontended: 115 us strided -> 86 us with 8 per phase -> ~70 us with 4).
+// PQ_CO coefficients of every chunk per phase (8: two phases, 17-unit rows; 4: four phases, 9-unit rows -- half the LDS
+// and registers per wave, twice the phases).  Row stride = 2 PQ_CO + 1 units: odd, so consecutive rows start 4 banks apart.
+#ifndef PQ_CO
+#define PQ_CO 4   // same-box A/B at 2^22 (profiles/r04_ab_opening_lds_phases.log): opening 0.253 (8) -> 0.236 (4) -> 0.272 ms (2)
+#endif
+#define PQ_ROW (2 * PQ_CO + 1)
+#define PQ_PHASES (16 / PQ_CO)
+#define PQ_ITERS (2 * PQ_CO)        // 16-byte units per lane and phase: 64 rows x 2 PQ_CO units / 64 lanes
+KZG_DEV void pq_load_part(uint4 (*sm)[PQ_ROW], const uint4* __restrict__ src, uint32_t uoff, uint32_t lane) {
+    uint4 tmp[PQ_ITERS];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {   // all sixteen loads in flight before the first LDS write
+    for (int i = 0; i < PQ_ITERS; i++) {   // all loads in flight before the first LDS write
         const uint32_t u = (uint32_t)i * 64 + lane;
-        tmp[i] = src[(uint64_t)(u >> 4) * 32 + hoff + (u & 15)];
+        tmp[i] = src[(uint64_t)(u / (2 * PQ_CO)) * 32 + uoff + (u % (2 * PQ_CO))];
     }
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
+    for (int i = 0; i < PQ_ITERS; i++) {
         const uint32_t u = (uint32_t)i * 64 + lane;
-        sm[u >> 4][u & 15] = tmp[i];
+        sm[u / (2 * PQ_CO)][u % (2 * PQ_CO)] = tmp[i];
     }
 }
 KZG_DEV void pq_row_load(fr9_t& v, const uint4* row, int k) {
@@ -740,11 +748,11 @@ __global__ void __launch_bounds__(64) k_poly_chunk_eval16_lds(const uint32_t* __
     }
     fr9_canon(a, a);
     fr9_zero(s);
-    for (int ph = 0; ph < 2; ph++) {
-        pq_load_half(sm, src, ph ? 0u : 16u, lane);   // the high half first: Horner runs from the top coefficient down
+    for (int ph = 0; ph < PQ_PHASES; ph++) {
+        pq_load_part(sm, src, (uint32_t)(PQ_PHASES - 1 - ph) * 2 * PQ_CO, lane);   // the top coefficients first: Horner runs downward
         __syncthreads();
 #pragma unroll 2
-        for (int k = 7; k >= 0; k--) {
+        for (int k = PQ_CO - 1; k >= 0; k--) {
             pq_row_load(c, sm[lane], k);
             fr9_mul(s, s, a);
             fr9_add(s, s, c);
@@ -767,12 +775,12 @@ __global__ void __launch_bounds__(64) k_poly_quotient16_lds(const uint32_t* __re
     fr9_t a, s, c, o;
     fr9_load(a, alpha_mont);
     fr9_load(s, hnext + 8 * (chunk0 + lane));
-    for (int ph = 0; ph < 2; ph++) {
-        const uint32_t hoff = ph ? 0u : 16u;
-        pq_load_half(sm, src, hoff, lane);
+    for (int ph = 0; ph < PQ_PHASES; ph++) {
+        const uint32_t uoff = (uint32_t)(PQ_PHASES - 1 - ph) * 2 * PQ_CO;
+        pq_load_part(sm, src, uoff, lane);
         __syncthreads();
 #pragma unroll 2
-        for (int k = 7; k >= 0; k--) {
+        for (int k = PQ_CO - 1; k >= 0; k--) {
             pq_row_load(c, sm[lane], k);
             fr9_mul(s, s, a);
             fr9_add(s, s, c);
@@ -783,12 +791,12 @@ __global__ void __launch_bounds__(64) k_poly_quotient16_lds(const uint32_t* __re
             sm[lane][2 * k + 1] = make_uint4(w[4], w[5], w[6], w[7]);
         }
         __syncthreads();
-        // the value computed at coefficient j is q[j - 1]: the whole half moves down by one coefficient (two units)
+        // the value computed at coefficient j is q[j - 1]: the whole part moves down by one coefficient (two units)
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
+        for (int i = 0; i < PQ_ITERS; i++) {
             const uint32_t u = (uint32_t)i * 64 + lane;
-            const uint64_t gu = (chunk0 + (u >> 4)) * 32 + hoff + (u & 15);
-            if (gu >= 2) dst[gu - 2] = sm[u >> 4][u & 15];
+            const uint64_t gu = (chunk0 + u / (2 * PQ_CO)) * 32 + uoff + (u % (2 * PQ_CO));
+            if (gu >= 2) dst[gu - 2] = sm[u / (2 * PQ_CO)][u % (2 * PQ_CO)];
         }
         __syncthreads();
     }
@@ -945,11 +953,13 @@ void launch_poly_open(hipStream_t s, const uint32_t* f_mont, uint64_t n, uint32_
     // long rows: the level-0 fold and the quotient with their coefficients staged through LDS (KZG_POLY_NO_LDS=1: the
     // strided forms, kept for the A/B and as the reference of test_poly_kernel_variants_agree)
     static const bool no_lds = getenv("KZG_POLY_NO_LDS") != nullptr;
-    // from 2^22 coefficients: same-box A/B (profiles/r04_ab_opening_lds_staging.log) 2^22 0.284 -> 0.253 ms, 2^20 0.160 ->
-    // 0.172 (one wave per SIMD there: the LDS hop is pure latency), 2^18 equal.  KZG_POLY_LDS_MIN_LOG moves the threshold.
-    static const int lds_min_log = getenv("KZG_POLY_LDS_MIN_LOG") ? atoi(getenv("KZG_POLY_LDS_MIN_LOG")) : 22;
+    // from 2^21 coefficients: same-box A/Bs (profiles/r04_ab_opening_lds_staging.log, r04_ab_opening_lds_phases.log) of the
+    // opening stage: 2^22 0.284 -> 0.236 ms, 2^21 0.196 -> 0.185, 2^20 0.160 -> 0.167 (one wave per SIMD there: the LDS hop
+    // is pure latency).  KZG_POLY_LDS_MIN_LOG moves the threshold.
+    static const int lds_min_log = getenv("KZG_POLY_LDS_MIN_LOG") ? atoi(getenv("KZG_POLY_LDS_MIN_LOG")) : 21;
     const bool lds = !no_lds && l0 == 4 && (n & 1023) == 0 && n >= ((uint64_t)1 << lds_min_log);
-    if (lds) {
+    static const bool eval_lds = getenv("KZG_POLY_EVAL_LDS") != nullptr;   // A/B: the level-0 fold staged too (measured: no gain)
+    if (lds && eval_lds) {
         if (alpha_be32_host)
             k_poly_chunk_eval16_lds<true><<<(uint32_t)(n >> 10), 64, 0, s>>>(f_mont, alpha_mont, h, arg, alpha_mont, bad);
         else
