@@ -360,7 +360,58 @@ __global__ void NTT4_BOUNDS(NT_) k_fr_ntt_pass4(const uint32_t* __restrict__ in,
     const uint64_t n = (uint64_t)1 << log_n;
     const int log_nt = log_n - S;
     // ---- load (as k_fr_ntt_pass: bit reversal folded into the first pass, 48-byte slots between passes)
+    // The (at most four) elements of a lane are REQUESTED TOGETHER and unpacked afterwards: a rolled loop waits for one HBM
+    // round trip per element -- four latencies in a row at the head of every workgroup's life, which the two other
+    // workgroups of the CU cover only partly (28 % of a wave's resident cycles were waits).
     uint64_t base = 0, col0 = 0;
+#if !defined(KZG_NTT_ROLLED_LOADS) && !defined(KZG_NTT_MID48)
+    {
+        const uint32_t* src = first ? in : mid;
+        uint64_t idx[4];
+        uint32_t dst[4];
+        if (first) {
+            const uint64_t NT = (uint64_t)1 << log_nt;
+            const uint64_t u = blockIdx.x;
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const uint32_t e = threadIdx.x + (uint32_t)it * NT_;
+                const uint32_t rp = e >> logC, c = e & (C - 1);
+                idx[it] = (uint64_t)rp * NT + u * C + c;
+                dst[it] = (c << S) + brev_bits(rp, S);        // LDS layout [tile][row]
+            }
+        } else {
+            const uint64_t groups = ((uint64_t)1 << s0) >> logC;
+            const uint64_t h = blockIdx.x / groups, cg = blockIdx.x - h * groups;
+            base = (h << (s0 + S)) + (cg << logC);
+            col0 = cg << logC;
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const uint32_t e = threadIdx.x + (uint32_t)it * NT_;
+                const uint32_t r = e >> logC, c = e & (C - 1);
+                idx[it] = base + ((uint64_t)r << s0) + c;
+                dst[it] = e;                                  // LDS layout [row][column]
+            }
+        }
+        uint4 lo[4], hi[4];
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            if (threadIdx.x + (uint32_t)it * NT_ < E) {
+                const uint4* q = reinterpret_cast<const uint4*>(src + 8 * idx[it]);
+                lo[it] = q[0];
+                hi[it] = q[1];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            if (threadIdx.x + (uint32_t)it * NT_ < E) {
+                const uint32_t w[8] = {lo[it].x, lo[it].y, lo[it].z, lo[it].w, hi[it].x, hi[it].y, hi[it].z, hi[it].w};
+                fr9_t v;
+                fr9_from_words(v, w);
+                tile4_put(sm, dst[it], v);
+            }
+        }
+    }
+#else
     if (first) {
         const uint64_t NT = (uint64_t)1 << log_nt;
         const uint64_t u = blockIdx.x;
@@ -382,6 +433,7 @@ __global__ void NTT4_BOUNDS(NT_) k_fr_ntt_pass4(const uint32_t* __restrict__ in,
             tile4_put(sm, e, v);                              // LDS layout [row][column]
         }
     }
+#endif
     __syncthreads();
     int l = 0;
     if (S & 1) {      // one radix-2 stage first
