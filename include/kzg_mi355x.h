@@ -205,6 +205,13 @@ int kzg_ntt_resident(kzg_ctx* ctx, int slot, uint64_t n, int inverse); /* in pla
  *      concurrent requests each decode into their own buffer. */
 int kzg_staging_acquire(kzg_ctx* ctx, uint64_t bytes, void** out_ptr, int* out_token);
 int kzg_staging_release(kzg_ctx* ctx, int token);
+/* Long rows: start the upload of bytes [offset, offset + bytes) of a held staging buffer NOW and return at once, so that
+ * the copy engine moves tile k while the host decodes tile k + 1 of the synapse's text (the reference ships the whole
+ * polynomial as text per call, neurons/miner.py:39,48).  Flushes are contiguous from offset 0 (multiples of 32 bytes).  A
+ * compute call that is then handed the buffer's pointer finds the flushed prefix on the device and skips its own upload
+ * (it waits for the copy on its stream, not on the host); whatever was not flushed is uploaded the ordinary way.
+ * kzg_staging_release forgets the flushes. */
+int kzg_staging_flush(kzg_ctx* ctx, int token, uint64_t offset, uint64_t bytes);
 
 /* ---- where the result point is encoded.  1 (default): the XYZZ working form of the ONE point a request produces
  *      comes back in the request's single device-to-host copy and the host does the affine conversion (one Fp

@@ -62,5 +62,6 @@ for lg in sizes:
     hits, misses = cl.engine.row_cache_stats()
     print(json.dumps({"log2_T": lg, "row_cache_hits_misses": [hits, misses], "e2e_fused_ms": round(e2e * 1e3, 3), "text_decode_ms": round(dec * 1e3, 3), "text_decode_into_pinned_ms": round(dec_pinned * 1e3, 3),
                       "host_buffer_call_ms": round(host_buf * 1e3, 3), "resident_call_ms": round(resident * 1e3, 3),
-                      "two_call_route_ms": round(two_call * 1e3, 3), "wire_ext": codec._wire is not None}), flush=True)
+                      "two_call_route_ms": round(two_call * 1e3, 3), "wire_ext": codec._wire is not None,
+                      "streamed_upload": T >= HipEngine.STREAM_MIN}), flush=True)
     cl.stop()

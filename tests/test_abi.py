@@ -332,3 +332,44 @@ def test_pmc_summary_fails_when_the_committed_traffic_figure_is_stale(tmp_path):
     stale = run(1_060_000.0, 150_000.0)                      # +5.6 %: the committed figure no longer describes the kernel
     assert stale.returncode == 3 and "STALE" in stale.stdout
     assert run(1_120_000.0, 150_000.0, "--accept").returncode == 0      # a deliberate kernel change
+
+
+def test_wire_range_decode_and_tag_shares_sum_to_the_whole_row():
+    """Tile-by-tile decode of a long row (what HipEngine._Staged does so that each tile's upload can start while the next
+    is decoded): ranges land at their own offsets, nothing outside a range is written, and the tag shares of consecutive
+    ranges sum to the one-shot tag -- so the row cache sees the same tag whichever way the row was decoded."""
+    import random
+
+    w = codec._wire
+    assert w is not None
+    rnd = random.Random(21)
+    n = 5000
+    raw = b"".join(rnd.randrange(codec.R_MODULUS).to_bytes(32, "big") for _ in range(n))
+    poly = codec.be32_to_fr_list(raw)
+    one = ctypes.create_string_buffer(len(raw))
+    got, tag_one = w.decode_fr_list_into_tagged(poly, ctypes.addressof(one), len(raw))
+    assert got == n and one.raw == raw
+    for tile in (1024, 1250, 4999, 5000):
+        buf = ctypes.create_string_buffer(b"\xaa" * len(raw), len(raw))
+        tag = bytes(16)
+        for first in range(0, n, tile):
+            cnt = min(tile, n - first)
+            k, tag = w.decode_fr_list_into_tagged(poly, ctypes.addressof(buf), len(raw), 3, first, cnt, tag)
+            assert k == cnt
+            assert buf.raw[:32 * (first + cnt)] == raw[:32 * (first + cnt)]
+            assert buf.raw[32 * (first + cnt):] == b"\xaa" * (len(raw) - 32 * (first + cnt))     # nothing beyond the range
+        assert tag == tag_one, tile
+        plain = ctypes.create_string_buffer(len(raw))
+        for first in range(0, n, tile):
+            assert w.decode_fr_list_into(poly, ctypes.addressof(plain), len(raw), 0, first, min(tile, n - first)) == min(tile, n - first)
+        assert plain.raw == raw
+    bad = list(poly)
+    bad[3000] = bad[3000][:-1] + "!"
+    with pytest.raises(ValueError):
+        w.decode_fr_list_into(bad, ctypes.addressof(one), len(raw), 0, 2048, 1024)       # the bad entry is inside the range
+    assert w.decode_fr_list_into(bad, ctypes.addressof(one), len(raw), 0, 0, 2048) == 2048   # ... and not inside this one
+    for args in ((0, -1, 10), (0, 4000, 2000), (0, n + 1, 0)):
+        with pytest.raises(ValueError):
+            w.decode_fr_list_into(poly, ctypes.addressof(one), len(raw), *args)
+    with pytest.raises(ValueError):
+        w.decode_fr_list_into(poly, ctypes.addressof(one), 32 * 100, 0, 0, 101)          # capacity counts from element 0

@@ -1630,3 +1630,55 @@ def test_calibrate_reports_a_plausible_mad_rate(hip):
     got = eng.msm_wait(t)
     assert got == eng.msm_resident(0, 256, 0)
     assert 1.5 < eng.calibrate(2)["ns_per_mad_per_simd"] < 4.0
+
+
+def test_tile_streamed_upload_of_long_rows_matches_the_one_shot_path(hip, monkeypatch):
+    """Long rows are decoded tile by tile, each tile's upload started at once (kzg_staging_flush) so that the copy engine
+    works while the codec decodes; the compute call then finds the row on the device.  Forced here at 2^12 in four tiles:
+    fused call, the two-call route (miss, verified hit -- the verification reads the flushed twin --, mutated row) all
+    equal the oracle; and the flush entry point refuses anything but the next contiguous piece."""
+    import ctypes
+
+    from zkp_subnet_amd import HipEngine, codec
+    from zkp_subnet_amd._native import KZG_E_ARG, KzgError
+
+    monkeypatch.setattr(HipEngine, "STREAM_MIN", 1 << 12)
+    monkeypatch.setattr(HipEngine, "STREAM_TILE", 1 << 10)
+    eng = hip()
+    lg = 12
+    T = 1 << lg
+    eng.gen_srs(0x57AEA3, 1, lg, 0)
+    srs = eng.srs_read(0, T)
+    row = rand_scalars_bytes(T, 1301)
+    alpha = rand_scalars_bytes(1, 1302)
+    poly = codec.be32_to_fr_list(row)
+    c = oc.commit(srs, row, True)
+    ev, pf = oc.open_(srs, row, alpha, True)
+    assert eng.commit_open_list(0, poly, alpha, True) == (c, ev, pf)
+    h0, m0 = eng.row_cache_stats()
+    assert eng.commit_list(0, poly, True) == c
+    assert eng.open_list(0, poly, alpha, True) == (ev, pf)
+    assert eng.row_cache_stats() == (h0 + 1, m0 + 1)
+    row2 = row[:32 * 3000] + (5).to_bytes(32, "big") + row[32 * 3001:]
+    assert eng.open_list(0, codec.be32_to_fr_list(row2), alpha, True) == oc.open_(srs, row2, alpha, True)
+    # a coefficient-form row and a shorter one through the same path (T < STREAM_MIN: one shot)
+    assert eng.commit_open_list(0, poly, alpha, False) == (oc.commit(srs, row, False),) + oc.open_(srs, row, alpha, False)
+    assert eng.commit_open_list(0, poly[:1024], alpha, False) == (oc.commit(srs, row[:32 * 1024], False),) + oc.open_(srs, row[:32 * 1024], alpha, False)
+    # the entry point itself
+    ptr, tok = ctypes.c_void_p(), ctypes.c_int(-1)
+    eng._chk(eng._lib.kzg_staging_acquire(eng._h, 32 * T, ctypes.byref(ptr), ctypes.byref(tok)))
+    ctypes.memmove(ptr.value, row, len(row))
+    for args in ((32 * 1024, 32 * 1024), (0, 33), (0, 1 << 40)):             # not at the flushed prefix / ragged / beyond the buffer
+        with pytest.raises(KzgError) as ei:
+            eng._chk(eng._lib.kzg_staging_flush(eng._h, tok.value, *args))
+        assert ei.value.code == KZG_E_ARG
+    eng._chk(eng._lib.kzg_staging_flush(eng._h, tok.value, 0, 32 * 2048))     # HALF the row flushed: the call uploads it all itself
+    out = ctypes.create_string_buffer(48)
+    eng._chk(eng._lib.kzg_commit(eng._h, 0, ctypes.cast(ptr, ctypes.c_char_p), T, 1, out))
+    assert out.raw == c
+    eng._chk(eng._lib.kzg_staging_flush(eng._h, tok.value, 32 * 2048, 32 * 2048))   # ... now all of it: served from the twin
+    eng._chk(eng._lib.kzg_commit(eng._h, 0, ctypes.cast(ptr, ctypes.c_char_p), T, 1, out))
+    assert out.raw == c
+    eng._chk(eng._lib.kzg_staging_release(eng._h, tok.value))
+    with pytest.raises(KzgError):
+        eng._chk(eng._lib.kzg_staging_flush(eng._h, tok.value, 0, 32))        # not held any more

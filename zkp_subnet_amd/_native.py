@@ -69,6 +69,7 @@ SYMBOLS = {
     "kzg_ntt_resident": (_I, [_P, _I, _U64, _I]),
     "kzg_staging_acquire": (_I, [_P, _U64, ctypes.POINTER(_P), ctypes.POINTER(_I)]),
     "kzg_staging_release": (_I, [_P, _I]),
+    "kzg_staging_flush": (_I, [_P, _I, _U64, _U64]),
     "kzg_set_host_finish": (_I, [_P, _I]),
     "kzg_host_xyzz_to_c48": (_I, [_P, _B]),
     "kzg_host_xyzz_pair_to_c48": (_I, [_P, _P, _B, _B]),

@@ -130,6 +130,7 @@ struct Lane {
     bool sort_ws_clean = false;   // the sort's partition counts are zero (left so by every completed sort)
     int skew_hint = 0;            // > 0: the last fast sort overflowed (skewed scalars): go straight to the exact sort
     hipEvent_t ev_sorted = nullptr, ev_done = nullptr, ev_coeffs = nullptr, ev_ext = nullptr, ev_acc = nullptr;
+    const uint8_t* in_be_src = nullptr;   // where upload_fr found the request's big-endian row on the device (in_be or a staging twin)
     hipStream_t vstream = nullptr;   // row-cache hits: upload of the caller's row + its comparison with the cached one,
     hipEvent_t ev_verify = nullptr;  // beside the request's own kernels (the lane's publish waits for this event)
     DevBuf vbuf;
@@ -146,6 +147,12 @@ struct Stage {
     void* p = nullptr;
     size_t cap = 0;
     bool used = false;
+    // kzg_staging_flush: a device twin that receives the buffer's prefix WHILE the host is still decoding the rest
+    DevBuf twin;
+    uint64_t flushed = 0;         // bytes [0, flushed) of p are in (or on their way to) the twin
+    hipEvent_t ev = nullptr;      // recorded on ctx->h2d behind the last flush
+    // the pointer as OTHER threads may read it (flushed_twin scans every record; only the holder touches the rest)
+    std::atomic<void*> p_pub{nullptr};
 };
 
 }  // namespace
@@ -168,6 +175,7 @@ struct kzg_ctx {
     int slot_mont[N_SLOTS] = {0, 0, 0, 0};
     std::map<int, DevBuf> tw_fwd, tw_inv, inv_n;
     Stage stage[N_STAGE];
+    hipStream_t h2d = nullptr;     // the copy stream of kzg_staging_flush (one for all staging buffers: they share the link)
     // kzg_g1_sum*: own stream and buffers, independent of the lanes
     std::mutex aux_mu;
     hipStream_t aux = nullptr;
@@ -730,12 +738,29 @@ int check_worker(kzg_ctx* ctx, uint32_t i, uint64_t T) {
     return KZG_OK;
 }
 // upload BE scalars to `dst` (device limbs); dst must hold n*32 bytes
+// the device twin of a staging buffer whose first `bytes` bytes have been flushed (kzg_staging_flush), or null.  The
+// caller holds that buffer (it was handed its pointer), so nobody else touches the record meanwhile.
+const uint8_t* flushed_twin(kzg_ctx* ctx, const uint8_t* host_ptr, uint64_t bytes, hipEvent_t* ev) {
+    for (Stage& st : ctx->stage)
+        if (host_ptr && st.p_pub.load(std::memory_order_acquire) == host_ptr && st.flushed >= bytes && st.twin.p) {
+            *ev = st.ev;
+            return static_cast<const uint8_t*>(st.twin.p);
+        }
+    return nullptr;
+}
 int upload_fr(kzg_ctx* ctx, Lane& L, const uint8_t* be32, uint64_t n, uint32_t* dst, int to_mont) {
     if (!n) return KZG_OK;
-    HIPCHK(ctx, L.in_be.ensure(n * 32));
     Span sp(ctx, L, KZG_T_DECODE);
-    HIPCHK(ctx, hipMemcpyAsync(L.in_be.p, be32, n * 32, hipMemcpyHostToDevice, L.stream));
-    launch_fr_from_be(L.stream, L.in_be.as<uint8_t>(), dst, n, to_mont, L.flags());
+    hipEvent_t ev = nullptr;
+    if (const uint8_t* twin = flushed_twin(ctx, be32, n * 32, &ev)) {   // uploaded tile by tile while the host decoded
+        HIPCHK(ctx, hipStreamWaitEvent(L.stream, ev, 0));
+        L.in_be_src = twin;
+    } else {
+        HIPCHK(ctx, L.in_be.ensure(n * 32));
+        HIPCHK(ctx, hipMemcpyAsync(L.in_be.p, be32, n * 32, hipMemcpyHostToDevice, L.stream));
+        L.in_be_src = L.in_be.as<uint8_t>();
+    }
+    launch_fr_from_be(L.stream, L.in_be_src, dst, n, to_mont, L.flags());
     return KZG_OK;
 }
 
@@ -812,10 +837,17 @@ int commit_open_dev(kzg_ctx* ctx, LaneHold& H, uint32_t i, const uint32_t* row_d
     if (verify) {   // row-cache hit: queued LAST, so that its few runtime calls cost host time while the GPU is busy with the
         // request's own kernels; the copy and the comparison run beside them, the publish waits for the verdict
         uint32_t* vflag = reinterpret_cast<uint32_t*>(A.tail + TB_VERIFY);
-        HIPCHK(ctx, A.vbuf.ensure(verify->T * 32));
         HIPCHK(ctx, hipMemsetAsync(vflag, 0, 4, A.vstream));
-        HIPCHK(ctx, hipMemcpyAsync(A.vbuf.p, verify->row_be32, verify->T * 32, hipMemcpyHostToDevice, A.vstream));
-        launch_words_differ(A.vstream, A.vbuf.as<uint32_t>(), verify->cached_raw, verify->T * 8, vflag);
+        hipEvent_t fev = nullptr;
+        const uint32_t* mine = reinterpret_cast<const uint32_t*>(flushed_twin(ctx, verify->row_be32, verify->T * 32, &fev));
+        if (mine) {      // the row is already on the device (flushed tile by tile during the decode)
+            HIPCHK(ctx, hipStreamWaitEvent(A.vstream, fev, 0));
+        } else {
+            HIPCHK(ctx, A.vbuf.ensure(verify->T * 32));
+            HIPCHK(ctx, hipMemcpyAsync(A.vbuf.p, verify->row_be32, verify->T * 32, hipMemcpyHostToDevice, A.vstream));
+            mine = A.vbuf.as<uint32_t>();
+        }
+        launch_words_differ(A.vstream, mine, verify->cached_raw, verify->T * 8, vflag);
         HIPCHK(ctx, hipEventRecord(A.ev_verify, A.vstream));
         HIPCHK(ctx, hipStreamWaitEvent(s, A.ev_verify, 0));   // the record must carry TB_VERIFY's final value
     }
@@ -1066,7 +1098,10 @@ int kzg_create(int device_id, kzg_ctx** out) {
     ctx->device = device_id;
     if (const char* e = getenv("KZG_SERIAL_ACC")) ctx->serial_accumulate = e[0] != '0';
     bool ok = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&ctx->h2d, hipStreamNonBlocking) == hipSuccess &&
               hipHostMalloc((void**)&ctx->aux_pin, 256, hipHostMallocDefault) == hipSuccess;
+    for (int k = 0; ok && k < N_STAGE; k++)
+        ok = hipEventCreateWithFlags(&ctx->stage[k].ev, hipEventDisableTiming) == hipSuccess;
     for (int l = 0; ok && l < N_LANES; l++) {
         Lane& L = ctx->lane[l];
         L.index = l;
@@ -1116,8 +1151,15 @@ void kzg_destroy(kzg_ctx* ctx) {
         (void)hipStreamDestroy(ctx->aux);
     }
     if (ctx->aux_pin) (void)hipHostFree(ctx->aux_pin);
-    for (Stage& st : ctx->stage)
+    if (ctx->h2d) {
+        (void)hipStreamSynchronize(ctx->h2d);
+        (void)hipStreamDestroy(ctx->h2d);
+    }
+    for (Stage& st : ctx->stage) {
         if (st.p) (void)hipHostFree(st.p);
+        if (st.ev) (void)hipEventDestroy(st.ev);
+        st.twin.release();
+    }
     delete ctx;  // the remaining DevBufs (table, slots, twiddles, aux) free themselves
 }
 
@@ -1673,7 +1715,7 @@ static int commit_open_host_cached(kzg_ctx* ctx, uint32_t i, const uint8_t* row_
     rc = L.coeffA.ensure(T * 32) == hipSuccess ? KZG_OK : fail(ctx, KZG_E_NOMEM, "row buffer");
     if (!rc) rc = upload_fr(ctx, L, row_be32, T, L.coeffA.as<uint32_t>(), 1);
     if (!rc && dst)   // the uploaded bytes themselves stay with the slot: what a later hit is verified against
-        rc = hipMemcpyAsync(ctx->rcache[slot].raw.p, L.in_be.p, T * 32, hipMemcpyDeviceToDevice, L.stream) == hipSuccess
+        rc = hipMemcpyAsync(ctx->rcache[slot].raw.p, L.in_be_src, T * 32, hipMemcpyDeviceToDevice, L.stream) == hipSuccess
                  ? KZG_OK : fail(ctx, KZG_E_HIP, "row cache: copy of the uploaded row");
     if (!rc) rc = commit_open_dev(ctx, H, i, L.coeffA.as<uint32_t>(), T, evaluation_form, alpha, c48, e32, p48, nullptr, dst);
     if (rc != KZG_OK && slot >= 0) H.drain();   // a failed call may have kernels queued that still write the slot: not reusable before
@@ -2111,6 +2153,7 @@ int kzg_staging_acquire(kzg_ctx* ctx, uint64_t bytes, void** out_ptr, int* out_t
     }
     Stage& st = ctx->stage[k];
     if (bytes > st.cap) {
+        st.p_pub.store(nullptr, std::memory_order_release);
         if (st.p) (void)hipHostFree(st.p);
         st.p = nullptr;
         st.cap = 0;
@@ -2127,8 +2170,36 @@ int kzg_staging_acquire(kzg_ctx* ctx, uint64_t bytes, void** out_ptr, int* out_t
         }
         st.cap = want;
     }
+    st.flushed = 0;
+    st.p_pub.store(st.p, std::memory_order_release);
     *out_ptr = st.p;
     *out_token = k;
+    return KZG_OK;
+}
+// Starts the upload of bytes [offset, offset + bytes) of a held staging buffer to its device twin and returns at once: the
+// host goes on decoding the next tile of the row while the copy engine moves this one.  Flushes must be contiguous from
+// offset 0.  A compute call that is later handed the buffer's pointer finds the prefix it needs already on the device (it
+// waits for the copy stream's event on ITS stream, not on the host) and skips its own upload; anything not flushed is
+// uploaded the ordinary way.  Releasing the buffer forgets the flushes.
+int kzg_staging_flush(kzg_ctx* ctx, int token, uint64_t offset, uint64_t bytes) {
+    if (!ctx || token < 0 || token >= N_STAGE) return KZG_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Stage& st = ctx->stage[token];
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (!st.used) return fail(ctx, KZG_E_ARG, "staging buffer is not held");
+    }
+    if (offset != st.flushed || offset + bytes > st.cap || (bytes & 31)) return fail(ctx, KZG_E_ARG, "staging flush: not the next contiguous piece");
+    if (!bytes) return KZG_OK;
+    if (st.twin.cap < st.cap) {
+        // the twin may still be read by nothing: the previous holder's compute call returned before it released the buffer
+        HIPCHK(ctx, hipStreamSynchronize(ctx->h2d));
+        HIPCHK(ctx, st.twin.ensure(st.cap));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(static_cast<uint8_t*>(st.twin.p) + offset, static_cast<const uint8_t*>(st.p) + offset, bytes,
+                               hipMemcpyHostToDevice, ctx->h2d));
+    HIPCHK(ctx, hipEventRecord(st.ev, ctx->h2d));
+    st.flushed = offset + bytes;
     return KZG_OK;
 }
 int kzg_staging_release(kzg_ctx* ctx, int token) {
@@ -2136,6 +2207,7 @@ int kzg_staging_release(kzg_ctx* ctx, int token) {
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         if (!ctx->stage[token].used) return fail(ctx, KZG_E_ARG, "staging buffer is not held");
+        ctx->stage[token].flushed = 0;
         ctx->stage[token].used = false;
     }
     ctx->cv.notify_all();

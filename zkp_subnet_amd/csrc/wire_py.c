@@ -381,11 +381,28 @@ static void pool_join(void) {
 /* Decodes the sequence into dst (n * 32 bytes).  Returns n, or -1 with a Python error set.  `cap` = room at dst in
  * bytes (0: dst is NULL and a bytes object is created: *out_bytes).  The GIL stays with the calling thread for the
  * whole call (~2 ns per element on 8 threads), which is what makes the lock-free reads above legal. */
+/* Range form (first / count, count < 0 = to the end): elements [first, first + count) are decoded to dst + 32 * first --
+ * dst is always the address of element 0 -- so that a long row can be decoded tile by tile, each tile's upload started
+ * (kzg_staging_flush) while the next is decoded.  The tag of a range is that range's share of the content tag; the
+ * length term is added by the call that decodes the LAST element, so the shares of consecutive ranges sum (mod 2^64 per
+ * lane) to the tag of the whole row.  Returns the number of elements decoded. */
+static Py_ssize_t decode_core_range(PyObject* seq_in, long threads, uint8_t* dst, size_t cap, PyObject** out_bytes,
+                                    uint64_t* out_tag, Py_ssize_t first, Py_ssize_t count);
 static Py_ssize_t decode_core(PyObject* seq_in, long threads, uint8_t* dst, size_t cap, PyObject** out_bytes,
                               uint64_t* out_tag) {
+    return decode_core_range(seq_in, threads, dst, cap, out_bytes, out_tag, 0, -1);
+}
+static Py_ssize_t decode_core_range(PyObject* seq_in, long threads, uint8_t* dst, size_t cap, PyObject** out_bytes,
+                                    uint64_t* out_tag, Py_ssize_t first, Py_ssize_t count) {
     PyObject* seq = PySequence_Fast(seq_in, "polynomial must be a sequence of base64 strings");
     if (!seq) return -1;
     const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
+    if (count < 0) count = n - first;
+    if (first < 0 || first > n || count < 0 || first + count > n || (out_bytes && (first || count != n))) {
+        Py_DECREF(seq);
+        PyErr_SetString(PyExc_ValueError, "bad element range");
+        return -1;
+    }
     PyObject* out = NULL;
     if (out_bytes) {
         out = PyBytes_FromStringAndSize(NULL, 32 * n);
@@ -394,25 +411,28 @@ static Py_ssize_t decode_core(PyObject* seq_in, long threads, uint8_t* dst, size
             return -1;
         }
         dst = (uint8_t*)PyBytes_AS_STRING(out);
-    } else if ((size_t)n * 32 > cap) {
+    } else if ((size_t)(first + count) * 32 > cap) {
         Py_DECREF(seq);
         PyErr_SetString(PyExc_ValueError, "destination buffer too small for the polynomial");
         return -1;
     }
-    const int T = pick_threads(threads, n);
+    const int T = pick_threads(threads, count);
     dec_job jobs[POOL_MAX + 1];
     for (int t = 0; t < T; t++) {
         jobs[t].items = PySequence_Fast_ITEMS(seq);
         jobs[t].dst = dst;
-        jobs[t].lo = n * t / T;
-        jobs[t].hi = n * (t + 1) / T;
+        jobs[t].lo = first + count * t / T;
+        jobs[t].hi = first + count * (t + 1) / T;
         jobs[t].want_tag = out_tag != NULL;
         jobs[t].kind = 0;
     }
     pool_run(jobs, T);
     if (out_tag) {
-        out_tag[0] = mum64((uint64_t)n ^ TAG_KEY[1], TAG_KEY[2] | 1);   /* the length is part of the content */
-        out_tag[1] = mum64((uint64_t)n ^ TAG_KEY[7], TAG_KEY[4] | 1);
+        out_tag[0] = out_tag[1] = 0;
+        if (first + count == n) {   /* the length is part of the content: added by the call that reaches the end */
+            out_tag[0] = mum64((uint64_t)n ^ TAG_KEY[1], TAG_KEY[2] | 1);
+            out_tag[1] = mum64((uint64_t)n ^ TAG_KEY[7], TAG_KEY[4] | 1);
+        }
         for (int t = 0; t < T; t++) {
             out_tag[0] += jobs[t].tag[0];
             out_tag[1] += jobs[t].tag[1];
@@ -434,7 +454,7 @@ static Py_ssize_t decode_core(PyObject* seq_in, long threads, uint8_t* dst, size
         return -1;
     }
     if (out_bytes) *out_bytes = out;
-    return n;
+    return count;
 }
 
 static PyObject* decode_fr_list(PyObject* self, PyObject* args) {
@@ -452,12 +472,13 @@ static PyObject* decode_fr_list_into(PyObject* self, PyObject* args) {
     PyObject* seq_in;
     unsigned long long addr, cap;
     long threads = 0;
-    if (!PyArg_ParseTuple(args, "OKK|l", &seq_in, &addr, &cap, &threads)) return NULL;
+    Py_ssize_t first = 0, count = -1;   /* a range of the sequence (tile-by-tile decode of a long row) */
+    if (!PyArg_ParseTuple(args, "OKK|lnn", &seq_in, &addr, &cap, &threads, &first, &count)) return NULL;
     if (!addr) {
         PyErr_SetString(PyExc_ValueError, "null destination");
         return NULL;
     }
-    Py_ssize_t n = decode_core(seq_in, threads, (uint8_t*)(uintptr_t)addr, (size_t)cap, NULL, NULL);
+    Py_ssize_t n = decode_core_range(seq_in, threads, (uint8_t*)(uintptr_t)addr, (size_t)cap, NULL, NULL, first, count);
     if (n < 0) return NULL;
     return PyLong_FromSsize_t(n);
 }
@@ -466,14 +487,23 @@ static PyObject* decode_fr_list_into_tagged(PyObject* self, PyObject* args) {
     PyObject* seq_in;
     unsigned long long addr, cap;
     long threads = 0;
-    if (!PyArg_ParseTuple(args, "OKK|l", &seq_in, &addr, &cap, &threads)) return NULL;
-    if (!addr) {
-        PyErr_SetString(PyExc_ValueError, "null destination");
+    Py_ssize_t first = 0, count = -1;
+    const char* base = NULL;            /* the tag shares of the ranges decoded so far (16 bytes), summed into the result */
+    Py_ssize_t base_len = 0;
+    if (!PyArg_ParseTuple(args, "OKK|lnnz#", &seq_in, &addr, &cap, &threads, &first, &count, &base, &base_len)) return NULL;
+    if (!addr || (base && base_len != 16)) {
+        PyErr_SetString(PyExc_ValueError, base ? "the running tag must be 16 bytes" : "null destination");
         return NULL;
     }
     uint64_t tag[2];
-    Py_ssize_t n = decode_core(seq_in, threads, (uint8_t*)(uintptr_t)addr, (size_t)cap, NULL, tag);
+    Py_ssize_t n = decode_core_range(seq_in, threads, (uint8_t*)(uintptr_t)addr, (size_t)cap, NULL, tag, first, count);
     if (n < 0) return NULL;
+    if (base) {
+        uint64_t b[2];
+        memcpy(b, base, 16);
+        tag[0] += b[0];
+        tag[1] += b[1];
+    }
     return Py_BuildValue("ny#", n, (const char*)tag, (Py_ssize_t)16);
 }
 

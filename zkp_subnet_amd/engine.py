@@ -34,6 +34,10 @@ def lagrange_factor(i: int, machines_scale: int, tau_y: int) -> int:
 
 
 class HipEngine:
+    # rows from this length up are decoded and uploaded tile by tile (see _Staged); KZG_STREAM_MIN_LOG moves the threshold
+    STREAM_MIN = 1 << int(os.environ.get("KZG_STREAM_MIN_LOG", "19"))
+    STREAM_TILE = 1 << int(os.environ.get("KZG_STREAM_TILE_LOG", "18"))   # 2^18 elements: the decode pool's full thread count
+
     def __init__(self, device: int = 0, window: int = 0):
         self._lib = _native.load()
         h = ctypes.c_void_p()
@@ -190,11 +194,29 @@ class HipEngine:
             ptr, tok = ctypes.c_void_p(), ctypes.c_int(-1)
             eng._chk(eng._lib.kzg_staging_acquire(eng._h, 32 * max(self.n, 1), ctypes.byref(ptr), ctypes.byref(tok)))
             self.token = tok.value
+            cap = 32 * max(self.n, 1)
             try:
-                if tagged:   # one pass: base64 -> bytes in the pinned buffer + the 128-bit content tag of those bytes
-                    got, self.tag = codec._wire.decode_fr_list_into_tagged(poly, ptr.value, 32 * max(self.n, 1))
+                tile = max(HipEngine.STREAM_TILE, self.n >> 2)
+                if not tagged and self.n >= HipEngine.STREAM_MIN and self.n % tile == 0:
+                    # long rows of the fused call: decode in (at most four) tiles and start each tile's upload at once
+                    # (kzg_staging_flush): the copy engine moves tile k while the pool decodes tile k + 1, and the compute
+                    # call finds the row on the device.  Short rows: the per-tile calls would cost what the overlap gives.
+                    # Tagged calls (the two-call route) decode in one shot: the tag -- hit or miss -- is only known at
+                    # the end, a hit's upload is off the critical path anyway, and tiles cost the decode ~0.1 ms each
+                    # (measured: profiles/r04_ab_streamed_upload.log).
+                    got, tag = 0, (bytes(16) if tagged else None)
+                    for first in range(0, self.n, tile):
+                        if tagged:
+                            k, tag = codec._wire.decode_fr_list_into_tagged(poly, ptr.value, cap, 0, first, tile, tag)
+                        else:
+                            k = codec._wire.decode_fr_list_into(poly, ptr.value, cap, 0, first, tile)
+                        got += k
+                        eng._chk(eng._lib.kzg_staging_flush(eng._h, self.token, 32 * first, 32 * tile))
+                    self.tag = tag
+                elif tagged:   # one pass: base64 -> bytes in the pinned buffer + the 128-bit content tag of those bytes
+                    got, self.tag = codec._wire.decode_fr_list_into_tagged(poly, ptr.value, cap)
                 else:        # fused / one-shot calls have no use for the tag (it costs ~0.7 ns per element and thread)
-                    got, self.tag = codec._wire.decode_fr_list_into(poly, ptr.value, 32 * max(self.n, 1)), None
+                    got, self.tag = codec._wire.decode_fr_list_into(poly, ptr.value, cap), None
             except ValueError as e:
                 eng._lib.kzg_staging_release(eng._h, self.token)
                 raise codec.CodecError(str(e)) from e
