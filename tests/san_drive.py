@@ -68,6 +68,14 @@ def worker(tid):
                 errors.append((tid, "tagged", n))
             if w.decode_fr_list_into(polys[n], ctypes.addressof(buf), 32 * n) != n or buf.raw != rows[n]:
                 errors.append((tid, "into", n))
+            if n >= 700:                                       # the tile-by-tile form of long rows: ranges + tag shares
+                part = bytes(16)
+                tile = n // 3 + 1
+                for first in range(0, n, tile):
+                    k, part = w.decode_fr_list_into_tagged(polys[n], ctypes.addressof(buf), 32 * n, r.choice((0, 4, 16)),
+                                                           first, min(tile, n - first), part)
+                if part != tags[n] or buf.raw != rows[n]:
+                    errors.append((tid, "ranges", n))
             if w.encode_fr_list(rows[n]) != polys[n]:
                 errors.append((tid, "encode", n))
             rr = w.random_fr_rows(r.choice((1, 3)), r.choice((5, 2000, 9000)))      # the asynchronous-batch path
