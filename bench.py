@@ -600,21 +600,10 @@ def main():
     calib = None
     if is_msm:
         try:
-            # the sysfs clock is sampled by a helper thread WHILE the calibration kernel runs (read afterwards it shows
-            # the idle state: 160 MHz); s_memtime ticks per ns from the kernel itself is the figure to trust
-            import threading
-
-            seen = []
-
-            def sample():
-                time.sleep(0.0008)
-                seen.append(sysfs_sclk_mhz(local_rank))
-
-            th = threading.Thread(target=sample)
-            th.start()
+            # the clock the SIMDs ran at is calib["memtime_ticks_per_ns"] (s_memtime over the kernel itself); the sysfs
+            # pp_dpm_sclk node lags by hundreds of milliseconds (it showed 158 MHz, 1941 MHz and 2398 MHz around identical
+            # kernels) and is only logged by scripts/clock_state.py
             calib = eng.calibrate(2)
-            th.join()
-            calib["sclk_mhz_sysfs_during"] = seen[0] if seen else None
         except Exception as e:                 # noqa: BLE001 -- a measurement aid must never cost the bench line
             calib = {"error": f"{type(e).__name__}: {e}"}
     acc_live_ms = stage_sum.get("accumulate", 0.0) / args.steps if live_level == 2 else None
