@@ -1384,6 +1384,8 @@ def test_reference_reward_scenarios_on_the_hip_engine(missing_info, too_late, in
             times[0] = 5.0
         got = [reward(client, ch, responses[i], i, times[i], timeout) for i in range(2)]
         assert got == expected
+        from zkp_subnet_amd.validator import get_rewards        # the reference's array form (neurons/validator.py:178-192)
+        assert [float(x) for x in get_rewards(client, ch, responses, times, timeout)] == expected
     finally:
         miner.stop()
 

@@ -129,6 +129,17 @@ def test_validator_reward_table():
     assert reward(c, ch, corrupt, 0, 0.0) == 0.0
     # the miner's eval equals the validator's independently computed one
     assert responses[1].eval == ch.evals[1]
+    # get_rewards (reference neurons/validator.py:178-192): the same five scenarios as one float32 array, row order kept
+    from zkp_subnet_amd.validator import get_rewards
+    import numpy as np
+
+    got = get_rewards(c, ch, [responses[1], responses[0]], [0.0, 5.0], timeout=10.0)
+    assert got.dtype == np.float32 and list(got) == [1.0, 0.5]
+    assert list(get_rewards(c, ch, [corrupt, responses[1]], [0.0, 0.0], 10.0)) == [0.0, 1.0]
+    assert list(get_rewards(c, ch, [responses[0].model_copy(update={"commitment": None}), responses[1]], [0.0, 0.0], 10.0)) == [0.0, 1.0]
+    assert list(get_rewards(c, ch, [responses[0], responses[1]], [11.0, 0.0], 10.0)) == [0.0, 1.0]
+    assert list(get_rewards(c, ch, [None, responses[1]], [None, 2.5], 10.0)) == [0.0, 0.75]
+    assert [float(x) for x in get_rewards(c, ch, responses, [0.0, 0.0], 30.0)] == [reward(c, ch, responses[i], i, 0.0) for i in range(2)]
 
 
 def test_config1_plumbing_degree_4096_commit_under_mock_loop():

@@ -93,3 +93,37 @@ def reward(client, challenge: Challenge, response: Optional[Prove], index: int, 
     if not valid:
         return 0.0
     return 1 - process_time / timeout
+
+
+def get_rewards(client, challenge: Challenge, responses: Sequence[Optional[Prove]], process_times: Sequence[Optional[float]],
+                timeout: float = 30.0, threads: int = 16):
+    """reference neurons/validator.py:178-192: one reward per response, as a float32 array -- `reward()` row by row.
+    The reference reads the latency from `response.dendrite.process_time` (bittensor; not part of the wire type), here it
+    comes as `process_times[k]`; the worker index of response k is `responses[k].index`, as in the reference.  Rows that
+    can be scored without a pairing (missing fields, too late) are; all the others are verified TOGETHER (`verify_all`:
+    one batched check for a step whose rows share alpha, row by row only to name culprits)."""
+    import numpy as np
+
+    n = len(responses)
+    if len(process_times) != n:
+        raise ValueError("one process time per response")
+    scores = [0.0] * n
+    todo = []
+    for k, (r, t) in enumerate(zip(responses, process_times)):
+        if r is None or r.commitment is None or r.proof is None:
+            continue                                # incomplete proof: 0.0 (reference :146-148)
+        if t is None or t > timeout:
+            continue                                # too slow: not even verified (:152-154)
+        if not 0 <= r.index < len(challenge.polys):
+            continue                                # an index the challenge never issued cannot be verified: 0.0
+        todo.append(k)
+    if todo:
+        # verify_all indexes its rows by position: hand it a list laid out by WORKER index
+        by_index: List[Optional[Prove]] = [None] * len(challenge.polys)
+        for k in todo:
+            by_index[responses[k].index] = responses[k]
+        ok = verify_all(client, challenge, by_index, threads)
+        for k in todo:
+            if ok[responses[k].index]:
+                scores[k] = 1.0 - process_times[k] / timeout
+    return np.array(scores, dtype=np.float32)
