@@ -92,6 +92,18 @@ def run(budget=60.0, seed=None, rounds=None, max_log=20):
             # the unchanged miner's two calls from the wire text: the second is served from the row cache -- unless the row
             # changed in between, in which case it must be recomputed
             poly = codec.be32_to_fr_list(row)
+            # the fused call from the wire text; for half of the rows of >= 2^10 elements in the tile-streamed form (decode
+            # in four tiles, each tile's upload started at once) that long rows take by default
+            stream = T >= 1024 and rnd.random() < 0.5
+            saved = (HipEngine.STREAM_MIN, HipEngine.STREAM_TILE)
+            if stream:
+                HipEngine.STREAM_MIN, HipEngine.STREAM_TILE = T, T >> 2
+            try:
+                assert eng.commit_open_list(0, poly, alpha, ev_form) == (c, ev, pf), ("commit_open_list", lg, ms, stream)
+            finally:
+                HipEngine.STREAM_MIN, HipEngine.STREAM_TILE = saved
+            stats["fused_from_text"] = stats.get("fused_from_text", 0) + 1
+            stats["fused_from_text_streamed"] = stats.get("fused_from_text_streamed", 0) + int(stream)
             h0, m0 = eng.row_cache_stats()
             assert eng.commit_list(0, poly, ev_form) == c, ("commit_list", lg, ms)
             if rnd.random() < 0.5:

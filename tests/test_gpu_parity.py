@@ -1350,6 +1350,7 @@ def test_seeded_fuzz_slice():
     assert stats["rounds"] == 14 and stats["msm"] == 42 and stats["ntt"] == 14 and stats["kzg"] == 28
     assert stats["cache_hits"] >= 6 and stats["cache_misses_after_mutation"] >= 6
     assert stats["cache_hits"] + stats["cache_misses_after_mutation"] == 28
+    assert stats["fused_from_text"] == 28 and stats["fused_from_text_streamed"] >= 4
 
 
 @pytest.mark.parametrize("missing_info,too_late,invalid_proof,half_time,expected",
