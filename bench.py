@@ -19,11 +19,30 @@ configs[4] after the headline region and adds them to the line as `msm26` (one 2
 strong scaling) and `pianist_kzg22` (one 2^22 commit+open per rank): a flag-less multi-GPU run yields every BASELINE
 multi-GPU number.  Every rank's MSM result is checked against rank 0's.
 
+Robustness of a multi-rank launch (the driver's SCALE runs cannot be watched or repeated):
+  * the control plane (barriers, MAX over ranks, cross-rank result checks) is a gloo process group with a timeout; phase
+    status travels through the rendezvous STORE, so one rank's failure can never park the others in a collective;
+  * the data path is the LIBRARY's own collective (kzg_comm_init / kzg_msm_sharded: one ncclAllGather of 192 B per rank on
+    the lane's stream, RCCL over xGMI).  Preflight before any table is built: communicator + a checked all_gather, both
+    under a watchdog; if any rank fails it every rank falls back to the all_gather of the gloo group (device tensors
+    through the host) and the line says so in `config.collective` / `config.rccl_version` -- a curve exists either way,
+    the exchange is 192 B per rank;
+  * rank 0 prints the headline line as soon as the headline region and its CPU baseline are done, and the augmented line
+    (msm26, pianist_kzg22) after the extras: the LAST line is the record, the first is the insurance;
+  * every extra runs in try/except on every rank, failures become {"msm26": {"error": ...}} and the exit code stays 0;
+  * `python bench.py --gpus N` (no launcher) is watched by its parent: BENCH_WATCHDOG_S (default 1500) seconds, then the
+    exact child it started is terminated and the last line seen is still printed.
+BENCH_BACKEND=nccl + BENCH_COLLECTIVE=torch is the round-4 form (torch's RCCL group carries everything): the A/B.
+BENCH_FAULT=<phase>:<rank> (msm26_setup, msm26_step, pianist_kzg22_setup, comm_init) injects a failure for the tests.
+
 Extra objects on the JSON line:
   roofline         dominant kernel (k_msm_accumulate): duration from HIP events on the library's own stream inside the
                    timed region, denominators from SURVEY.md 8d (128 B per point)
   mad_issue        what actually bounds that kernel: v_mad_u64_u32 wave-instructions per second against the chip's
                    measured mad rate (profiles/ubench_valu_rates.txt) -- see DESIGN.md 3.3
+  e2e_from_text    N = 1 default run only: the route the reference actually runs (neurons/miner.py:56-61: worker_commit then
+                   worker_open, List[str] in) and the fused call, at mainnet 2^16, testnet 2^12 and default-flag 2^10 rows,
+                   median of >= 20, each answer asserted equal to the C oracle's on the same row
   kzg_commit_open  N = 1 default run only: commit+open latency of device-resident rows of 2^22 (configs[2]), 2^16
                    (mainnet row) and 2^12 (testnet row) coefficients, each with p10/p90, stage times, a roofline entry at
                    384 B per coefficient and its own CPU baseline
@@ -218,115 +237,423 @@ def kzg_rows_report(HipEngine, lagrange_factor, device, logs, cpu_threads, with_
     return rows
 
 
-def dist_extra_workloads(args, torch, dist, HipEngine, lagrange_factor, rank, local_rank, world):
-    """With a process group and no --workload: the OTHER multi-GPU configurations of BASELINE.json, measured in the same
-    launch so that a driver SCALE run (which passes no flags) yields every multi-GPU number:
-      msm26          configs[3]: ONE 2^26-point MSM, SRS split into `world` contiguous segments, one per rank, partials
-                     all_gathered over RCCL and summed on every rank (strong scaling: total work fixed)
-      pianist_kzg22  configs[4]: one degree-2^22 commit+open per rank (Pianist worker row `rank`), no exchange (weak)
-    Same timing discipline as the headline: W warm-up steps, K steps between barrier + synchronize, MAX over ranks.
-    Every rank's MSM result must equal rank 0's."""
-    from zkp_subnet_amd.distributed import DeviceGather
+class Fault(Exception):
+    """BENCH_FAULT=<phase>:<rank> -- an injected failure (tests of the multi-rank error paths)."""
 
-    tdev = "cuda"          # device tensors under RCCL and under the gloo self-test alike (gloo moves them through the host)
 
-    def barrier():
-        dist.barrier()
-        torch.cuda.synchronize()
+def inject(phase, rank):
+    spec = os.environ.get("BENCH_FAULT", "")
+    for item in spec.split(","):
+        if item and item.split(":")[0] == phase and int(item.split(":")[1]) == rank:
+            raise Fault(f"injected fault in {phase} on rank {rank} (BENCH_FAULT)")
 
-    def max_over_ranks(x):
-        t = torch.tensor([x], dtype=torch.float64, device=tdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+
+class Ctl:
+    """Control plane of a multi-rank launch.  Collectives (barrier, MAX, byte gathers) run on the default process group
+    -- gloo with a timeout unless BENCH_BACKEND says otherwise; phase STATUS travels through the rendezvous store (set /
+    wait / get with a timeout), never through a collective: a rank that failed its phase cannot be waited for in one."""
+
+    def __init__(self, torch, dist, rank, world, active, timeout_s):
+        self.torch, self.dist, self.rank, self.world, self.active, self.timeout_s = torch, dist, rank, world, active, timeout_s
+        self.poisoned = None         # set once a collective of the group may have been left half-done
+        self.store = None
+        if active:
+            try:
+                from torch.distributed.distributed_c10d import _get_default_store
+
+                self.store = _get_default_store()
+            except Exception:        # noqa: BLE001 -- older / newer torch: agree() then uses an object gather
+                self.store = None
+        self.cpu = not active or dist.get_backend() != "nccl"
+
+    def _dev(self):
+        return "cpu" if self.cpu else "cuda"
+
+    def barrier(self):
+        if self.active:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if not self.active:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self._dev())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
-    def gather_bytes(b):
-        src = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(tdev)
-        out = torch.empty(world * len(b), dtype=torch.uint8, device=tdev)
-        dist.all_gather_into_tensor(out, src)
+    def gather_bytes(self, b):
+        if not self.active:
+            return [bytes(b)]
+        src = self.torch.frombuffer(bytearray(b), dtype=self.torch.uint8).to(self._dev())
+        out = self.torch.empty(self.world * len(b), dtype=self.torch.uint8, device=self._dev())
+        self.dist.all_gather_into_tensor(out, src)
         raw = out.cpu().numpy().tobytes()
-        return [raw[i * len(b):(i + 1) * len(b)] for i in range(world)]
+        return [raw[i * len(b):(i + 1) * len(b)] for i in range(self.world)]
 
+    def agree(self, phase, ok, msg=""):
+        """Every rank reports (ok, msg) for `phase`; returns (all ok, {rank: msg of the failed ones}).  A rank that does not
+        report within the timeout counts as failed."""
+        if not self.active:
+            return ok, ({} if ok else {self.rank: msg})
+        import datetime
+
+        if self.store is None:
+            objs = [None] * self.world
+            self.dist.all_gather_object(objs, (bool(ok), str(msg)[:400]))
+            bad = {r: m for r, (k, m) in enumerate(objs) if not k}
+            return not bad, bad
+        self.store.set(f"bench/{phase}/{self.rank}", json.dumps([bool(ok), str(msg)[:400]]))
+        bad = {}
+        for r in range(self.world):
+            key = f"bench/{phase}/{r}"
+            try:
+                self.store.wait([key], datetime.timedelta(seconds=self.timeout_s))
+                k, m = json.loads(self.store.get(key).decode())
+                if not k:
+                    bad[r] = m
+            except Exception as e:   # noqa: BLE001 -- no status from that rank: it is gone or stuck
+                bad[r] = f"no status within {self.timeout_s} s ({type(e).__name__})"
+        return not bad, bad
+
+
+def errmsg(e):
+    return f"{type(e).__name__}: {e}"[:400]
+
+
+def make_collective(args, ctl, eng, torch, dist, rank, world):
+    """The data-path collective of the SRS-sharded MSM, decided ONCE per launch, before any table is built.
+    Preferred: the library's own (kzg_comm_init + a checked all_gather; both under a watchdog).  If ANY rank fails that
+    preflight, every rank uses the process group's all_gather instead (`DeviceGather`: gloo moves the device tensors
+    through the host; with BENCH_BACKEND=nccl it is torch's RCCL group) and the line records why.
+    Returns (gather object with .msm(slot, n, offset), description dict)."""
+    from zkp_subnet_amd.distributed import DeviceGather, LibraryGather
+
+    want = os.environ.get("BENCH_COLLECTIVE", "library")
+    backend = dist.get_backend()
+    info = {"preferred": want, "process_group_backend": backend}
+    if want == "library":
+        g, err = None, ""
+        try:
+            inject("comm_init", rank)
+            t0 = time.time()
+            g = LibraryGather(eng, timeout_ms=int(os.environ.get("BENCH_COMM_TIMEOUT_MS", "120000")),
+                              init_timeout_s=float(os.environ.get("BENCH_COMM_INIT_TIMEOUT_S", "120")))
+            eng.comm_selftest()
+            info["comm_init_s"] = round(time.time() - t0, 2)
+        except BaseException as e:       # noqa: BLE001 -- including a TimeoutError of the init watchdog
+            err = errmsg(e)
+        ok, bad = ctl.agree("collective_preflight", not err, err)
+        if ok:
+            ci = eng.comm_info()
+            info.update({"collective": "library: ncclAllGather of 192 B per rank on the lane's own stream (kzg_msm_sharded)",
+                         "rccl_version": ci["rccl_version"], "rccl_binding": "dlopen(librccl.so.1) inside libkzg_mi355x.so"})
+            return g, info
+        info["library_preflight_failed"] = {str(r): m for r, m in sorted(bad.items())}
+        if g is not None and not err:
+            try:
+                g.close()                # healthy here, unusable elsewhere: drop it
+            except Exception:            # noqa: BLE001
+                pass
+        first = next(iter(sorted(bad.items())))
+        why = f"library RCCL preflight failed on rank {first[0]}: {first[1]}"
+        if backend == "nccl":
+            info.update({"collective": f"torch.distributed all_gather over torch's RCCL group ({why})",
+                         "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())})
+        else:
+            info.update({"collective": f"{backend} fallback ({why})", "rccl_version": f"none ({backend} fallback: {why})"})
+        stuck = bool(err) and "did not all join" in err
+        return DeviceGather(eng) if not stuck else None, dict(info, engine_stuck_in_comm_init=stuck)
+    if backend == "nccl":
+        info.update({"collective": "torch.distributed all_gather over torch's RCCL group, chained through streams (A/B form)",
+                     "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())})
+    else:
+        info.update({"collective": f"torch.distributed all_gather over {backend} (self-test form)",
+                     "rccl_version": f"none ({backend} self-test)"})
+    return DeviceGather(eng), info
+
+
+def dist_extra_workloads(args, ctl, eng, gather, lagrange_factor, rank, world):
+    """With a process group and no --workload: the OTHER multi-GPU configurations of BASELINE.json, measured in the same
+    launch so that a driver SCALE run (which passes no flags) yields every multi-GPU number:
+      pianist_kzg22  configs[4]: one degree-2^22 commit+open per rank (Pianist worker row `rank`), no exchange (weak)
+      msm26          configs[3]: ONE 2^26-point MSM, SRS split into `world` contiguous segments, one per rank, partials
+                     all_gathered and summed on every rank (strong scaling: total work fixed)
+    Same timing discipline as the headline: W warm-up steps, K steps between barrier + synchronize, MAX over ranks.
+    The same engine (and its communicator) serves all of them: the tables are rebuilt per workload.  Every phase runs in
+    try/except on every rank and its status is agreed through the store BEFORE anybody enters a collective of the next
+    phase: a failure becomes {"error": ...} in that object, never a hang and never a lost headline.  pianist first: it
+    needs no data-path collective and the least memory; msm26 (largest tables, a collective per step) last."""
     res = {}
     steps, warm = max(1, min(args.steps, 10)), max(1, min(args.warmup, 3))
+
+    def phase(name, setup, timed, report):
+        """setup() -> state on every rank; agreed; timed(state) -> per-rank result inside barriers; agreed; report()."""
+        if ctl.poisoned:
+            res[name] = {"error": f"skipped: the process group is unusable after {ctl.poisoned}"}
+            return
+        state, err = None, ""
+        try:
+            inject(name + "_setup", rank)
+            state = setup()
+        except BaseException as e:       # noqa: BLE001 -- OOM, HIP errors, injected faults: all become a status
+            err = errmsg(e)
+        ok, bad = ctl.agree(name + "_setup", not err, err)
+        if not ok:
+            res[name] = {"error": "setup failed", "ranks": {str(r): m for r, m in sorted(bad.items())}}
+            return
+        out, err = None, ""
+        try:
+            out = timed(state)
+        except BaseException as e:       # noqa: BLE001
+            err = errmsg(e)
+        ok, bad = ctl.agree(name + "_timed", not err, err)
+        if not ok:
+            # somebody left the timed loop early: collectives of the group may be half-done on the others
+            ctl.poisoned = f"{name} failed inside its timed region"
+            res[name] = {"error": "timed region failed", "ranks": {str(r): m for r, m in sorted(bad.items())}}
+            return
+        try:
+            res[name] = report(state, out)
+        except BaseException as e:       # noqa: BLE001
+            res[name] = {"error": "report failed: " + errmsg(e)}
+            ctl.poisoned = f"{name} failed while gathering its results"
+
+    # ---- pianist_kzg22: worker row `rank` on this GPU, full commit+open, no data-path collective
+    lg_row = args.kzg22_log
+    T = 1 << lg_row
+    ms = max(0, (world - 1).bit_length())
+    alpha = uniform_fr(1, seed=1)
+
+    def pianist_setup():
+        t0 = time.time()
+        row = uniform_fr(T, seed=rank)
+        tau_y = (TAU * 7 + 1) % R_MOD
+        eng.gen_srs(TAU, 0, lg_row + ms, ms, factors=[lagrange_factor(rank, ms, tau_y)])
+        eng.upload_fr(0, row, True)
+        ref = None
+        for _ in range(warm):
+            ref = eng.commit_open_resident(0, 0, T, alpha, True)
+        return {"ref": ref, "setup_s": time.time() - t0, "window": eng.window}
+
+    def pianist_timed(st):
+        ctl.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            assert eng.commit_open_resident(0, 0, T, alpha, True) == st["ref"], "non-deterministic commit+open"
+        ctl.barrier()
+        return ctl.max_over_ranks(time.perf_counter() - t0)
+
+    def pianist_report(st, el):
+        rows = ctl.gather_bytes(b"".join(st["ref"]))          # 48 + 32 + 48 bytes per rank
+        agg = eng.g1_sum_compressed(b"".join(r[:48] for r in rows))     # master aggregation: sum_i commit_i
+        alg = 384.0 * T
+        return {
+            "metric": f"KZG commit+open coefficients/sec at 2^{lg_row} per segment", "value": T * world * steps / el,
+            "unit": "coefficients/s", "ms_per_step": el / steps * 1e3, "per_segment_latency_ms": el / steps * 1e3,
+            "steps": steps, "warmup": warm, "scaling": "weak", "n_gpus": world, "window_bits": st["window"],
+            "workload": f"Pianist segments: {world} worker row(s) of 2^{lg_row} evaluation-form coefficients, one per GPU, full "
+                        "commit+open (INTT + 2 MSM + quotient) per segment, no exchange on the data path",
+            "results_hex_by_rank": [r.hex() for r in rows], "aggregate_commitment_hex": agg.hex(),
+            "setup_s": round(st["setup_s"], 2),
+            "roofline": {"bound": "hbm", "achieved": alg / (el / steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / (el / steps) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg,
+                         "per": "whole commit+open call", "traffic": None}}
+
+    phase("pianist_kzg22", pianist_setup, pianist_timed, pianist_report)
+
     # ---- msm26
     lg_total = args.msm26_log
-    if not (world & (world - 1)) and (1 << lg_total) >= world:
-        n_total = 1 << lg_total
-        n = n_total // world
-        lg = n.bit_length() - 1
-        eng = HipEngine(local_rank, window=args.window)
+    if world & (world - 1) or (1 << lg_total) < world:
+        res["msm26"] = {"error": f"needs a power-of-two number of ranks <= 2^{lg_total} (got {world})"}
+        return res
+    n_total = 1 << lg_total
+    n = n_total // world
+    lg = n.bit_length() - 1
+
+    def msm26_setup():
+        if gather is None:
+            raise RuntimeError("no usable collective on this rank (its engine is stuck in the communicator's init)")
         t0 = time.time()
         scal = uniform_fr(n, seed=1000 + rank)
         eng.gen_srs(TAU, 1, lg, 0, factors=[pow(TAU, rank * n, R_MOD)])
         eng.upload_fr(0, scal, False)
-        setup_s = time.time() - t0
-        g = DeviceGather(eng)
-        step = lambda: g.msm(0, n, 0)          # noqa: E731 -- partial -> all_gather -> sum, chained through streams
+        return {"setup_s": time.time() - t0, "window": eng.window}
+
+    def msm26_timed(st):
+        ref = None
         for _ in range(warm):
-            ref = step()
+            ref = gather.msm(0, n, 0)      # partial -> all_gather -> sum, on the device
         eng.set_profiling(2)
-        barrier()
-        t0 = time.perf_counter()
-        acc = 0.0
-        for _ in range(steps):
-            r = step()
-            acc += eng.timings().get("accumulate", 0.0)
-            assert r == ref, "non-deterministic sharded MSM"
-        barrier()
-        el = max_over_ranks(time.perf_counter() - t0)
-        eng.set_profiling(0)
-        allr = gather_bytes(ref)
-        assert all(x == allr[0] for x in allr), "ranks disagree on the sharded MSM result"
-        kernel_ms = acc / steps
+        try:
+            ctl.barrier()
+            t0 = time.perf_counter()
+            acc = 0.0
+            for k in range(steps):
+                if k == steps // 2:
+                    inject("msm26_step", rank)
+                r = gather.msm(0, n, 0)
+                acc += eng.timings().get("accumulate", 0.0)
+                assert r == ref, "non-deterministic sharded MSM"
+            ctl.barrier()
+            el = ctl.max_over_ranks(time.perf_counter() - t0)
+        finally:
+            eng.set_profiling(0)
+        return {"ref": ref, "el": el, "kernel_ms": acc / steps}
+
+    def msm26_report(st, out):
+        allr = ctl.gather_bytes(out["ref"])
+        equal = all(x == allr[0] for x in allr)
+        kernel_ms, el = out["kernel_ms"], out["el"]
         ach = 128.0 * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None
-        res["msm26"] = {
+        rec = {
             "metric": f"BLS12-381 G1 MSM points/sec at 2^{lg_total} (SRS-sharded)", "value": n_total * steps / el,
             "unit": "points/s", "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warm, "scaling": "strong",
-            "n_gpus": world, "points_per_gpu": n, "window_bits": eng.window, "result_hex": ref.hex(),
-            "all_ranks_equal": True, "setup_s": round(setup_s, 2),
+            "n_gpus": world, "points_per_gpu": n, "window_bits": st["window"], "result_hex": out["ref"].hex(),
+            "all_ranks_equal": equal, "setup_s": round(st["setup_s"], 2),
             "workload": f"2^{lg_total}-point G1 MSM, SRS split into {world} contiguous segment(s) of 2^{lg} points, "
-                        "partials all_gathered (192 B per rank) over RCCL, summed on every rank",
+                        "partials all_gathered (192 B per rank), summed on every rank",
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS if ach else None, "kernel_ms": kernel_ms,
                          "algorithmic_bytes": 128.0 * n, "traffic": None}}
-        del g
-        eng.close()
-        torch.cuda.empty_cache()
-    # ---- pianist_kzg22: worker row `rank` on this GPU, full commit+open, no data-path collective
-    lg = args.kzg22_log
-    T = 1 << lg
-    ms = max(0, (world - 1).bit_length())
-    eng = HipEngine(local_rank, window=args.window)
-    t0 = time.time()
-    row = uniform_fr(T, seed=rank)
-    alpha = uniform_fr(1, seed=1)
-    tau_y = (TAU * 7 + 1) % R_MOD
-    eng.gen_srs(TAU, 0, lg + ms, ms, factors=[lagrange_factor(rank, ms, tau_y)])
-    eng.upload_fr(0, row, True)
-    setup_s = time.time() - t0
-    for _ in range(warm):
-        ref = eng.commit_open_resident(0, 0, T, alpha, True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        assert eng.commit_open_resident(0, 0, T, alpha, True) == ref, "non-deterministic commit+open"
-    barrier()
-    el = max_over_ranks(time.perf_counter() - t0)
-    rows = gather_bytes(b"".join(ref))               # 48 + 32 + 48 bytes per rank
-    agg = eng.g1_sum_compressed(b"".join(r[:48] for r in rows))     # master aggregation: sum_i commit_i
-    alg = 384.0 * T
-    res["pianist_kzg22"] = {
-        "metric": f"KZG commit+open coefficients/sec at 2^{lg} per segment", "value": T * world * steps / el,
-        "unit": "coefficients/s", "ms_per_step": el / steps * 1e3, "per_segment_latency_ms": el / steps * 1e3,
-        "steps": steps, "warmup": warm, "scaling": "weak", "n_gpus": world, "window_bits": eng.window,
-        "workload": f"Pianist segments: {world} worker row(s) of 2^{lg} evaluation-form coefficients, one per GPU, full "
-                    "commit+open (INTT + 2 MSM + quotient) per segment, no exchange on the data path",
-        "results_hex_by_rank": [r.hex() for r in rows], "aggregate_commitment_hex": agg.hex(), "setup_s": round(setup_s, 2),
-        "roofline": {"bound": "hbm", "achieved": alg / (el / steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": alg / (el / steps) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg, "per": "whole commit+open call",
-                     "traffic": None}}
-    eng.close()
+        if not equal:
+            rec["error"] = "ranks disagree on the sharded MSM result"
+        return rec
+
+    phase("msm26", msm26_setup, msm26_timed, msm26_report)
     return res
+
+
+SOURCE_GLOBS = ("bench.py", "__graft_entry__.py", "include/*.h", "oracle/*.py", "oracle/*.c", "oracle/Makefile",
+                "zkp_subnet_amd/*.py", "zkp_subnet_amd/csrc/*")
+
+
+def source_sha16(root=ROOT):
+    """Content identity of the tree a line was measured on, computable where there is no .git (the GPU boxes receive a
+    snapshot without it): sha256 over (relative path, sha256 of the file) of every product / oracle / bench source."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for pat in SOURCE_GLOBS:
+        for path in sorted(glob.glob(os.path.join(root, pat))):
+            if os.path.isfile(path) and not path.endswith((".so", ".o", ".pyc")):
+                with open(path, "rb") as f:
+                    h.update(os.path.relpath(path, root).encode() + b"\0" + hashlib.sha256(f.read()).digest())
+    return h.hexdigest()[:16]
+
+
+def identity():
+    """Who measured this line: library version, git head (when the tree has a .git or the launcher left `.git_head`),
+    sha256[:16] of bench.py and of the whole source set.  scripts/evidence_keep.py refuses a file whose source_sha16 is not
+    the tree's; no two rounds' evidence files can be byte-identical."""
+    import hashlib
+    import subprocess
+
+    from zkp_subnet_amd import _native
+
+    head = None
+    try:
+        r = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=20)
+        if r.returncode == 0:
+            head = r.stdout.strip()
+            d = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], capture_output=True,
+                               text=True, timeout=20)
+            if d.returncode == 0 and d.stdout.strip():
+                head += "+dirty"
+    except (OSError, subprocess.TimeoutExpired):
+        pass
+    if head is None:
+        try:
+            with open(os.path.join(ROOT, ".git_head")) as f:
+                head = f.read().strip() or None
+        except OSError:
+            pass
+    with open(os.path.abspath(__file__), "rb") as f:
+        bsha = hashlib.sha256(f.read()).hexdigest()[:16]
+    return {"lib_version": _native.load().kzg_version().decode(), "git_head": head, "bench_py_sha16": bsha,
+            "source_sha16": source_sha16(), "utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime())}
+
+
+def e2e_from_text_report(device, logs, with_cpu):
+    """The route the reference ACTUALLY runs, at the reference's sizes (N = 1, after the timed regions, never part of
+    `value`): for T = 2^16 (mainnet, Makefile:63-74), 2^12 (testnet, :89-101) and 2^10 (default flags, utils/config.py:
+    152-164) -- `Client.worker_commit` then `worker_open` from List[str] (the unchanged neurons/miner.py:56-61; the second
+    call is a verified row-cache hit) and the one-call `worker_commit_and_open`; median of >= 20 requests, every answer
+    asserted equal to the C oracle's on the same row."""
+    from zkp_subnet_amd import codec
+    from zkp_subnet_amd.client import Client
+
+    rows = {}
+    for lg in logs:
+        T = 1 << lg
+        cl = Client(seed=3, workers=[0], device=device)
+        cl.start(scale=lg, machines_scale=0)
+        try:
+            # SIX different rows in rotation: the library keeps the last four rows' coefficients, so every worker_commit is
+            # a miss (as for a fresh challenge) and every worker_open that follows it a verified hit -- what a miner sees
+            nrows = 6
+            raws = [uniform_fr(T, seed=100 * lg + k) for k in range(nrows)]
+            polys = [codec.be32_to_fr_list(r) for r in raws]
+            xb = uniform_fr(1, seed=2)
+            x = codec.be32_to_fr(xb)
+            wants = None
+            if with_cpu:
+                from oracle import cpu as oc     # the checker: never inside a timed call
+
+                oc.build()
+                srs = cl.engine.srs_read(0, T)
+                wants = []
+                for r in raws:
+                    ev, pf = oc.open_(srs, r, xb, True, threads=8)
+                    wants.append({"commitment": codec.g1_to_b64(oc.commit(srs, r, True, threads=8)),
+                                  "eval": codec.be32_to_fr(ev), "proof": codec.g1_to_b64(pf)})
+
+            def two_call(poly):
+                with cl.worker_commit(0, poly) as a, cl.worker_open(0, poly, x) as b:
+                    assert a.status_code == 200 and b.status_code == 200, (a.json(), b.json())
+                    return {"commitment": a.json()["commitment"], "eval": b.json()["eval"], "proof": b.json()["proof"]}
+
+            def fused(poly):
+                with cl.worker_commit_and_open(0, poly, x) as r:
+                    assert r.status_code == 200, r.json()
+                    return dict(r.json())
+
+            rec = {"log2_T": lg}
+            for name, fn in (("two_call", two_call), ("fused", fused)):
+                t_w, warm = time.perf_counter(), 0
+                while warm < nrows or time.perf_counter() - t_w < 0.08:      # the clocks need ~40 ms of load
+                    fn(polys[warm % nrows])
+                    warm += 1
+                h0, m0 = cl.engine.row_cache_stats()
+                lat = []
+                for k in range(30):
+                    t1 = time.perf_counter()
+                    got = fn(polys[k % nrows])
+                    lat.append((time.perf_counter() - t1) * 1e3)
+                    if wants is not None:
+                        assert got == wants[k % nrows], f"{name} route at 2^{lg} differs from the C oracle"
+                h1, m1 = cl.engine.row_cache_stats()
+                rec[name + "_ms"] = {"median": round(pctl(lat, 0.5), 4), "p10": round(pctl(lat, 0.1), 4),
+                                     "p90": round(pctl(lat, 0.9), 4), "requests": len(lat)}
+                if name == "two_call":
+                    rec["two_call_row_cache_hits_misses"] = [h1 - h0, m1 - m0]   # every worker_open a verified hit
+            rec["matches_cpu_oracle_bit_exact"] = wants is not None
+            rec["wire_codec"] = "csrc/wire_py.c (AVX2, pinned staging)" if codec._wire is not None else "python"
+            rows[f"2^{lg}"] = rec
+        finally:
+            cl.stop()
+    return rows
+
+
+def flush_c_stdio():
+    """RCCL writes its banner through C stdio, which is flushed at exit: push it out so that a JSON line printed next is
+    the LAST line of stdout."""
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
 
 
 def visible_gpus():
@@ -352,8 +679,12 @@ def free_port():
 
 def self_launch(n):
     """The N > 1 launch line of the bench contract (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
-    --master-addr 127.0.0.1 --master-port P bench.py <same args>`) run as a child process; returns its exit code."""
+    --master-addr 127.0.0.1 --master-port P bench.py <same args>`) run as a child process under a watchdog; returns its exit
+    code.  The ranks' stdout is relayed line by line with the JSON lines held back so that the LAST one ends the output;
+    their stderr passes through and its tail is repeated when the launch fails or is killed."""
+    import collections
     import subprocess
+    import threading
 
     one_gpu = os.environ.get("BENCH_ONE_GPU") == "1"       # self-test: every rank on device 0 (gloo)
     have = 1 if one_gpu else visible_gpus()
@@ -366,25 +697,60 @@ def self_launch(n):
            "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this pool
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
-    last_json = None
-    try:
+    limit = float(os.environ.get("BENCH_WATCHDOG_S", "1500"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True, bufsize=1)
+    tail = collections.deque(maxlen=60)
+
+    def relay_err():
+        for line in proc.stderr:
+            tail.append(line)
+            sys.stderr.write(line)
+
+    state = {"last_json": None}
+
+    def relay_out():
         for line in proc.stdout:
             if line.lstrip().startswith("{") and '"metric"' in line:
-                last_json = line                           # held back: printed after everything else the ranks wrote
+                state["last_json"] = line                  # held back: printed after everything else the ranks wrote
             else:
                 sys.stdout.write(line)
-        rc = proc.wait()
+
+    threads = [threading.Thread(target=relay_err, daemon=True), threading.Thread(target=relay_out, daemon=True)]
+    for t in threads:
+        t.start()
+    killed = False
+    try:
+        try:
+            rc = proc.wait(timeout=limit)
+        except subprocess.TimeoutExpired:
+            killed = True
+            print(f"bench.py: the launch did not finish within {limit:.0f} s (BENCH_WATCHDOG_S): terminating it",
+                  file=sys.stderr)
+            proc.terminate()                               # the exact child we started, never a pattern
+            try:
+                rc = proc.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                proc.kill()
+                rc = proc.wait()
     except BaseException:
-        proc.terminate()                                   # the exact child we started, never a pattern
+        proc.terminate()
         try:
             proc.wait(timeout=30)
         except subprocess.TimeoutExpired:
             proc.kill()
         raise
+    for t in threads:
+        t.join(timeout=10)
+    last_json = state["last_json"]
+    if rc != 0 or killed:
+        print(f"bench.py: the launch ended with code {rc}" + (" (killed by the watchdog)" if killed else "")
+              + "; last lines of the ranks' stderr:", file=sys.stderr)
+        sys.stderr.write("".join(list(tail)[-25:]))
     if last_json is not None:
         sys.stdout.write(last_json if last_json.endswith("\n") else last_json + "\n")
     sys.stdout.flush()
+    if killed:
+        return rc if rc not in (0, None) else 124
     if rc == 0 and last_json is None:
         print("bench.py: the ranks exited cleanly but printed no result line", file=sys.stderr)
         return 3
@@ -408,7 +774,9 @@ def main():
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the second timing of the same K steps with two requests in flight (`pipelined`)")
     ap.add_argument("--no-kzg-rows", action="store_true", help="skip the commit+open latency rows (`kzg_commit_open`)")
-    ap.add_argument("--kzg-rows", default="22,16,12", help="log2 row lengths of `kzg_commit_open`")
+    ap.add_argument("--kzg-rows", default="22,16,12,10", help="log2 row lengths of `kzg_commit_open`")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the from-text rows of the reference's own route (`e2e_from_text`)")
+    ap.add_argument("--e2e-rows", default="16,12,10", help="log2 row lengths of `e2e_from_text`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adversarial", action="store_true", help="skip the separately reported adversarial inputs")
     ap.add_argument("--no-dist-extra", action="store_true",
@@ -420,7 +788,7 @@ def main():
                          "of the headline size, so rocprofv3's average matches `roofline.kernel_ms`)")
     args = ap.parse_args()
     if args.headline_only:
-        args.no_pipelined = args.no_kzg_rows = args.no_cpu_baseline = args.no_adversarial = args.no_dist_extra = True
+        args.no_pipelined = args.no_kzg_rows = args.no_cpu_baseline = args.no_adversarial = args.no_dist_extra = args.no_e2e = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -433,40 +801,51 @@ def main():
     if world != args.gpus:
         args.gpus = world
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this pool
+    import datetime
+
     import torch
     import torch.distributed as dist
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    # BENCH_ONE_GPU=1 + BENCH_BACKEND=gloo: every rank on device 0, the SAME code path with gloo as the transport -- the self-test
-    # of the N > 1 logic (rank-dependent SRS segments, cross-rank checks, msm26 / pianist_kzg22) on a one-GPU box, where
-    # RCCL cannot form a group of two (tests/test_gpu_parity.py).  Never what a measurement uses.
-    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    # The process group is the CONTROL plane (barriers, MAX over ranks, cross-rank checks, the rendezvous of the library's
+    # communicator): gloo with a timeout by default.  The data path of the sharded MSM is the library's own ncclAllGather
+    # (RCCL over xGMI), see make_collective().  BENCH_BACKEND=nccl: torch's RCCL group carries both (the round-4 form).
+    # BENCH_ONE_GPU=1: every rank on device 0 -- the self-test of the N > 1 logic (rank-dependent SRS segments, cross-rank
+    # checks, msm26 / pianist_kzg22, the fallback from a communicator that cannot form) on a one-GPU box, where RCCL refuses
+    # two ranks on one device (tests/test_gpu_parity.py).  Never what a measurement uses.
+    backend = os.environ.get("BENCH_BACKEND", "gloo")
     if os.environ.get("BENCH_ONE_GPU") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the latter: 1-rank RCCL group (self-test)
-    rccl = backend == "nccl"
-    tdev = "cuda"        # gloo carries device tensors too (through the host): one code path for both backends
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the latter: a 1-rank group (self-test)
+    pg_timeout_s = float(os.environ.get("BENCH_PG_TIMEOUT_S", "180"))
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if rccl:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=pg_timeout_s), **kw)
+    ctl = Ctl(torch, dist, rank, world, use_dist, pg_timeout_s + 90)
+    barrier = ctl.barrier
 
     from zkp_subnet_amd import HipEngine
     from zkp_subnet_amd.distributed import all_gather_partials
     from zkp_subnet_amd.engine import lagrange_factor
 
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     is_msm = args.workload in ("msm20", "msm26")
     eng = HipEngine(local_rank, window=args.window)
+    # the collective of the sharded MSM is decided NOW, before any table is built or scalar uploaded: communicator +
+    # checked all_gather under a watchdog, agreed between the ranks through the store; a failure falls back, flagged
+    gather, coll_info, leaked = None, None, []
+    if use_dist and is_msm:
+        from zkp_subnet_amd.distributed import DeviceGather
+
+        gather, coll_info = make_collective(args, ctl, eng, torch, dist, rank, world)
+        if gather is None:      # this rank's engine is stuck inside ncclCommInitRank on a helper thread: leave it, start over
+            leaked.append(eng)
+            eng = HipEngine(local_rank, window=args.window)
+            gather = DeviceGather(eng)
     t_setup = time.time()
     if args.workload == "msm20":
         lg = args.log_n or 20
@@ -511,13 +890,12 @@ def main():
     depth = args.in_flight if is_msm else 1
     state = {"depth": depth}
 
-    # N > 1, one request at a time: partial -> RCCL all_gather -> sum entirely through device buffers
-    gather = None
-    if use_dist and is_msm and depth == 1:
-        from zkp_subnet_amd.distributed import DeviceGather
-
-        gather = DeviceGather(eng)
-    state["gather"] = gather
+    # N > 1, one request at a time: partial -> all_gather -> sum entirely on the device (make_collective above)
+    if depth != 1:
+        gather_step = None
+    else:
+        gather_step = gather
+    state["gather"] = gather_step
 
     def submit():
         if is_msm and state["gather"] is None:
@@ -568,19 +946,23 @@ def main():
     pipelined = None
     if is_msm and depth == 1 and not args.no_pipelined:
         state["depth"], state["gather"] = 2, None
-        run_steps(args.warmup, False)
+        # >= 80 ms of the same load first (and at least W steps): the clocks need ~40 ms, and this region used to be the
+        # cold one of the run; the count is reported as `pre_warm_steps`
+        t_w = time.perf_counter()
+        pipe_warm = 0
+        while pipe_warm < args.warmup or time.perf_counter() - t_w < 0.08:
+            run_steps(2, False)
+            pipe_warm += 2
         barrier()
         tp = time.perf_counter()
         run_steps(args.steps, False)
         barrier()
         pipe_s = time.perf_counter() - tp
-        state["depth"], state["gather"] = 1, gather
-        if use_dist:
-            t = torch.tensor([pipe_s], dtype=torch.float64, device=tdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            pipe_s = float(t.item())
+        state["depth"], state["gather"] = 1, gather_step
+        pipe_s = ctl.max_over_ranks(pipe_s)
         pipelined = {"requests_in_flight": 2, "value": n_total * args.steps / pipe_s, "unit": "points/s",
-                     "ms_per_step": pipe_s / args.steps * 1e3}
+                     "ms_per_step": pipe_s / args.steps * 1e3, "pre_warm_steps": pipe_warm}
+    pre_warm_steps = len(results)          # MSMs this GPU ran before the declared warm-up (the `pipelined` measurement)
     run_steps(args.warmup, False)
     results.clear()
     step_ms.clear()
@@ -622,33 +1004,22 @@ def main():
         if is_msm:
             if not use_dist:
                 results.append(eng.msm_resident(0, n, 0))
-            elif gather is not None:
-                results.append(gather.msm(0, n, 0))
+            elif gather_step is not None:
+                results.append(gather_step.msm(0, n, 0))
             else:
                 results.append(eng.g1_sum(b"".join(all_gather_partials(eng.msm_partial_resident(0, n, 0)))))
         else:
             results.append(eng.commit_open_resident(0, 0, n, alpha, True))
         lat.append((time.perf_counter() - tl) * 1e3)
     latency_ms = sorted(lat)[len(lat) // 2]
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = ctl.max_over_ranks(elapsed)
     assert all(r == results[0] for r in results), "non-deterministic result across steps"
     window_bits = eng.window
     dist_extra = None
-    rccl_version = None
-    if use_dist:
-        try:
-            rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version()) if rccl else f"none ({backend} self-test)"
-        except Exception:                      # noqa: BLE001 -- informational only
-            rccl_version = "unknown"
-        if is_msm:                             # every rank computed the same sum: check it, do not assume it
-            src = torch.frombuffer(bytearray(results[0]), dtype=torch.uint8).to(tdev)
-            allr = torch.empty(world * 48, dtype=torch.uint8, device=tdev)
-            dist.all_gather_into_tensor(allr, src)
-            allr = allr.cpu().numpy().tobytes()
-            assert all(allr[48 * i:48 * i + 48] == results[0] for i in range(world)), "ranks disagree on the MSM result"
+    rccl_version = coll_info.get("rccl_version") if coll_info else None
+    if use_dist and is_msm:                    # every rank computed the same sum: check it, do not assume it
+        allr = ctl.gather_bytes(results[0])
+        assert all(x == results[0] for x in allr), "ranks disagree on the MSM result"
     # inputs of the CPU baseline (rank 0, every N): a bounded sample of THIS rank's segment and the GPU's answer on it,
     # taken before the engine is closed; the CPU itself is timed after every timed region of the launch
     cpu_in = None
@@ -659,13 +1030,7 @@ def main():
         else:
             m = min(n, 1 << 17)
             cpu_in = (m, eng.srs_read(0, m), results[0] if m == n else eng.commit_open(0, scal[: 32 * m], alpha, True))
-    if use_dist and args.workload == "msm20" and not args.no_dist_extra:
-        # free this workload's tables first (2^26 / world points per rank come next); rank 0 needs nothing more from `eng`
-        eng.close()
-        eng = None
-        torch.cuda.empty_cache()
-        dist_extra = dist_extra_workloads(args, torch, dist, HipEngine, lagrange_factor, rank, local_rank, world)
-
+    out = None
     if rank == 0:
         stages = {k: v / n_prof for k, v in stage_sum.items()}
         acc_ms = acc_live_ms if acc_live_ms else stages.get("accumulate", 0.0)   # live over the timed region when available
@@ -714,9 +1079,15 @@ def main():
                        "buckets": plan["buckets"], "entries_per_lane": plan["chunk"], "lanes": plan["lanes"],
                        "requests_in_flight": depth, "world_size": dist.get_world_size() if use_dist else 1,
                        "rccl_version": rccl_version,
+                       "collective": coll_info.get("collective") if coll_info else None,
+                       "collective_detail": coll_info,
                        "parallelism": "single GPU" if world == 1 else
-                       (f"SRS-sharded x{world}, all_gather of 192 B partials over RCCL" if is_msm
+                       (f"SRS-sharded x{world}, all_gather of 192 B partials" if is_msm
                         else f"Pianist segments x{world}, no exchange")},
+            "pre_warm_steps": pre_warm_steps,
+            "pre_warm_note": "MSMs this GPU ran BEFORE the W declared warm-up steps (the `pipelined` measurement, taken first so "
+                             "that the one-at-a-time region starts on warm clocks)",
+            "identity": identity(),
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel_ms": per_launch_s * 1e3 if acc_ms else None, "algorithmic_bytes": alg_bytes,
@@ -835,29 +1206,60 @@ def main():
                               + ", ".join(f"{th}: {s:.3f}" for th, s in sorted(per.items())),
                     "matches_gpu_bit_exact": cpu_res == tuple(gpu_same)}
                 assert cpu_res == tuple(gpu_same), "GPU commit+open differs from the CPU oracle on the baseline sample"
-        if dist_extra:
-            out.update(dist_extra)      # `msm26` (configs[3]) and `pianist_kzg22` (configs[4]) of the same launch
-        if eng is not None:
-            eng.close()
-        eng = None
-        # ---- KZG commit+open latency: the other half of BASELINE.json's metric (configs[2] + the production row sizes)
-        if world == 1 and args.workload == "msm20" and not args.no_kzg_rows:
-            logs = [int(x) for x in args.kzg_rows.split(",") if x]
-            out["kzg_commit_open"] = kzg_rows_report(HipEngine, lagrange_factor, local_rank, logs, threads,
-                                                     not args.no_cpu_baseline)
-        # RCCL writes its version banner through C stdio, which is flushed at exit: push it out now so that the JSON
-        # line is the LAST line of stdout
+        if use_dist:
+            # the headline is complete: print it NOW.  The extras below (the largest tables of the launch, a collective per
+            # step) can then cost at most themselves; the augmented line printed after them supersedes this one (the LAST
+            # JSON line is the record).
+            flush_c_stdio()
+            print(json.dumps(dict(out, partial_line="headline only: the extras of this launch follow in the next line")),
+                  flush=True)
+    if use_dist and args.workload == "msm20" and not args.no_dist_extra:
         try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
+            dist_extra = dist_extra_workloads(args, ctl, eng, gather, lagrange_factor, rank, world)
+        except BaseException as e:       # noqa: BLE001 -- belt and braces: the phases catch their own failures
+            dist_extra = {"dist_extra_error": errmsg(e)}
+            ctl.poisoned = ctl.poisoned or "an unexpected failure in the extra workloads"
+    if rank == 0:
+        if dist_extra:
+            out.update(dist_extra)      # `pianist_kzg22` (configs[4]) and `msm26` (configs[3]) of the same launch
+            if ctl.poisoned:
+                out["process_group_note"] = ctl.poisoned
+        if not use_dist:                # N = 1: free the headline's tables before the rows below build their own
+            eng.close()
+            eng = None
+        if world == 1 and args.workload == "msm20" and not use_dist:
+            # ---- KZG commit+open latency: the other half of BASELINE.json's metric (configs[2] + the production row sizes)
+            if not args.no_kzg_rows:
+                try:
+                    logs = [int(x) for x in args.kzg_rows.split(",") if x]
+                    out["kzg_commit_open"] = kzg_rows_report(HipEngine, lagrange_factor, local_rank, logs, threads,
+                                                             not args.no_cpu_baseline)
+                except Exception as e:   # noqa: BLE001 -- an extra never costs the headline
+                    out["kzg_commit_open"] = {"error": errmsg(e)}
+            # ---- the reference's own route and sizes, from text (VERDICT r4 task 5)
+            if not args.no_e2e:
+                try:
+                    out["e2e_from_text"] = e2e_from_text_report(local_rank, [int(x) for x in args.e2e_rows.split(",") if x],
+                                                                not args.no_cpu_baseline)
+                except Exception as e:   # noqa: BLE001
+                    out["e2e_from_text"] = {"error": errmsg(e)}
+        flush_c_stdio()
         print(json.dumps(out), flush=True)
+    if leaked or ctl.poisoned:
+        # a helper thread may still sit inside ncclCommInitRank, or a collective was abandoned half-way: the line is out --
+        # leave without running destructors (communicator, process group) that would wait for peers that are gone
+        flush_c_stdio()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     if eng is not None:
         eng.close()
     if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:                # noqa: BLE001 -- the line is out; a broken group must not turn into a failure code
+            pass
 
 
 if __name__ == "__main__":

@@ -37,7 +37,8 @@ typedef enum {
     KZG_E_POINT = -3,   /* G1 input not reduced or not on the curve */
     KZG_E_HIP = -4,     /* HIP runtime failure or no usable device */
     KZG_E_NOMEM = -5,
-    KZG_E_BUSY = -6     /* an MSM ticket is outstanding (see kzg_msm_submit) */
+    KZG_E_BUSY = -6,    /* an MSM ticket is outstanding (see kzg_msm_submit) */
+    KZG_E_COMM = -7     /* RCCL: the library cannot be loaded, a collective call failed or timed out (kzg_comm_*) */
 } kzg_status;
 
 /* ---- lifecycle: replaces Client(port, bin, ...) + Client.start()/stop()  (reference base/miner.py:73-84,155,181) */
@@ -177,6 +178,38 @@ int kzg_msm_sharded_begin(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offse
 int kzg_msm_sharded_finish(kzg_ctx* ctx, int ticket, const void* dev_partials_xyzz192, uint32_t count,
                            void* producer_stream, uint8_t out48[48]);
 
+/* ---- the collective INSIDE the library ("RCCL is used directly from C++"; one process per GPU, rank g
+ *      holds SRS segment g).  The only exchange of an SRS-sharded MSM is one ncclAllGather of 192 bytes per rank; these
+ *      entry points own the communicator and enqueue that all_gather on the LANE's own stream, between the partial and
+ *      the sum: no foreign stream, no event hand-over, one host wait per MSM, no framework underneath (the reference
+ *      seam is one client object per process, base/miner.py:73-84).  RCCL is bound at the first kzg_comm_* call
+ *      (dlopen of librccl.so.1 -- the copy the process already maps, if any; KZG_RCCL_LIB names another file); without
+ *      it these calls fail with KZG_E_COMM and everything else works as before.
+ *  kzg_comm_unique_id   ncclGetUniqueId: ONE rank calls it and hands the 128 bytes to every rank by any means it has
+ *                       (a file, a socket, torch.distributed's store, MPI): the rendezvous is the caller's.
+ *  kzg_comm_init        ncclCommInitRank on the context's device; collective over the `world` ranks (blocks until all
+ *                       have called it).  Waits for the lanes to be idle; KZG_E_BUSY while a ticket is out.
+ *  kzg_comm_set_timeout per-call budget in ms for kzg_msm_sharded (0 = wait for ever, the default).  When it expires the
+ *                       communicator is ABORTED (ncclCommAbort: the stuck collective leaves the stream), the call and every
+ *                       later one return KZG_E_COMM until kzg_comm_destroy + kzg_comm_init -- a dead peer costs one
+ *                       timeout, never a parked axon thread.
+ *  kzg_comm_info        out[0] rank, out[1] world (0 = no communicator), out[2] RCCL version (e.g. 22707), out[3] 1 if broken.
+ *  kzg_comm_selftest    one small all_gather with checked content (rank i sends 192 bytes of value i + 1): run it right
+ *                       after kzg_comm_init, before tables are built -- ncclCommInitRank succeeding does not prove that bytes
+ *                       move between these ranks.  Collective; honours the timeout.
+ *  kzg_msm_sharded      the MSM of this rank's segment (resident scalars in `slot`, points [srs_offset, srs_offset + n)
+ *                       of this rank's resident SRS) -> 192-byte partial -> ncclAllGather on the lane's stream -> sum of
+ *                       the `world` partials -> 48-byte compressed point, the same on every rank.  Thread-safe like every
+ *                       call (each takes a lane); ranks must issue their sharded MSMs in the same order (RCCL's rule for
+ *                       collectives on one communicator). */
+int kzg_comm_unique_id(uint8_t out_id128[128]);
+int kzg_comm_init(kzg_ctx* ctx, const uint8_t unique_id128[128], int rank, int world);
+int kzg_comm_destroy(kzg_ctx* ctx);
+int kzg_comm_set_timeout(kzg_ctx* ctx, int timeout_ms);
+int kzg_comm_info(kzg_ctx* ctx, int32_t out[4]);
+int kzg_comm_selftest(kzg_ctx* ctx);
+int kzg_msm_sharded(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint8_t out48[48]);
+
 /* ---- device-resident inputs (what a serving loop and bench.py use: inputs already in HBM when timing starts).
  *      slot in [0, 4).  to_mont=1 stores Montgomery form (rows for commit/open), 0 canonical (MSM scalars). */
 int kzg_upload_fr(kzg_ctx* ctx, int slot, const uint8_t* be32, uint64_t n, int to_mont);
@@ -210,7 +243,9 @@ int kzg_staging_release(kzg_ctx* ctx, int token);
  * polynomial as text per call, neurons/miner.py:39,48).  Flushes are contiguous from offset 0 (multiples of 32 bytes).  A
  * compute call that is then handed the buffer's pointer finds the flushed prefix on the device and skips its own upload
  * (it waits for the copy on its stream, not on the host); whatever was not flushed is uploaded the ordinary way.
- * kzg_staging_release forgets the flushes. */
+ * The flushes are ONE-SHOT: they serve the first compute call that is handed the pointer; a second call on the same held
+ * buffer (whose bytes the holder may have rewritten) uploads the ordinary way, and the next flush starts again at
+ * offset 0.  kzg_staging_release forgets the flushes. */
 int kzg_staging_flush(kzg_ctx* ctx, int token, uint64_t offset, uint64_t bytes);
 
 /* ---- where the result point is encoded.  1 (default): the XYZZ working form of the ONE point a request produces
@@ -222,7 +257,8 @@ int kzg_set_host_finish(kzg_ctx* ctx, int enable);
 /* ---- per-stage HIP-event timings of the last hot-path call (events recorded on the ctx's own stream) */
 enum {
     KZG_T_DECODE = 0, KZG_T_NTT, KZG_T_DIGITS, KZG_T_SCAN, KZG_T_SCATTER, KZG_T_ACCUMULATE, KZG_T_FIXUP,
-    KZG_T_TREE, KZG_T_FINAL, KZG_T_POLY, KZG_T_TOTAL, KZG_T_COUNT
+    KZG_T_TREE, KZG_T_FINAL, KZG_T_POLY, KZG_T_TOTAL, KZG_T_COLLECTIVE /* kzg_msm_sharded: pack + all_gather + sum */,
+    KZG_T_COUNT
 };
 /* enable: 0 off; 1 events around every stage (concurrent calls then serialise on one lane so that stage times stay
    attributable); 2 events around the accumulate kernel only (two per launch; nothing is serialised) */

@@ -26,6 +26,11 @@ int kzg_host_xyzz_pair_to_c48(const uint32_t a_limbs28[56], const uint32_t b_lim
                               uint8_t out_b48[48]); /* two points, one shared inversion (commit + open) */
 int kzg_host_xyzz_to_partial192(const uint32_t xyzz_limbs28[56], uint8_t out192[192]);
 
+/* test hook for the timeout path of kzg_msm_sharded: the NEXT sharded MSM on this context first queues a kernel that
+ * spins for `ms` milliseconds (bounded: at most 2000) on its lane, so that a 1-rank communicator can be made to overrun
+ * kzg_comm_set_timeout without a dead peer. */
+int kzg_test_comm_stall(kzg_ctx* ctx, int ms);
+
 /* test hook: final_exp(miller(P, Q)) as 12 x 48 B in tower order (Fp12 = Fp6[w], Fp6 = Fp2[v], Fp2 = Fp[u]) */
 int kzg_vk_pairing(const uint8_t p_be96[96], const uint8_t q_be192[192], uint8_t out_fp12[576]);
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Sanitizer pass over the HOST side on the CPU build (no GPU sanitizer, no XNACK: not available on this pool).
-#   bash scripts/sanitize_cpu.sh [asan|tsan|all]        logs -> profiles/r04_sanitize_<mode>.log
+#   bash scripts/sanitize_cpu.sh [asan|tsan|tsan-lanes|all]        logs -> profiles/<round>_sanitize_<mode>.log
 # Works on a scratch COPY of the tree (default /tmp/kzg_san/<mode>): the shipped .so files are never touched.
 # What is instrumented, with ONE runtime (the ROCm clang's, preloaded into the uninstrumented python):
 #   - libkzg_mi355x.so: every host translation unit (csrc/api.hip host side, pairing_host.cpp, finish_host.cpp) via
@@ -8,13 +8,17 @@
 #   - zkp_subnet_amd/_wire (csrc/wire_py.c) and oracle/libkzg_oracle.so (oracle/kzg_cpu.c) via clang
 # What runs: asan (ASan + UBSan): the whole CPU suite (pytest -m "not gpu") + tests/san_drive.py;
 #            tsan: tests/san_drive.py (8 Python threads on the wire pool incl. the asynchronous batches, the verifier's
-#            thread pool, the oracle's task pool) + the threaded CPU tests (test_verify, test_host_logic, test_oracle).
+#            thread pool, the oracle's task pool) + the threaded CPU tests (test_verify, test_host_logic, test_oracle);
+#            tsan-lanes: tests/lanebook_tsan.cpp -- the context's lane / ticket / staging / row-cache state machine
+#            (csrc/lanebook.h, the HIP-free half of csrc/api.hip) driven by 12 threads with a fake back end and injected
+#            failures.  On this box kzg_create answers KZG_E_HIP, so the instrumented libkzg_mi355x.so never reaches that
+#            code: the drive is how a race detector gets to see it.
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
 MODE=${1:-all}
 WORK=${SAN_WORK:-/tmp/kzg_san}
 CLANG=/opt/rocm/lib/llvm/bin/clang
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 run_mode() {
   local mode=$1 san rt opts
   if [ "$mode" = asan ]; then
@@ -70,10 +74,32 @@ run_mode() {
   tail -n 4 "$LOG"
   return $rc
 }
+run_lanes() {
+  local W=$WORK/tsan-lanes LOG=$R/profiles/${ROUND}_sanitize_tsan_lanes.log rc=0
+  rm -rf "$W"; mkdir -p "$W"
+  {
+    echo "== tsan-lanes build: $(date -u +%FT%TZ)  clang: $($CLANG --version | head -1)"
+    ${CLANG}++ -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=thread -pthread -I "$R/zkp_subnet_amd/csrc" \
+        "$R/tests/lanebook_tsan.cpp" -o "$W/lanebook_tsan" || exit 1
+    export TSAN_OPTIONS="halt_on_error=0:second_deadlock_stack=1:exitcode=66"
+    if "$W/lanebook_tsan" canary 2>&1 | grep -q "ThreadSanitizer: data race"; then
+      echo "== canary: two threads touching one lane without the book ARE reported by this harness"
+    else
+      echo "== canary: NOT reported -- the harness is blind, a clean log below proves nothing"; rc=1
+    fi
+    echo "== tests/lanebook_tsan.cpp: ${LANES_S:-20} s, ${LANES_THREADS:-12} threads"
+    "$W/lanebook_tsan" ${LANES_S:-20} ${LANES_THREADS:-12} > "$W/drive.out" 2>&1 || rc=1
+    cat "$W/drive.out"
+    echo "== ThreadSanitizer reports in the drive: $(grep -c 'WARNING: ThreadSanitizer' "$W/drive.out") (0 = clean)  rc=$rc"
+  } > "$LOG" 2>&1
+  tail -n 3 "$LOG"
+  return $rc
+}
 status=0
 case $MODE in
   asan|tsan) run_mode $MODE || status=1 ;;
-  all) run_mode asan || status=1; run_mode tsan || status=1 ;;
-  *) echo "usage: $0 [asan|tsan|all]"; exit 2 ;;
+  tsan-lanes) run_lanes || status=1 ;;
+  all) run_mode asan || status=1; run_mode tsan || status=1; run_lanes || status=1 ;;
+  *) echo "usage: $0 [asan|tsan|tsan-lanes|all]"; exit 2 ;;
 esac
 exit $status

@@ -26,7 +26,7 @@ def test_header_symbols_all_exported_and_bound(lib):
     hooks = set(re.findall(r"\b(kzg_[a-z0-9_]+)\s*\(", test_hdr))
     # the test hooks are declared apart from the serving surface, in the same library
     assert hooks == {"kzg_test_field", "kzg_test_g1", "kzg_host_xyzz_to_c48", "kzg_host_xyzz_pair_to_c48",
-                     "kzg_host_xyzz_to_partial192", "kzg_vk_pairing"} and not (hooks & serving)
+                     "kzg_host_xyzz_to_partial192", "kzg_vk_pairing", "kzg_test_comm_stall"} and not (hooks & serving)
     assert "test hook" not in hdr.lower() and "kzg_test_" not in hdr
     declared = (serving | hooks) - {"kzg_ctx", "kzg_status"}
     assert len(declared) >= 30
@@ -51,6 +51,54 @@ def test_no_cpu_fallback_without_device(lib):
 
     with pytest.raises(KzgError):
         HipEngine(0)
+
+
+def test_library_collective_is_bound_at_run_time_and_fails_with_a_status_code(lib):
+    """The SRS-sharded MSM's all_gather is the library's own (kzg_comm_* / kzg_msm_sharded), with RCCL
+    resolved by dlopen at the first kzg_comm_* call: loading the prover must not map librccl, and on a box without a GPU
+    the communicator calls answer KZG_E_COMM / KZG_E_ARG -- a status code, never an abort."""
+    import subprocess
+    import sys
+
+    code = ("import ctypes; from zkp_subnet_amd import _native; lib = _native.load();"
+            "m = open('/proc/self/maps').read(); assert 'libkzg_mi355x' in m; print('rccl' in m)")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "False", (out.stdout, out.stderr[-400:])
+    assert lib.kzg_comm_unique_id(None) == _native.KZG_E_ARG
+    assert lib.kzg_comm_init(None, bytes(128), 0, 1) == _native.KZG_E_ARG
+    assert lib.kzg_comm_info(None, None) == _native.KZG_E_ARG
+    assert lib.kzg_msm_sharded(None, 0, 1, 0, ctypes.create_string_buffer(48)) == _native.KZG_E_ARG
+    import torch
+
+    if not torch.cuda.is_available():
+        buf = ctypes.create_string_buffer(128)
+        # without a device: torch's RCCL copy (already mapped when torch was imported first) still draws an id, ROCm's own
+        # refuses -- either way a status code
+        rc = lib.kzg_comm_unique_id(buf)
+        assert rc in (_native.KZG_OK, _native.KZG_E_COMM)
+        if rc:
+            assert b"nccl" in lib.kzg_last_error(None).lower() or b"rccl" in lib.kzg_last_error(None).lower()
+
+
+def test_native_c_caller_builds_against_the_public_header_and_gets_a_status_code_without_a_gpu(lib, tmp_path):
+    """tests/native_caller.c (INTEGRATION.md section 3 as a program): compiles as C99 with -Wall -Wextra -Werror against
+    include/kzg_mi355x.h alone and links the library; on a box without an MI355X kzg_create answers KZG_E_HIP and the
+    program leaves with its "no usable device" code -- no abort, no CPU fallback.  The full run is a `-m gpu` test."""
+    import subprocess
+
+    import torch
+
+    exe = str(tmp_path / "native_caller")
+    libdir = os.path.join(ROOT, "zkp_subnet_amd")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "native_caller.c"), "-o", exe, "-L", libdir, "-lkzg_mi355x", "-Wl,-rpath," + libdir]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-3000:]
+    (tmp_path / "s.bin").write_bytes(bytes(32 * 16))
+    assert subprocess.run([exe], capture_output=True).returncode == 2                 # usage
+    if not torch.cuda.is_available():
+        out = subprocess.run([exe, "4", "00" * 31 + "05", str(tmp_path / "s.bin")], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 3 and "kzg_create -> -4" in out.stderr and "version" in out.stdout, (out.returncode, out.stderr[-500:])
 
 
 def test_product_never_imports_the_oracle():

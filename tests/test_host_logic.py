@@ -142,6 +142,38 @@ def test_validator_reward_table():
     assert [float(x) for x in get_rewards(c, ch, responses, [0.0, 0.0], 30.0)] == [reward(c, ch, responses[i], i, 0.0) for i in range(2)]
 
 
+def test_get_rewards_scores_each_response_on_its_own_proof_even_when_indices_repeat():
+    """Reference neurons/validator.py:160-170 verifies every response's OWN proof and commitment against
+    challenge[response.index]: a corrupt answer echoing another miner's index can neither score nor zero the honest one
+    (ADVICE r4, high), and an index the challenge holds no eval for scores 0.0 instead of raising (medium)."""
+    from zkp_subnet_amd.validator import get_rewards, verify_rows
+
+    c = make_client(6, 2, seed=5)
+    miner = Miner(default_config(scale=6, machines_scale=2), client=c)
+    ch = generate_challenge(c, 2)                                   # 4 rows of polys, evals for the first 2 only
+    assert len(ch.polys) == 4 and len(ch.evals) == 2
+    responses = [miner.forward(ch.to_synapse(i)) for i in range(2)]
+    raw = base64.b64decode(responses[1].proof)
+    bumped = base64.b64encode((int.from_bytes(raw, "big") + 1).to_bytes(len(raw), "big")).decode()
+    forged = responses[1].model_copy(update={"proof": bumped})      # index 1, corrupt proof
+    honest = responses[1]
+    for threads in (1, 4):
+        assert list(get_rewards(c, ch, [forged, honest], [0.0, 0.0], 10.0, threads)) == [0.0, 1.0]
+        assert list(get_rewards(c, ch, [honest, forged], [0.0, 0.0], 10.0, threads)) == [1.0, 0.0]
+        assert list(get_rewards(c, ch, [honest, honest, responses[0]], [0.0, 5.0, 0.0], 10.0, threads)) == [1.0, 0.5, 1.0]
+        assert list(get_rewards(c, ch, [forged, responses[0], honest, forged], [0.0] * 4, 10.0, threads)) == [0.0, 1.0, 1.0, 0.0]
+    # another row's valid proof under the wrong index is invalid for THAT index
+    swapped = responses[0].model_copy(update={"index": 1})
+    assert list(get_rewards(c, ch, [swapped, honest], [0.0, 0.0], 10.0)) == [0.0, 1.0]
+    # indices in [len(evals), len(polys)) and outside the challenge altogether: 0.0, nobody else loses the step
+    for idx in (2, 3, 4, 99, -1):
+        stray = responses[0].model_copy(update={"index": idx})
+        assert list(get_rewards(c, ch, [stray, honest, responses[0]], [0.0] * 3, 10.0)) == [0.0, 1.0, 1.0], idx
+    assert verify_rows(c, ch, [3, 1, 0, 7], [responses[0], honest, None, honest]) == [False, True, False, False]
+    with pytest.raises(ValueError):
+        verify_rows(c, ch, [0], [responses[0], honest])
+
+
 def test_config1_plumbing_degree_4096_commit_under_mock_loop():
     """BASELINE.json configs[0]: degree-2^12 random polynomial (scale 20 / machines_scale 8 shape) through the CPU
     prover under the miner/validator loop.  Trapdoor cross-check keeps it independent of the prover's own MSM."""
@@ -324,6 +356,7 @@ def test_multi_device_client_routes_rows_by_worker_index():
         def __init__(self):
             super().__init__()
             self.seen = []
+            self.batches = []
 
         def commit_open(self, i, row, alpha, evaluation_form=True):
             self.seen.append(("commit_open", self.workers[i]))
@@ -336,6 +369,10 @@ def test_multi_device_client_routes_rows_by_worker_index():
         def open(self, i, row, alpha, evaluation_form=True):
             self.seen.append(("open", self.workers[i]))
             return super().open(i, row, alpha, evaluation_form)
+
+        def verify_batch(self, slices, proofs, alpha, evals, commitments, threads=1):
+            self.batches.append([self.workers[i] for i in slices])
+            return all(self.verify(i, p, alpha, e, c) for i, p, e, c in zip(slices, proofs, evals, commitments))
 
     single = make_client(7, 2, seed=14)
     engines = [Spy(), Spy(), Spy()]
@@ -359,9 +396,37 @@ def test_multi_device_client_routes_rows_by_worker_index():
     responses = [miner.forward(ch.to_synapse(i)) for i in range(4)]
     assert [r.commitment for r in responses] == [a.json()["commitment"] for a in answers]
     assert verify_all(multi, ch, responses, threads=2) == [True] * 4
+    # the batched check runs once per device on that device's own rows (each context only holds its workers' slices and
+    # verifier-key factors) and the verdicts are AND-ed -- it must SUCCEED here, not fall back to row-by-row
+    idx = list(range(4))
+    with multi.worker_verify_batch(idx, [r.proof for r in responses], ch.alpha, ch.evals, [r.commitment for r in responses]) as r:
+        assert r.status_code == 200 and r.json() == {"valid": True}
+    assert [e.batches[-1] for e in engines] == [[0, 3], [1], [2]]
+    bad = [r.proof for r in responses]
+    bad[2] = responses[1].proof
+    with multi.worker_verify_batch(idx, bad, ch.alpha, ch.evals, [r.commitment for r in responses]) as r:
+        assert r.status_code == 200 and r.json() == {"valid": False}
+    assert multi.worker_verify_batch(idx, bad[:3], ch.alpha, ch.evals, [r.commitment for r in responses]).status_code == 400
     assert multi.worker_commit(9, ch.polys[0]).status_code == 400        # index outside 2^machines_scale, as Client
     with multi.aggregate_commitments([r.commitment for r in responses]) as r, \
             single.aggregate_commitments([r.commitment for r in responses]) as s:
         assert r.status_code == s.status_code and r.json() == s.json()
     multi.stop()
     assert multi.worker_commit(0, ch.polys[0]).status_code == 503
+
+
+def test_lane_book_drive_without_a_sanitizer(tmp_path):
+    """csrc/lanebook.h (lanes, MSM tickets, staging pool, row-cache slots: the HIP-free half of csrc/api.hip) under the
+    12-thread fake-back-end drive of tests/lanebook_tsan.cpp, here compiled WITHOUT a sanitizer as a functional check of its
+    invariants (no slot ever handed to two holders, tickets claimed exactly once, BUSY instead of waits that only the caller
+    could end, hits return the row they were filled with).  The ThreadSanitizer run is scripts/sanitize_cpu.sh tsan-lanes
+    (profiles/r05_sanitize_tsan_lanes.log)."""
+    import subprocess
+
+    exe = str(tmp_path / "lanebook_drive")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(root, "zkp_subnet_amd", "csrc"),
+                          os.path.join(root, "tests", "lanebook_tsan.cpp"), "-o", exe], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = subprocess.run([exe, "1.5", "8"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "invariant failures: 0" in out.stdout, (out.stdout[-500:], out.stderr[-1000:])

@@ -10,9 +10,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # scripts point at it instead of overwriting the shipped file.  Never a different implementation, never a fallback.
 LIB_PATH = os.environ.get("KZG_MI355X_LIB") or os.path.join(HERE, "libkzg_mi355x.so")
 
-KZG_OK, KZG_E_ARG, KZG_E_SCALAR, KZG_E_POINT, KZG_E_HIP, KZG_E_NOMEM, KZG_E_BUSY = 0, -1, -2, -3, -4, -5, -6
-STATUS_NAMES = {0: "OK", -1: "E_ARG", -2: "E_SCALAR", -3: "E_POINT", -4: "E_HIP", -5: "E_NOMEM", -6: "E_BUSY"}
-TIMING_NAMES = ["decode", "ntt", "digits", "scan", "scatter", "accumulate", "fixup", "tree", "final", "poly", "total"]
+KZG_OK, KZG_E_ARG, KZG_E_SCALAR, KZG_E_POINT, KZG_E_HIP, KZG_E_NOMEM, KZG_E_BUSY, KZG_E_COMM = 0, -1, -2, -3, -4, -5, -6, -7
+STATUS_NAMES = {0: "OK", -1: "E_ARG", -2: "E_SCALAR", -3: "E_POINT", -4: "E_HIP", -5: "E_NOMEM", -6: "E_BUSY", -7: "E_COMM"}
+TIMING_NAMES = ["decode", "ntt", "digits", "scan", "scatter", "accumulate", "fixup", "tree", "final", "poly", "total", "collective"]
 
 # every symbol include/kzg_mi355x.h (serving surface) and include/kzg_mi355x_test.h (test hooks) declare:
 # name -> (restype, argtypes)
@@ -59,6 +59,14 @@ SYMBOLS = {
     "kzg_g1_sum_dev": (_I, [_P, _P, _U32, _B]),
     "kzg_msm_sharded_begin": (_I, [_P, _I, _U64, _U64, _P, _P, ctypes.POINTER(_I)]),
     "kzg_msm_sharded_finish": (_I, [_P, _I, _P, _U32, _P, _B]),
+    "kzg_comm_unique_id": (_I, [_B]),
+    "kzg_comm_init": (_I, [_P, _B, _I, _I]),
+    "kzg_comm_destroy": (_I, [_P]),
+    "kzg_comm_set_timeout": (_I, [_P, _I]),
+    "kzg_comm_info": (_I, [_P, ctypes.POINTER(ctypes.c_int32)]),
+    "kzg_comm_selftest": (_I, [_P]),
+    "kzg_msm_sharded": (_I, [_P, _I, _U64, _U64, _B]),
+    "kzg_test_comm_stall": (_I, [_P, _I]),
     "kzg_upload_fr": (_I, [_P, _I, _B, _U64, _I]),
     "kzg_msm_resident": (_I, [_P, _I, _U64, _U64, _B]),
     "kzg_msm_partial_resident": (_I, [_P, _I, _U64, _U64, _B]),

@@ -28,6 +28,8 @@
 #include "fr_kernels.hip.h"
 #include "msm.hip.h"
 #include "fp_lp.hip.h"
+#include "rccl_dl.h"
+#include "lanebook.h"
 
 #define KZG_VERSION "kzg_mi355x 0.4 (gfx950)"
 #define N_SLOTS 4
@@ -97,7 +99,8 @@ struct StageSpan {
 // the host in a single copy.  A call owns its lane from acquire to release, so host threads calling into one ctx (the
 // reference's axon runs Miner.forward on worker threads, neurons/miner.py:106-135) run concurrently on different lanes:
 // one request's sort and latency-bound tail hide under another's accumulate.  The SRS tables are shared, read-only.
-enum { LANE_FREE = 0, LANE_CALL, LANE_TICKET, LANE_WAITING };
+using kzg_book::LANE_CALL;      // lane / ticket / staging / row-cache bookkeeping: csrc/lanebook.h (HIP-free, TSan-driven)
+using kzg_book::LANE_TICKET;
 // tail record (device, 1024 B).  [0, TB_COPY) is copied to the lane's pinned buffer when a request finishes.
 enum {
     TB_RES0 = 0, TB_RES1 = 224,   // result points, XYZZ working form (2 x 224 B)
@@ -118,6 +121,7 @@ struct Lane {
     DevBuf rank, sorted, hist, offsets, bufA, bufB, bufC, bufD, carries, carry_key;      // MSM workspace
     DevBuf ntt_mid;               // the vector between the passes of an NTT (9 words per element)
     DevBuf gather;                // kzg_msm_sharded_finish: the gathered partials, unpacked (own buffer: the MSM may still run)
+    DevBuf comm_send, comm_recv;  // kzg_msm_sharded: this rank's packed 192-byte partial / the `world` gathered ones (sized by kzg_comm_init)
     DevBuf in_be, scal, coeffA, coeffB, qbuf, hbuf, hnext, out_be;                 // request buffers
     uint8_t* tail = nullptr;      // device, TB_SIZE
     uint8_t* pin = nullptr;       // host pinned, 4096
@@ -134,7 +138,6 @@ struct Lane {
     hipStream_t vstream = nullptr;   // row-cache hits: upload of the caller's row + its comparison with the cached one,
     hipEvent_t ev_verify = nullptr;  // beside the request's own kernels (the lane's publish waits for this event)
     DevBuf vbuf;
-    int state = LANE_FREE;
     bool partial = false;         // outstanding ticket wants the 192-byte partial
     // profiling spans of the call running on this lane
     std::vector<hipEvent_t> ev_pool;
@@ -145,11 +148,13 @@ struct Lane {
 };
 struct Stage {
     void* p = nullptr;
-    size_t cap = 0;
-    bool used = false;
+    size_t cap = 0;               // (who holds the buffer is the book's business: ctx->book.stage_*)
     // kzg_staging_flush: a device twin that receives the buffer's prefix WHILE the host is still decoding the rest
     DevBuf twin;
     uint64_t flushed = 0;         // bytes [0, flushed) of p are in (or on their way to) the twin
+    uint64_t consumed_by = 0;     // id of the API call that was served from the twin (0: none yet).  The flushes are ONE-SHOT:
+                                  // a later call handed the same pointer (the holder may have rewritten the buffer) uploads
+                                  // the ordinary way, and the next flush starts again from offset 0
     hipEvent_t ev = nullptr;      // recorded on ctx->h2d behind the last flush
     // the pointer as OTHER threads may read it (flushed_twin scans every record; only the holder touches the rest)
     std::atomic<void*> p_pub{nullptr};
@@ -159,8 +164,8 @@ struct Stage {
 
 struct kzg_ctx {
     int device = 0;
-    std::mutex mu;                 // guards lane states, the staging pool, the twiddle caches, config and timings
-    std::condition_variable cv;    // a lane or a staging buffer was released
+    kzg_book::LaneBook<N_LANES, N_STAGE> book;   // lanes, tickets, staging pool, row-cache slots: csrc/lanebook.h
+    std::mutex mu;                 // guards the twiddle caches, config and timings
     int c_user = 0, c = 0, nwin = 0;
     int poll_timeout_ms = 200;   // finish(): how long the pinned page is polled before falling back to the stream
     WinLayout lay;
@@ -181,6 +186,16 @@ struct kzg_ctx {
     hipStream_t aux = nullptr;
     DevBuf aux_in, aux_pts, aux_out;
     uint8_t* aux_pin = nullptr;
+    // the library's own communicator (kzg_comm_*): one ncclAllGather of 192 B per rank per sharded MSM, on the lane's stream
+    struct Comm {
+        std::mutex mu;            // RCCL allows one thread at a time per communicator: guards every call that names `comm`
+        ncclComm_t comm = nullptr;
+        int rank = 0, world = 0;
+        int timeout_ms = 0;       // kzg_comm_set_timeout (0: wait for ever)
+        bool broken = false;      // a collective failed or timed out and the communicator was aborted
+        std::string why;
+        std::atomic<int> stall_ms{0};   // kzg_test_comm_stall
+    } comm;
     int profiling = 0;   // 0 off, 1 every stage (calls serialise on lane 0), 2 the accumulate kernel only (no serialisation)
     bool host_finish = true;
     bool srs_subgroup_check = true;  // kzg_load_srs*: G1 membership of every point (kzg_set_srs_subgroup_check)
@@ -193,21 +208,21 @@ struct kzg_ctx {
     double load_stats[4] = {0, 0, 0, 0};   // kzg_get_load_stats
     // coefficient vectors of the last few rows, keyed by the caller's 128-bit content tag (kzg_commit_cached /
     // kzg_open_cached): the reference miner sends the SAME row twice per request (neurons/miner.py:56-61)
+    // (which slot holds which row, and who is using it: ctx->book.rcache_*)
     struct RowCache {
-        uint8_t tag[16] = {0};
-        uint64_t T = 0, stamp = 0;
-        int eval_form = 0;
-        bool valid = false, busy = false;
         DevBuf coef;
         DevBuf raw;        // the row's 32-byte big-endian elements as they were uploaded: what a hit is verified against
     } rcache[N_LANES];
-    uint64_t rc_clock = 0, rc_hits = 0, rc_misses = 0, rc_tag_collisions = 0;
 };
 
 namespace {
 
 // the message of the last failing call ON THIS THREAD (calls run concurrently: a per-ctx string would be torn)
 thread_local std::string tl_err;
+// the API call running on this thread: a fresh id whenever a call takes its lane(s) (LaneHold::take*).  What a one-shot
+// resource (the flushed twin of a staging buffer) remembers of the call it served.
+thread_local uint64_t tl_call_id = 0;
+std::atomic<uint64_t> g_call_ids{0};
 int fail(kzg_ctx*, int code, const std::string& msg) {
     tl_err = msg;
     return code;
@@ -226,64 +241,25 @@ int fail(kzg_ctx*, int code, const std::string& msg) {
 // kzg_msm_wait can free those: waiting here could deadlock a single-threaded caller).  Profiling pins everything to
 // lane 0 so that stage times stay attributable.
 int lane_acquire(kzg_ctx* ctx, int state, int* out_li) {
-    std::unique_lock<std::mutex> lk(ctx->mu);
-    for (;;) {
-        const int limit = ctx->profiling == 1 ? 1 : N_LANES;
-        bool any_call = false;
-        for (int i = 0; i < limit; i++) {
-            if (ctx->lane[i].state == LANE_FREE) {
-                ctx->lane[i].state = state;
-                *out_li = i;
-                return KZG_OK;
-            }
-            any_call |= ctx->lane[i].state == LANE_CALL;
-        }
-        if (!any_call || state == LANE_TICKET)
-            return fail(ctx, KZG_E_BUSY, state == LANE_TICKET ? "every MSM lane is taken: call kzg_msm_wait first"
-                                                               : "every lane holds an outstanding MSM ticket: call kzg_msm_wait first");
-        ctx->cv.wait(lk);
+    switch (ctx->book.acquire(state, out_li)) {
+        case kzg_book::BOOK_OK: return KZG_OK;
+        case kzg_book::BOOK_BUSY_NO_TICKET_LANE: return fail(ctx, KZG_E_BUSY, "every MSM lane is taken: call kzg_msm_wait first");
+        default: return fail(ctx, KZG_E_BUSY, "every lane holds an outstanding MSM ticket: call kzg_msm_wait first");
     }
 }
-int lane_try_second(kzg_ctx* ctx, int first) {  // a second free lane for the two-lane form of a long commit+open, or -1
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    if (ctx->profiling == 1) return -1;
-    for (int i = 0; i < N_LANES; i++) {
-        if (i != first && ctx->lane[i].state == LANE_FREE) {
-            ctx->lane[i].state = LANE_CALL;
-            return i;
-        }
-    }
-    return -1;
-}
-void lane_release(kzg_ctx* ctx, int li) {
-    {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        ctx->lane[li].state = LANE_FREE;
-    }
-    ctx->cv.notify_all();
-}
+int lane_try_second(kzg_ctx* ctx, int first) { return ctx->book.try_second(first); }
+void lane_release(kzg_ctx* ctx, int li) { ctx->book.release(li); }
 // exclusive operations ((re)loading the SRS, uploading a resident slot, reading the SRS back): all lanes, on lane 0
 int lanes_acquire_all(kzg_ctx* ctx) {
-    std::unique_lock<std::mutex> lk(ctx->mu);
-    for (;;) {
-        bool all_free = true, ticket = false;
-        for (const Lane& L : ctx->lane) {
-            all_free &= L.state == LANE_FREE;
-            ticket |= L.state == LANE_TICKET || L.state == LANE_WAITING;
-        }
-        if (ticket) return fail(ctx, KZG_E_BUSY, "an MSM ticket is outstanding: call kzg_msm_wait first");
-        if (all_free) break;
-        ctx->cv.wait(lk);
-    }
-    for (Lane& L : ctx->lane) L.state = LANE_CALL;
+    if (ctx->book.acquire_all() != kzg_book::BOOK_OK) return fail(ctx, KZG_E_BUSY, "an MSM ticket is outstanding: call kzg_msm_wait first");
     return KZG_OK;
 }
-void lanes_release_all(kzg_ctx* ctx) {
-    {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        for (Lane& L : ctx->lane) L.state = LANE_FREE;
-    }
-    ctx->cv.notify_all();
+void lanes_release_all(kzg_ctx* ctx) { ctx->book.release_all(); }
+// the one waiter (or canceller) of a ticket: TICKET -> WAITING under the book's lock
+int ticket_claim(kzg_ctx* ctx, int ticket) {
+    if (ctx->book.ticket_claim(ticket) != kzg_book::BOOK_OK)
+        return fail(ctx, KZG_E_ARG, "no outstanding MSM on this ticket (or it is already being waited for)");
+    return KZG_OK;
 }
 // Owns one lane (optionally a second) for the duration of a call.  Unless the call reached its normal end (`clean`),
 // the streams are drained before the lanes become reusable: a HIP failure midway leaves kernels queued that still read
@@ -293,8 +269,12 @@ struct LaneHold {
     int li = -1, li2 = -1;
     bool all = false, clean = false;
     explicit LaneHold(kzg_ctx* c) : ctx(c) {}
-    int take() { return lane_acquire(ctx, LANE_CALL, &li); }
+    int take() {
+        tl_call_id = ++g_call_ids;
+        return lane_acquire(ctx, LANE_CALL, &li);
+    }
     int take_all() {
+        tl_call_id = ++g_call_ids;
         int rc = lanes_acquire_all(ctx);
         if (rc == KZG_OK) { all = true; li = 0; }
         return rc;
@@ -740,11 +720,22 @@ int check_worker(kzg_ctx* ctx, uint32_t i, uint64_t T) {
 // upload BE scalars to `dst` (device limbs); dst must hold n*32 bytes
 // the device twin of a staging buffer whose first `bytes` bytes have been flushed (kzg_staging_flush), or null.  The
 // caller holds that buffer (it was handed its pointer), so nobody else touches the record meanwhile.
+// One-shot: the twin serves the FIRST API call that asks for it (that call may ask more than once: its upload and its
+// row-cache verification); any later call finds the flushes forgotten -- the holder may have rewritten the pinned buffer
+// between two calls, and a stale twin would be a wrong answer with no error.
 const uint8_t* flushed_twin(kzg_ctx* ctx, const uint8_t* host_ptr, uint64_t bytes, hipEvent_t* ev) {
     for (Stage& st : ctx->stage)
-        if (host_ptr && st.p_pub.load(std::memory_order_acquire) == host_ptr && st.flushed >= bytes && st.twin.p) {
-            *ev = st.ev;
-            return static_cast<const uint8_t*>(st.twin.p);
+        if (host_ptr && st.p_pub.load(std::memory_order_acquire) == host_ptr) {
+            if (st.consumed_by && st.consumed_by != tl_call_id) {
+                st.flushed = 0;                // a second call on the same held buffer: ordinary upload from the host bytes
+                return nullptr;
+            }
+            if (st.flushed >= bytes && st.flushed && st.twin.p) {
+                st.consumed_by = tl_call_id;
+                *ev = st.ev;
+                return static_cast<const uint8_t*>(st.twin.p);
+            }
+            return nullptr;
         }
     return nullptr;
 }
@@ -1066,6 +1057,79 @@ __global__ void __launch_bounds__(64) k_test_g1_lp(int op, const uint8_t* a_be, 
     }
 }
 
+// ---- the library's own collective (kzg_comm_*, kzg_msm_sharded)
+// drops the communicator: destroyed when healthy, aborted when a collective failed or timed out on it (ncclCommDestroy
+// would wait for operations that will never complete).  Callers hold every lane (or are tearing the context down).
+void comm_teardown(kzg_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(ctx->comm.mu);
+    if (ctx->comm.comm) {
+        std::string err;
+        if (const kzg_rccl::Api* r = kzg_rccl::api(&err)) {
+            if (ctx->comm.broken) (void)r->CommAbort(ctx->comm.comm);
+            else (void)r->CommDestroy(ctx->comm.comm);
+        }
+        ctx->comm.comm = nullptr;
+    }
+    ctx->comm.rank = ctx->comm.world = 0;
+    ctx->comm.broken = false;
+    ctx->comm.why.clear();
+}
+// test hook (kzg_test_comm_stall): keeps one wave busy for `ticks` of the constant-rate wall clock, or 2^31 polls at most
+__global__ void __launch_bounds__(64) k_test_stall(uint64_t ticks) {
+    if (threadIdx.x) return;
+    const uint64_t t0 = wall_clock64();
+    for (uint32_t i = 0; i < 0x7fffffffu && wall_clock64() - t0 < ticks; i++) __builtin_amdgcn_s_sleep(32);
+}
+// finish() with a bounded wait: the lane's stream holds a collective whose peers are not ours to trust.  Polls the pinned
+// sequence word the publish sets (busy for the first 100 us, then yielding, then in 50-us sleeps).  The budget counts from
+// the moment `coll_start` (an event recorded right in front of the collective) has fired: it bounds the COLLECTIVE, not
+// this rank's own MSM in front of it -- so when it expires the collective is what the stream is executing, which is the
+// state ncclCommAbort is made for.  *timed_out: the caller aborts the communicator, which releases the stream.
+int finish_bounded(kzg_ctx* ctx, Lane& L, int timeout_ms, hipEvent_t coll_start, bool* timed_out) {
+    *timed_out = false;
+    if (timeout_ms <= 0) return finish(ctx, L, false);
+    prof_close(ctx, L);
+    const uint32_t seq = ++L.pub_seq;
+    launch_publish(L.stream, L.tail, L.pin_dev, TB_COPY, L.flags(), reinterpret_cast<uint32_t*>(L.pin_dev + PIN_SEQ), seq);
+    HIPCHK(ctx, hipGetLastError());
+    const volatile uint32_t* w = reinterpret_cast<const volatile uint32_t*>(L.pin + PIN_SEQ);
+    const auto t0 = std::chrono::steady_clock::now();
+    auto t_coll = t0;
+    bool coll_running = false;
+    for (uint32_t spin = 0; *w != seq; spin++) {
+        if ((spin & 0x3f) != 0x3f) {
+            __builtin_ia32_pause();
+            continue;
+        }
+        const auto now = std::chrono::steady_clock::now();
+        if (!coll_running) {
+            const hipError_t e = hipEventQuery(coll_start);
+            if (e == hipSuccess) {
+                coll_running = true;
+                t_coll = now;
+            } else if (e != hipErrorNotReady) {
+                return fail(ctx, KZG_E_HIP, std::string("kzg_msm_sharded: ") + hipGetErrorString(e));
+            }
+            (void)hipGetLastError();
+        } else if (now - t_coll > std::chrono::milliseconds(timeout_ms)) {
+            *timed_out = true;
+            return fail(ctx, KZG_E_COMM, "kzg_msm_sharded: the all_gather did not complete within " + std::to_string(timeout_ms) +
+                                             " ms (a peer is dead or late); the communicator has been aborted");
+        }
+        const auto dt = now - t0;
+        if (dt > std::chrono::milliseconds(5)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        else if (dt > std::chrono::microseconds(100)) std::this_thread::yield();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    L.flags_clean = true;
+    if (ctx->profiling) HIPCHK(ctx, hipStreamSynchronize(L.stream));    // the stage events behind the publish
+    prof_end(ctx, L);
+    const uint32_t* f = reinterpret_cast<const uint32_t*>(L.pin + TB_FLAGS);
+    if (f[0]) return fail(ctx, KZG_E_SCALAR, "non-canonical Fr scalar (>= r)");
+    if (f[1]) return fail(ctx, KZG_E_POINT, "G1 input not reduced, not on the curve or outside the prime-order subgroup");
+    return KZG_OK;
+}
+
 const char B64[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
 int8_t b64_rev[256];
 bool b64_init_done = false;
@@ -1098,7 +1162,6 @@ int kzg_create(int device_id, kzg_ctx** out) {
     ctx->device = device_id;
     if (const char* e = getenv("KZG_SERIAL_ACC")) ctx->serial_accumulate = e[0] != '0';
     bool ok = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&ctx->h2d, hipStreamNonBlocking) == hipSuccess &&
               hipHostMalloc((void**)&ctx->aux_pin, 256, hipHostMallocDefault) == hipSuccess;
     for (int k = 0; ok && k < N_STAGE; k++)
         ok = hipEventCreateWithFlags(&ctx->stage[k].ev, hipEventDisableTiming) == hipSuccess;
@@ -1121,6 +1184,12 @@ int kzg_create(int device_id, kzg_ctx** out) {
              hipStreamCreateWithFlags(&L.vstream, hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&L.ev_verify, hipEventDisableTiming) == hipSuccess;
     }
+    // The copy stream of kzg_staging_flush is created LAST.  The runtime spreads streams over its few hardware queues in
+    // creation order; created between `aux` and the lanes' streams (as round 4's 1b467d4 did) it moved lanes 0 and 1 --
+    // the two that carry two MSMs in flight -- onto one queue, and the second request's sort and accumulate no longer
+    // overlapped the first one's latency-bound tail: `pipelined` 2.44-2.46 ms per MSM before that commit, 2.64-2.73 with
+    // it, 2.44-2.46 again with the stream created here (same box, three rounds: profiles/r05_ab_pipelined_bisect.log).
+    ok = ok && hipStreamCreateWithFlags(&ctx->h2d, hipStreamNonBlocking) == hipSuccess;
     if (!ok) {
         kzg_destroy(ctx);
         return fail(nullptr, KZG_E_HIP, "stream / event / buffer creation failed");
@@ -1132,11 +1201,13 @@ int kzg_create(int device_id, kzg_ctx** out) {
 void kzg_destroy(kzg_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    comm_teardown(ctx);     // before the lanes' streams go: a communicator holds kernels and proxies on them
     for (Lane& L : ctx->lane) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         if (L.vstream) (void)hipStreamSynchronize(L.vstream);
         for (DevBuf* b : {&L.vbuf, &L.rank, &L.sorted, &L.hist, &L.offsets, &L.bufA, &L.bufB, &L.bufC, &L.bufD, &L.carries, &L.carry_key,
-                          &L.in_be, &L.scal, &L.coeffA, &L.coeffB, &L.qbuf, &L.hbuf, &L.hnext, &L.out_be, &L.ntt_mid, &L.gather})
+                          &L.in_be, &L.scal, &L.coeffA, &L.coeffB, &L.qbuf, &L.hbuf, &L.hnext, &L.out_be, &L.ntt_mid, &L.gather,
+                          &L.comm_send, &L.comm_recv})
             b->release();
         for (hipEvent_t e : L.ev_pool) (void)hipEventDestroy(e);
         for (hipEvent_t e : {L.ev_sorted, L.ev_done, L.ev_coeffs, L.ev_ext, L.ev_acc, L.ev_verify})
@@ -1211,39 +1282,46 @@ static void copy_parallel(uint8_t* dst, const uint8_t* src, size_t bytes) {
 // reads [off, off + bytes) of `fd` into dst with up to four threads of pread(2): a setup file in the page cache arrives at
 // memory speed, and a file truncated or replaced under the load is a short read / errno here -- a status code -- where
 // a mapping would have raised SIGBUS in the miner process.  false: I/O error or end of file before `bytes`.
-static bool pread_full(int fd, uint8_t* dst, size_t bytes, off_t off) {
+// 0: all of it arrived; > 0: the errno of the failing pread (each reader thread has its OWN errno: the value travels in
+// the return code, never through the caller's thread-local); -1: end of file before `bytes` (the file shrank).
+static int pread_full(int fd, uint8_t* dst, size_t bytes, off_t off) {
     while (bytes) {
         const ssize_t r = pread(fd, dst, bytes, off);
         if (r < 0 && errno == EINTR) continue;
-        if (r <= 0) return false;
+        if (r < 0) return errno ? errno : EIO;
+        if (r == 0) return -1;
         dst += r;
         off += r;
         bytes -= (size_t)r;
     }
-    return true;
+    return 0;
 }
-static bool read_parallel(int fd, uint8_t* dst, size_t bytes, off_t off) {
+static int read_parallel(int fd, uint8_t* dst, size_t bytes, off_t off) {   // same codes as pread_full: the first failure
     const size_t min_piece = (size_t)4 << 20;
     const unsigned parts = (unsigned)std::min<size_t>(4, std::max<size_t>(1, bytes / min_piece));
     if (parts <= 1) return pread_full(fd, dst, bytes, off);
     const size_t piece = ((bytes / parts) + 4095) & ~(size_t)4095;
-    std::atomic<bool> ok{true};
+    std::atomic<int> err{0};
+    auto note = [&err](int rc) {
+        int none = 0;
+        if (rc) err.compare_exchange_strong(none, rc);
+    };
     std::vector<std::thread> th;
     unsigned started = 1;
     try {
         for (unsigned t = 1; t < parts && (size_t)t * piece < bytes; t++, started++) {
             const size_t o = (size_t)t * piece, len = std::min(piece, bytes - o);
-            th.emplace_back([=, &ok] { if (!pread_full(fd, dst + o, len, off + (off_t)o)) ok = false; });
+            th.emplace_back([=, &note] { note(pread_full(fd, dst + o, len, off + (off_t)o)); });
         }
     } catch (const std::system_error&) {   // no thread to be had: the caller reads the rest itself
     }
-    if (!pread_full(fd, dst, std::min(piece, bytes), off)) ok = false;
+    note(pread_full(fd, dst, std::min(piece, bytes), off));
     for (unsigned t = started; t < parts && (size_t)t * piece < bytes; t++) {
         const size_t o = (size_t)t * piece;
-        if (!pread_full(fd, dst + o, std::min(piece, bytes - o), off + (off_t)o)) ok = false;
+        note(pread_full(fd, dst + o, std::min(piece, bytes - o), off + (off_t)o));
     }
     for (auto& t : th) t.join();
-    return ok;
+    return err.load();
 }
 // The points of a setup file / caller buffer -> a NEW window-0 table, tile by tile through two pinned staging buffers: the
 // host fills buffer b (pread from the setup file, or a copy of the caller's memory) while the GPU still copies and decodes buffer 1 - b;
@@ -1308,11 +1386,10 @@ static int load_srs_common(kzg_ctx* ctx, const uint8_t* data, int fd, uint64_t n
         }
         const auto c0 = clk::now();
         if (data) copy_parallel(pin.p[b], data + rec * first, cnt * rec);
-        else if (!read_parallel(fd, pin.p[b], cnt * rec, (off_t)(rec * first))) {
-            const int e = errno;
+        else if (const int e = read_parallel(fd, pin.p[b], cnt * rec, (off_t)(rec * first))) {
             (void)hipStreamSynchronize(L.stream);     // copies of the other buffer may still be in flight
-            return fail(ctx, KZG_E_ARG, std::string("setup file: read failed or the file shrank during the load") +
-                                            (e ? std::string(" (") + strerror(e) + ")" : std::string()));
+            return fail(ctx, KZG_E_ARG, e < 0 ? std::string("setup file: the file shrank during the load (end of file before the last point)")
+                                              : std::string("setup file: read failed (") + strerror(e) + ")");
         }
         host_copy_s += std::chrono::duration<double>(clk::now() - c0).count();
         err = hipMemcpyAsync(dev_in[b].p, pin.p[b], cnt * rec, hipMemcpyHostToDevice, L.stream);
@@ -1631,43 +1708,9 @@ static int commit_open_host(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, u
 // behaves exactly like the untagged call and leaves its own coefficients behind.  The tag (zkp_subnet_amd/csrc/wire_py.c:
 // a keyed multiply-fold over the decoded bytes, fast but with no cryptographic analysis) is a HINT, not a proof of
 // identity: every hit is verified bit for bit on the GPU against the row the slot was filled from.
-static int rcache_lookup(kzg_ctx* ctx, const uint8_t tag[16], uint64_t T, int ef) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    for (int k = 0; k < N_LANES; k++) {
-        auto& e = ctx->rcache[k];
-        if (e.valid && !e.busy && e.T == T && e.eval_form == ef && !memcmp(e.tag, tag, 16)) {
-            e.busy = true;
-            e.stamp = ++ctx->rc_clock;
-            ctx->rc_hits++;
-            return k;
-        }
-    }
-    ctx->rc_misses++;
-    int lru = -1;             // a slot to fill: an empty one, else the least recently used of those nobody is using
-    for (int k = 0; k < N_LANES; k++) {
-        const auto& e = ctx->rcache[k];
-        if (e.busy) continue;
-        const uint64_t age_k = e.valid ? e.stamp : 0;
-        if (lru < 0 || age_k < (ctx->rcache[lru].valid ? ctx->rcache[lru].stamp : 0)) lru = k;
-    }
-    if (lru >= 0) {
-        ctx->rcache[lru].busy = true;
-        ctx->rcache[lru].valid = false;
-        return -2 - lru;      // a free slot to fill: index = -2 - result
-    }
-    return -1;                // every slot is in use by a concurrent request: no caching for this call
-}
+static int rcache_lookup(kzg_ctx* ctx, const uint8_t tag[16], uint64_t T, int ef) { return ctx->book.rcache_lookup(tag, T, ef); }
 static void rcache_release(kzg_ctx* ctx, int k, bool valid, const uint8_t tag[16], uint64_t T, int ef) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    auto& e = ctx->rcache[k];
-    e.busy = false;
-    e.valid = valid;
-    if (valid) {
-        memcpy(e.tag, tag, 16);
-        e.T = T;
-        e.eval_form = ef;
-        e.stamp = ++ctx->rc_clock;
-    }
+    ctx->book.rcache_release(k, valid, tag, T, ef);
 }
 static int commit_open_host_cached(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
                                    const uint8_t tag[16], const uint8_t* alpha, uint8_t* c48, uint8_t* e32, uint8_t* p48) {
@@ -1693,12 +1736,8 @@ static int commit_open_host_cached(kzg_ctx* ctx, uint32_t i, const uint8_t* row_
         const bool same = rc != KZG_OK || *reinterpret_cast<const volatile uint32_t*>(L.pin + TB_VERIFY) == 0;
         rcache_release(ctx, look, same, tag, T, evaluation_form);   // a slot whose tag collided is dropped
         if (same) return rc;
-        {   // equal tags, different rows: the answer just computed belongs to the OTHER row -- discard it, take the miss path
-            std::lock_guard<std::mutex> lk(ctx->mu);
-            ctx->rc_hits--;
-            ctx->rc_misses++;
-            ctx->rc_tag_collisions++;
-        }
+        ctx->book.rcache_collision();   // equal tags, different rows: the answer just computed belongs to the OTHER row --
+                                        // discard it, take the miss path
         H.clean = false;
         prof_begin(ctx, L);
         rc = clear_flags(ctx, L);
@@ -1735,9 +1774,10 @@ int kzg_open_cached(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t 
 }
 int kzg_row_cache_stats(kzg_ctx* ctx, uint64_t out_hits_misses[2]) {
     if (!ctx || !out_hits_misses) return KZG_E_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    out_hits_misses[0] = ctx->rc_hits;
-    out_hits_misses[1] = ctx->rc_misses;
+    uint64_t st[3];
+    ctx->book.rcache_stats(st);
+    out_hits_misses[0] = st[0];
+    out_hits_misses[1] = st[1];
     return KZG_OK;
 }
 int kzg_commit(kzg_ctx* ctx, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
@@ -1977,11 +2017,7 @@ int kzg_msm_sharded_finish(kzg_ctx* ctx, int ticket, const void* dev_partials_xy
                            void* producer_stream, uint8_t out48[48]) {
     if (!ctx || !out48 || !dev_partials_xyzz192 || !count || count > KZG_MAX_GATHER || ticket < 0 || ticket >= N_LANES) return KZG_E_ARG;
     Lane& L = ctx->lane[ticket];
-    {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        if (L.state != LANE_TICKET) return fail(ctx, KZG_E_ARG, "no outstanding MSM on this ticket (or it is already being waited for)");
-        L.state = LANE_WAITING;
-    }
+    if (int rc0 = ticket_claim(ctx, ticket)) return rc0;
     (void)hipSetDevice(ctx->device);
     int rc = KZG_OK;
     hipError_t e = hipEventRecord(L.ev_ext, reinterpret_cast<hipStream_t>(producer_stream));
@@ -2004,6 +2040,212 @@ int kzg_msm_sharded_finish(kzg_ctx* ctx, int ticket, const void* dev_partials_xy
     }
     lane_release(ctx, ticket);
     return rc;
+}
+
+// ---- the collective inside the library (include/kzg_mi355x.h "the collective INSIDE the library")
+int kzg_comm_unique_id(uint8_t out_id128[128]) {
+    if (!out_id128) return KZG_E_ARG;
+    std::string err;
+    const kzg_rccl::Api* r = kzg_rccl::api(&err);
+    if (!r) return fail(nullptr, KZG_E_COMM, err);
+    static_assert(sizeof(ncclUniqueId) == 128, "the ABI hands the unique id over as 128 bytes");
+    ncclUniqueId id;
+    const ncclResult_t e = r->GetUniqueId(&id);
+    if (e != ncclSuccess) return fail(nullptr, KZG_E_COMM, std::string("ncclGetUniqueId: ") + r->GetErrorString(e));
+    memcpy(out_id128, &id, 128);
+    return KZG_OK;
+}
+int kzg_comm_init(kzg_ctx* ctx, const uint8_t unique_id128[128], int rank, int world) {
+    if (!ctx || !unique_id128 || world < 1 || world > KZG_MAX_GATHER || rank < 0 || rank >= world) return KZG_E_ARG;
+    std::string err;
+    const kzg_rccl::Api* r = kzg_rccl::api(&err);
+    if (!r) return fail(ctx, KZG_E_COMM, err);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    LaneHold H(ctx);
+    if (int rc = H.take_all()) return rc;
+    std::lock_guard<std::mutex> lk(ctx->comm.mu);
+    if (ctx->comm.comm) return fail(ctx, KZG_E_ARG, "a communicator exists already: kzg_comm_destroy first");
+    // every buffer a sharded MSM needs beyond the plain MSM's, now: nothing is (re)allocated while collectives are in flight
+    for (Lane& L : ctx->lane) {
+        HIPCHK(ctx, L.comm_send.ensure(256));
+        HIPCHK(ctx, L.comm_recv.ensure((size_t)world * 192));
+        HIPCHK(ctx, L.gather.ensure(((size_t)world + 2) * sizeof(g1_xyzz_t)));
+    }
+    ncclUniqueId id;
+    memcpy(&id, unique_id128, 128);
+    ncclComm_t c = nullptr;
+    const ncclResult_t e = r->CommInitRank(&c, world, id, rank);      // collective: returns when every rank has joined
+    if (e != ncclSuccess || !c)
+        return fail(ctx, KZG_E_COMM, std::string("ncclCommInitRank(rank ") + std::to_string(rank) + " of " + std::to_string(world) +
+                                         "): " + r->GetErrorString(e));
+    ctx->comm.comm = c;
+    ctx->comm.rank = rank;
+    ctx->comm.world = world;
+    ctx->comm.broken = false;
+    ctx->comm.why.clear();
+    H.clean = true;
+    return KZG_OK;
+}
+int kzg_comm_destroy(kzg_ctx* ctx) {
+    if (!ctx) return KZG_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    LaneHold H(ctx);
+    if (int rc = H.take_all()) return rc;       // no sharded MSM is in flight while the communicator goes
+    comm_teardown(ctx);
+    H.clean = true;
+    return KZG_OK;
+}
+int kzg_comm_set_timeout(kzg_ctx* ctx, int timeout_ms) {
+    if (!ctx || timeout_ms < 0) return KZG_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->comm.mu);
+    ctx->comm.timeout_ms = timeout_ms;
+    return KZG_OK;
+}
+int kzg_comm_info(kzg_ctx* ctx, int32_t out[4]) {
+    if (!ctx || !out) return KZG_E_ARG;
+    std::string err;
+    const kzg_rccl::Api* r = kzg_rccl::api(&err);
+    std::lock_guard<std::mutex> lk(ctx->comm.mu);
+    out[0] = ctx->comm.rank;
+    out[1] = ctx->comm.comm || ctx->comm.broken ? ctx->comm.world : 0;
+    out[2] = r ? r->version : 0;
+    out[3] = ctx->comm.broken ? 1 : 0;
+    return KZG_OK;
+}
+// One small all_gather whose content is checked: rank i contributes 192 bytes of value (i + 1) & 0xff, every rank verifies
+// all `world` pieces.  What a caller runs right after kzg_comm_init -- before it builds tables and uploads scalars -- to
+// learn that the communicator really moves bytes between THESE ranks (ncclCommInitRank succeeding does not prove the
+// data path: transports connect at the first collective).  Honours kzg_comm_set_timeout like kzg_msm_sharded.
+int kzg_comm_selftest(kzg_ctx* ctx) {
+    if (!ctx) return KZG_E_ARG;
+    std::string err;
+    const kzg_rccl::Api* r = kzg_rccl::api(&err);
+    if (!r) return fail(ctx, KZG_E_COMM, err);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    LaneHold H(ctx);
+    if (int rc = H.take()) return rc;
+    Lane& L = H.L();
+    int world = 0, rank = 0, timeout_ms = 0;
+    {
+        std::lock_guard<std::mutex> lk(ctx->comm.mu);
+        if (ctx->comm.broken) return fail(ctx, KZG_E_COMM, "the communicator was aborted (" + ctx->comm.why + "): kzg_comm_destroy + kzg_comm_init");
+        if (!ctx->comm.comm) return fail(ctx, KZG_E_ARG, "no communicator: call kzg_comm_init");
+        world = ctx->comm.world;
+        rank = ctx->comm.rank;
+        timeout_ms = ctx->comm.timeout_ms;
+    }
+    std::vector<uint8_t> got((size_t)world * 192);
+    HIPCHK(ctx, hipMemsetAsync(L.comm_send.p, (rank + 1) & 0xff, 192, L.stream));
+    HIPCHK(ctx, hipMemsetAsync(L.comm_recv.p, 0, (size_t)world * 192, L.stream));
+    {
+        std::lock_guard<std::mutex> lk(ctx->comm.mu);
+        if (!ctx->comm.comm) return fail(ctx, KZG_E_COMM, "the communicator went away during the call");
+        const ncclResult_t e = r->AllGather(L.comm_send.p, L.comm_recv.p, 192, ncclUint8, ctx->comm.comm, L.stream);
+        if (e != ncclSuccess) {
+            ctx->comm.broken = true;
+            ctx->comm.why = std::string("ncclAllGather: ") + r->GetErrorString(e);
+            return fail(ctx, KZG_E_COMM, ctx->comm.why);
+        }
+    }
+    HIPCHK(ctx, hipEventRecord(L.ev_done, L.stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipEventQuery(L.ev_done);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) return fail(ctx, KZG_E_HIP, std::string("kzg_comm_selftest: ") + hipGetErrorString(e));
+        (void)hipGetLastError();
+        if (timeout_ms > 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms)) {
+            std::lock_guard<std::mutex> lk(ctx->comm.mu);
+            if (ctx->comm.comm) {
+                (void)r->CommAbort(ctx->comm.comm);
+                ctx->comm.comm = nullptr;
+            }
+            ctx->comm.broken = true;
+            ctx->comm.why = "the self-test all_gather timed out after " + std::to_string(timeout_ms) + " ms";
+            return fail(ctx, KZG_E_COMM, "kzg_comm_selftest: " + ctx->comm.why);
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+    HIPCHK(ctx, hipMemcpy(got.data(), L.comm_recv.p, got.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < world; i++)
+        for (int b = 0; b < 192; b++)
+            if (got[(size_t)i * 192 + b] != (uint8_t)((i + 1) & 0xff))
+                return fail(ctx, KZG_E_COMM, "kzg_comm_selftest: the piece of rank " + std::to_string(i) + " arrived damaged on rank " +
+                                                 std::to_string(rank));
+    H.clean = true;
+    return KZG_OK;
+}
+int kzg_test_comm_stall(kzg_ctx* ctx, int ms) {
+    if (!ctx || ms < 0 || ms > 2000) return KZG_E_ARG;
+    ctx->comm.stall_ms.store(ms);
+    return KZG_OK;
+}
+int kzg_msm_sharded(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint8_t out48[48]) {
+    if (!ctx || !out48 || slot < 0 || slot >= N_SLOTS) return KZG_E_ARG;
+    std::string err;
+    const kzg_rccl::Api* r = kzg_rccl::api(&err);
+    if (!r) return fail(ctx, KZG_E_COMM, err);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    LaneHold H(ctx);
+    if (int rc = H.take()) return rc;
+    Lane& L = H.L();
+    int rc = need_srs(ctx);
+    if (rc) return rc;
+    if (n > ctx->slot_n[slot]) return fail(ctx, KZG_E_ARG, "slot holds fewer scalars than requested");
+    int world = 0, timeout_ms = 0;
+    {
+        std::lock_guard<std::mutex> lk(ctx->comm.mu);
+        if (ctx->comm.broken) return fail(ctx, KZG_E_COMM, "the communicator was aborted (" + ctx->comm.why + "): kzg_comm_destroy + kzg_comm_init");
+        if (!ctx->comm.comm) return fail(ctx, KZG_E_ARG, "no communicator: call kzg_comm_init");
+        world = ctx->comm.world;
+        timeout_ms = ctx->comm.timeout_ms;
+    }
+    prof_begin(ctx, L);
+    rc = clear_flags(ctx, L);
+    if (rc) return rc;
+    rc = msm_core(ctx, L, ctx->slot[slot].as<uint32_t>(), ctx->slot_mont[slot], n, srs_offset, L.res());
+    if (rc) return rc;
+    {
+        Span sp(ctx, L, KZG_T_COLLECTIVE);
+        launch_xyzz_pack(L.stream, L.res(), L.comm_send.as<uint32_t>(), 1);
+        if (timeout_ms > 0) HIPCHK(ctx, hipEventRecord(L.ev_ext, L.stream));   // from here on the timeout's clock runs
+        if (const int ms = ctx->comm.stall_ms.exchange(0)) {      // test hook: a late "peer"
+            int khz = 0;
+            (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device);
+            k_test_stall<<<1, 64, 0, L.stream>>>((uint64_t)(khz > 0 ? khz : 100000) * (uint64_t)ms);
+        }
+        {
+            // enqueued on the LANE's stream, stream-ordered between the partial and the sum.  The lock only serialises the
+            // enqueue (RCCL: one thread at a time per communicator); the transfer itself overlaps other lanes' work.
+            std::lock_guard<std::mutex> lk(ctx->comm.mu);
+            if (!ctx->comm.comm) return fail(ctx, KZG_E_COMM, "the communicator went away during the call");
+            const ncclResult_t e = r->AllGather(L.comm_send.p, L.comm_recv.p, 192, ncclUint8, ctx->comm.comm, L.stream);
+            if (e != ncclSuccess) {
+                ctx->comm.broken = true;
+                ctx->comm.why = std::string("ncclAllGather: ") + r->GetErrorString(e);
+                return fail(ctx, KZG_E_COMM, ctx->comm.why);
+            }
+        }
+        g1_xyzz_t* pts = L.gather.as<g1_xyzz_t>();
+        launch_xyzz_unpack(L.stream, L.comm_recv.as<uint32_t>(), pts, (uint32_t)world);
+        launch_g1_sum(L.stream, pts, (uint32_t)world, L.res());
+    }
+    queue_encode(ctx, L, true, false);
+    bool timed_out = false;
+    rc = finish_bounded(ctx, L, timeout_ms, L.ev_ext, &timed_out);
+    if (timed_out) {
+        std::lock_guard<std::mutex> lk(ctx->comm.mu);
+        if (ctx->comm.comm) {
+            (void)r->CommAbort(ctx->comm.comm);      // the stuck collective leaves the stream; LaneHold then drains the lane
+            ctx->comm.comm = nullptr;
+        }
+        ctx->comm.broken = true;
+        ctx->comm.why = "a sharded MSM timed out after " + std::to_string(timeout_ms) + " ms";
+    }
+    if (rc) return rc;
+    result_c48(ctx, L, 0, out48);
+    H.clean = true;
+    return KZG_OK;
 }
 
 // ---- ticketed MSM: submit returns once the work is queued on a free lane, wait returns the result, so MSM i+1 (sort,
@@ -2050,12 +2292,7 @@ int kzg_msm_submit(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, int 
 int kzg_msm_wait(kzg_ctx* ctx, int ticket, uint8_t* out) {
     if (!ctx || !out || ticket < 0 || ticket >= N_LANES) return KZG_E_ARG;
     Lane& L = ctx->lane[ticket];
-    {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        // exactly one waiter per ticket: a second one would read the pinned result after the lane has been reused
-        if (L.state != LANE_TICKET) return fail(ctx, KZG_E_ARG, "no outstanding MSM on this ticket (or it is already being waited for)");
-        L.state = LANE_WAITING;
-    }
+    if (int rc0 = ticket_claim(ctx, ticket)) return rc0;   // exactly one waiter per ticket
     (void)hipSetDevice(ctx->device);
     hipError_t e = hipSuccess;  // not under the lock: other threads submit / run meanwhile
 #ifndef KZG_NO_POLL
@@ -2081,11 +2318,7 @@ int kzg_msm_wait(kzg_ctx* ctx, int ticket, uint8_t* out) {
 int kzg_msm_cancel(kzg_ctx* ctx, int ticket) {
     if (!ctx || ticket < 0 || ticket >= N_LANES) return KZG_E_ARG;
     Lane& L = ctx->lane[ticket];
-    {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        if (L.state != LANE_TICKET) return fail(ctx, KZG_E_ARG, "no outstanding MSM on this ticket (or it is already being waited for)");
-        L.state = LANE_WAITING;
-    }
+    if (int rc0 = ticket_claim(ctx, ticket)) return rc0;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(L.stream);
     (void)hipGetLastError();
@@ -2137,20 +2370,7 @@ int kzg_ntt_resident(kzg_ctx* ctx, int slot, uint64_t n, int inverse) {
 int kzg_staging_acquire(kzg_ctx* ctx, uint64_t bytes, void** out_ptr, int* out_token) {
     if (!ctx || !out_ptr || !out_token) return KZG_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    int k = -1;
-    {
-        std::unique_lock<std::mutex> lk(ctx->mu);
-        for (;;) {
-            // prefer a free buffer that is already large enough
-            for (int i = 0; i < N_STAGE && k < 0; i++)
-                if (!ctx->stage[i].used && ctx->stage[i].cap >= bytes) k = i;
-            for (int i = 0; i < N_STAGE && k < 0; i++)
-                if (!ctx->stage[i].used) k = i;
-            if (k >= 0) break;
-            ctx->cv.wait(lk);
-        }
-        ctx->stage[k].used = true;
-    }
+    const int k = ctx->book.stage_acquire(bytes);   // waits while all are held; prefers one that is already large enough
     Stage& st = ctx->stage[k];
     if (bytes > st.cap) {
         st.p_pub.store(nullptr, std::memory_order_release);
@@ -2161,16 +2381,15 @@ int kzg_staging_acquire(kzg_ctx* ctx, uint64_t bytes, void** out_ptr, int* out_t
         hipError_t e = hipHostMalloc(&st.p, want, hipHostMallocDefault);
         if (e != hipSuccess) {
             st.p = nullptr;
-            {
-                std::lock_guard<std::mutex> lk(ctx->mu);
-                st.used = false;
-            }
-            ctx->cv.notify_all();
+            ctx->book.stage_set_cap(k, 0);
+            (void)ctx->book.stage_release(k);
             return fail(ctx, KZG_E_NOMEM, std::string("hipHostMalloc(staging): ") + hipGetErrorString(e));
         }
         st.cap = want;
+        ctx->book.stage_set_cap(k, want);
     }
     st.flushed = 0;
+    st.consumed_by = 0;
     st.p_pub.store(st.p, std::memory_order_release);
     *out_ptr = st.p;
     *out_token = k;
@@ -2185,11 +2404,13 @@ int kzg_staging_flush(kzg_ctx* ctx, int token, uint64_t offset, uint64_t bytes) 
     if (!ctx || token < 0 || token >= N_STAGE) return KZG_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Stage& st = ctx->stage[token];
-    {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        if (!st.used) return fail(ctx, KZG_E_ARG, "staging buffer is not held");
+    if (!ctx->book.stage_held(token)) return fail(ctx, KZG_E_ARG, "staging buffer is not held");
+    if (st.consumed_by) {      // a compute call has been served from the twin: the flushes start over (one-shot, see flushed_twin)
+        st.consumed_by = 0;
+        st.flushed = 0;
     }
-    if (offset != st.flushed || offset + bytes > st.cap || (bytes & 31)) return fail(ctx, KZG_E_ARG, "staging flush: not the next contiguous piece");
+    if (offset != st.flushed || offset > st.cap || bytes > st.cap - offset || (bytes & 31))
+        return fail(ctx, KZG_E_ARG, "staging flush: not the next contiguous piece");
     if (!bytes) return KZG_OK;
     if (st.twin.cap < st.cap) {
         // the twin may still be read by nothing: the previous holder's compute call returned before it released the buffer
@@ -2204,13 +2425,10 @@ int kzg_staging_flush(kzg_ctx* ctx, int token, uint64_t offset, uint64_t bytes) 
 }
 int kzg_staging_release(kzg_ctx* ctx, int token) {
     if (!ctx || token < 0 || token >= N_STAGE) return KZG_E_ARG;
-    {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        if (!ctx->stage[token].used) return fail(ctx, KZG_E_ARG, "staging buffer is not held");
-        ctx->stage[token].flushed = 0;
-        ctx->stage[token].used = false;
-    }
-    ctx->cv.notify_all();
+    if (!ctx->book.stage_held(token)) return fail(ctx, KZG_E_ARG, "staging buffer is not held");
+    ctx->stage[token].flushed = 0;       // still the holder's: nobody else is handed this buffer before stage_release
+    ctx->stage[token].consumed_by = 0;
+    if (ctx->book.stage_release(token) != kzg_book::BOOK_OK) return fail(ctx, KZG_E_ARG, "staging buffer is not held");
     return KZG_OK;
 }
 
@@ -2218,6 +2436,7 @@ int kzg_set_profiling(kzg_ctx* ctx, int enable) {
     if (!ctx) return KZG_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->profiling = enable == 2 ? 2 : (enable != 0);
+    ctx->book.set_serial(ctx->profiling == 1);     // stage profiling pins every call to lane 0
     return KZG_OK;
 }
 int kzg_get_timings(kzg_ctx* ctx, float* out_ms, int count) {

@@ -38,6 +38,56 @@ def all_gather_partials(partial: bytes, group=None) -> List[bytes]:
     return [raw[i * PARTIAL_BYTES:(i + 1) * PARTIAL_BYTES] for i in range(world)]
 
 
+class LibraryGather:
+    """The multi-GPU step with the collective INSIDE the library (`kzg_comm_init` / `kzg_msm_sharded`): the 192-byte
+    partial, RCCL's all_gather and the sum run on the engine's own lane stream -- no torch tensor, no foreign stream, one
+    host wait.  torch.distributed (any backend) is only the rendezvous: rank 0 draws the RCCL unique id and the process
+    group's object broadcast carries its 128 bytes.  `DeviceGather` below is the torch-collective form kept as the A/B.
+
+    `init_timeout_s`: ncclCommInitRank blocks in native code until every rank has joined; it runs on a helper thread so
+    that a rank whose peers never arrive raises TimeoutError here instead of hanging for ever."""
+
+    def __init__(self, engine, group=None, timeout_ms: int = 0, init_timeout_s: float = 120.0):
+        import threading
+
+        import torch.distributed as dist
+
+        self.engine = engine
+        self.world = dist.get_world_size(group)
+        rank = dist.get_rank(group)
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = engine.comm_unique_id()
+            except Exception as e:               # noqa: BLE001 -- every rank must learn of it, or they wait for the id
+                box[0] = e
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if isinstance(box[0], Exception):
+            raise box[0]
+        err = []
+
+        def join():
+            try:
+                engine.comm_init(box[0], rank, self.world, timeout_ms)
+            except Exception as e:               # noqa: BLE001
+                err.append(e)
+
+        t = threading.Thread(target=join, name="kzg-comm-init", daemon=True)
+        t.start()
+        t.join(init_timeout_s)
+        if t.is_alive():
+            raise TimeoutError(f"kzg_comm_init: the {self.world} ranks did not all join within {init_timeout_s:.0f} s")
+        if err:
+            raise err[0]
+        self.info = engine.comm_info()
+
+    def msm(self, slot: int, n: int, srs_offset: int = 0) -> bytes:
+        return self.engine.msm_sharded(slot, n, srs_offset)
+
+    def close(self) -> None:
+        self.engine.comm_destroy()
+
+
 class DeviceGather:
     """The collective step with no host round trip for the partials: the engine writes its 192-byte partial into a
     torch device tensor, RCCL all_gathers device-to-device, the engine sums the gathered tensor on the GPU.  Tensors are

@@ -204,15 +204,10 @@ class HipEngine:
                     # Tagged calls (the two-call route) decode in one shot: the tag -- hit or miss -- is only known at
                     # the end, a hit's upload is off the critical path anyway, and tiles cost the decode ~0.1 ms each
                     # (measured: profiles/r04_ab_streamed_upload.log).
-                    got, tag = 0, (bytes(16) if tagged else None)
+                    got, self.tag = 0, None
                     for first in range(0, self.n, tile):
-                        if tagged:
-                            k, tag = codec._wire.decode_fr_list_into_tagged(poly, ptr.value, cap, 0, first, tile, tag)
-                        else:
-                            k = codec._wire.decode_fr_list_into(poly, ptr.value, cap, 0, first, tile)
-                        got += k
+                        got += codec._wire.decode_fr_list_into(poly, ptr.value, cap, 0, first, tile)
                         eng._chk(eng._lib.kzg_staging_flush(eng._h, self.token, 32 * first, 32 * tile))
-                    self.tag = tag
                 elif tagged:   # one pass: base64 -> bytes in the pinned buffer + the 128-bit content tag of those bytes
                     got, self.tag = codec._wire.decode_fr_list_into_tagged(poly, ptr.value, cap)
                 else:        # fused / one-shot calls have no use for the tag (it costs ~0.7 ns per element and thread)
@@ -360,6 +355,51 @@ class HipEngine:
         out = ctypes.create_string_buffer(48)
         self._chk(self._lib.kzg_msm_sharded_finish(self._h, ticket, ctypes.c_void_p(dev_ptr), count,
                                                    ctypes.c_void_p(producer_stream), out))
+        return out.raw
+
+    # ------------------------------------------------------------------ the library's own collective (kzg_comm_*)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """ncclGetUniqueId through the library: ONE rank calls it and hands the 128 bytes to the others (rendezvous is the
+        caller's: a store, a file, a socket)."""
+        lib = _native.load()
+        out = ctypes.create_string_buffer(128)
+        rc = lib.kzg_comm_unique_id(out)
+        if rc != 0:
+            raise KzgError(rc, lib.kzg_last_error(None).decode(errors="replace"))
+        return out.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int, timeout_ms: int = 0) -> None:
+        """Joins the `world`-rank RCCL communicator on this context's GPU (collective: returns when every rank has joined)."""
+        if len(unique_id) != 128:
+            raise ValueError("the RCCL unique id is 128 bytes")
+        self._chk(self._lib.kzg_comm_init(self._h, unique_id, rank, world))
+        if timeout_ms:
+            self._chk(self._lib.kzg_comm_set_timeout(self._h, timeout_ms))
+
+    def comm_set_timeout(self, timeout_ms: int) -> None:
+        self._chk(self._lib.kzg_comm_set_timeout(self._h, timeout_ms))
+
+    def comm_selftest(self) -> None:
+        """One small all_gather with checked content on the communicator (collective): raises KzgError(E_COMM) when the
+        ranks cannot actually exchange bytes."""
+        self._chk(self._lib.kzg_comm_selftest(self._h))
+
+    def comm_destroy(self) -> None:
+        self._chk(self._lib.kzg_comm_destroy(self._h))
+
+    def comm_info(self) -> Dict[str, int]:
+        arr = (ctypes.c_int32 * 4)()
+        self._chk(self._lib.kzg_comm_info(self._h, arr))
+        v = int(arr[2])
+        return {"rank": arr[0], "world": arr[1], "rccl_version_code": v, "broken": bool(arr[3]),
+                "rccl_version": f"{v // 10000}.{v // 100 % 100}.{v % 100}" if v else None}
+
+    def msm_sharded(self, slot: int, n: int, srs_offset: int = 0) -> bytes:
+        """This rank's SRS segment -> partial -> ncclAllGather on the lane's own stream -> sum: 48 bytes, the same on
+        every rank.  One host wait; nothing but the library between the partial and the sum."""
+        out = ctypes.create_string_buffer(48)
+        self._chk(self._lib.kzg_msm_sharded(self._h, slot, n, srs_offset, out))
         return out.raw
 
     def commit_open_resident(self, i: int, slot: int, T: int, alpha_be32: bytes,

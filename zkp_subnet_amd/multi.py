@@ -108,8 +108,27 @@ class MultiDeviceClient:
         return self._for(i).worker_verify(i, proof, alpha, eval, commitment)      # host-side pairing: any would do
 
     def worker_verify_batch(self, indices, proofs, alpha, evals, commitments, threads: int = 16):
-        return (self.clients[0] if self.clients else _NOT_STARTED).worker_verify_batch(indices, proofs, alpha, evals,
-                                                                                       commitments, threads)
+        """One batched check PER DEVICE, verdicts AND-ed: with a synthetic setup each context holds the slices and
+        verifier-key factors of its own workers only (i mod G == g), so row k goes to the client that serves indices[k].
+        Any non-200 answer of a group is returned as it is (the caller then falls back to row-by-row checks)."""
+        if not self.clients:
+            return _NOT_STARTED.worker_verify_batch(indices, proofs, alpha, evals, commitments, threads)
+        if not (len(indices) == len(proofs) == len(evals) == len(commitments)):
+            return Response(400, {"error": "worker_verify_batch: ragged input"})
+        G = len(self.clients)
+        groups = {}
+        for k, i in enumerate(indices):
+            groups.setdefault(int(i) % G, []).append(k)
+        valid = True
+        for g, ks in sorted(groups.items()):
+            r = self.clients[g].worker_verify_batch([indices[k] for k in ks], [proofs[k] for k in ks], alpha,
+                                                    [evals[k] for k in ks], [commitments[k] for k in ks], threads)
+            if r.status_code != 200:
+                return r
+            valid = valid and r.json().get("valid") is True
+            if not valid:
+                break
+        return Response(200, {"valid": valid})
 
     def fft(self, poly: Sequence[str], left: bool = True, inverse: bool = False):
         return self._any().fft(poly, left, inverse)
@@ -134,7 +153,7 @@ class MultiDeviceClient:
         return self._any().random_point()
 
     def aggregate_commitments(self, commitments: Sequence[str]):
-        return (self.clients[0] if self.clients else _NOT_STARTED).aggregate_commitments(commitments)
+        return self._any().aggregate_commitments(commitments)     # a sum of points: no slice involved, any device
 
 
 _NOT_STARTED = Client(engine=None)      # engine None -> every call answers 503 "prover not started", as Client does

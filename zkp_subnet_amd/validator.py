@@ -44,31 +44,40 @@ def generate_challenge(client, machines_count: int) -> Challenge:  # reference n
     return Challenge(polys=poly, alpha=alpha, evals=evals)
 
 
-def verify_all(client, challenge: Challenge, responses: Sequence[Optional[Prove]], threads: int = 16) -> List[bool]:
-    """worker_verify for every row of a step (reference neurons/validator.py:168-170 verifies inside reward(), one row
-    at a time: 256 pairing checks of ~4-7 ms each at mainnet scale).  First ONE batched check of all answered rows (they
-    share alpha; `Client.worker_verify_batch`: a random linear combination, two Miller loops in total); if that passes
-    every answered row is valid.  Otherwise -- or with a client that has no batch verifier -- the independent host-side
-    checks run row by row on a thread pool (ctypes releases the GIL) to tell the valid rows from the invalid ones."""
+def verify_rows(client, challenge: Challenge, indices: Sequence[int], responses: Sequence[Optional[Prove]],
+                threads: int = 16) -> List[bool]:
+    """One verdict PER RESPONSE: response k is checked as worker row `indices[k]` against the challenge's alpha and
+    `challenge.evals[indices[k]]` with ITS OWN proof and commitment (reference neurons/validator.py:160-170).  Two
+    responses may name the same worker index -- each still gets its own verdict (they are separate rows of the batched
+    check and separate row-by-row checks), so a corrupt answer can neither borrow an honest one's validity nor take
+    it away.  An index without a challenge eval, or a response with missing fields, is False without a pairing.
+
+    First ONE batched check of all checkable rows (they share alpha; `Client.worker_verify_batch`: a random linear
+    combination, two Miller loops in total); if that passes every such row is valid.  Otherwise -- or with a client
+    that has no batch verifier -- the independent host-side checks run row by row on a thread pool (ctypes releases the
+    GIL) to tell the valid rows from the invalid ones."""
     from concurrent.futures import ThreadPoolExecutor
 
     n = len(responses)
-    answered = [i for i in range(n) if responses[i] is not None and responses[i].commitment is not None
-                and responses[i].proof is not None]
+    if len(indices) != n:
+        raise ValueError("one worker index per response")
+    n_rows = len(challenge.evals)
+    answered = [k for k in range(n) if responses[k] is not None and responses[k].commitment is not None
+                and responses[k].proof is not None and 0 <= int(indices[k]) < n_rows]
     batch = getattr(client, "worker_verify_batch", None)
     if batch is not None and len(answered) > 1:
-        with batch(answered, [responses[i].proof for i in answered], challenge.alpha,
-                   [challenge.evals[i] for i in answered], [responses[i].commitment for i in answered], threads) as r:
+        with batch([int(indices[k]) for k in answered], [responses[k].proof for k in answered], challenge.alpha,
+                   [challenge.evals[int(indices[k])] for k in answered], [responses[k].commitment for k in answered],
+                   threads) as r:
             if r.status_code == 200 and r.json().get("valid") is True:
                 ok = set(answered)
-                return [i in ok for i in range(n)]
+                return [k in ok for k in range(n)]
 
-    def one(i):
-        r = responses[i]
-        if r is None or r.commitment is None or r.proof is None:
-            return False
+    def one(k):
+        r = responses[k]
         # 400 = the MINER's bytes are unusable (not base64, wrong length, off-curve / non-canonical): an invalid row, never
         # a reason to lose the other rows.  Only a failing verifier (5xx / 501 / 503) raises, as in the reference.
+        i = int(indices[k])
         with client.worker_verify(i, r.proof, challenge.alpha, challenge.evals[i], r.commitment) as resp:
             if resp.status_code == 400:
                 return False
@@ -76,10 +85,22 @@ def verify_all(client, challenge: Challenge, responses: Sequence[Optional[Prove]
                 raise Exception("Failed to verify the proof.")
             return bool(resp.json().get("valid"))
 
-    if n <= 1 or threads <= 1:
-        return [one(i) for i in range(n)]
-    with ThreadPoolExecutor(max_workers=min(threads, n)) as ex:
-        return list(ex.map(one, range(n)))
+    verdict = [False] * n
+    if len(answered) <= 1 or threads <= 1:
+        for k in answered:
+            verdict[k] = one(k)
+        return verdict
+    with ThreadPoolExecutor(max_workers=min(threads, len(answered))) as ex:
+        for k, v in zip(answered, ex.map(one, answered)):
+            verdict[k] = v
+    return verdict
+
+
+def verify_all(client, challenge: Challenge, responses: Sequence[Optional[Prove]], threads: int = 16) -> List[bool]:
+    """worker_verify for every row of a step laid out BY WORKER INDEX (responses[i] answers row i; reference
+    neurons/validator.py:168-170 verifies inside reward(), one row at a time: 256 pairing checks of ~4-7 ms each at
+    mainnet scale).  `verify_rows` with indices 0..n-1."""
+    return verify_rows(client, challenge, range(len(responses)), responses, threads)
 
 
 def reward(client, challenge: Challenge, response: Optional[Prove], index: int, process_time: Optional[float],
@@ -100,7 +121,7 @@ def get_rewards(client, challenge: Challenge, responses: Sequence[Optional[Prove
     """reference neurons/validator.py:178-192: one reward per response, as a float32 array -- `reward()` row by row.
     The reference reads the latency from `response.dendrite.process_time` (bittensor; not part of the wire type), here it
     comes as `process_times[k]`; the worker index of response k is `responses[k].index`, as in the reference.  Rows that
-    can be scored without a pairing (missing fields, too late) are; all the others are verified TOGETHER (`verify_all`:
+    can be scored without a pairing (missing fields, too late) are; all the others are verified TOGETHER (`verify_rows`:
     one batched check for a step whose rows share alpha, row by row only to name culprits)."""
     import numpy as np
 
@@ -114,16 +135,14 @@ def get_rewards(client, challenge: Challenge, responses: Sequence[Optional[Prove
             continue                                # incomplete proof: 0.0 (reference :146-148)
         if t is None or t > timeout:
             continue                                # too slow: not even verified (:152-154)
-        if not 0 <= r.index < len(challenge.polys):
-            continue                                # an index the challenge never issued cannot be verified: 0.0
+        if not 0 <= r.index < len(challenge.evals):
+            continue                                # an index the challenge holds no eval for cannot be verified: 0.0
         todo.append(k)
     if todo:
-        # verify_all indexes its rows by position: hand it a list laid out by WORKER index
-        by_index: List[Optional[Prove]] = [None] * len(challenge.polys)
-        for k in todo:
-            by_index[responses[k].index] = responses[k]
-        ok = verify_all(client, challenge, by_index, threads)
-        for k in todo:
-            if ok[responses[k].index]:
+        # one verdict per RESPONSE (its own proof and commitment against challenge[response.index]), never per index:
+        # two responses echoing one index do not share a verdict (reference neurons/validator.py:160-170)
+        ok = verify_rows(client, challenge, [responses[k].index for k in todo], [responses[k] for k in todo], threads)
+        for k, good in zip(todo, ok):
+            if good:
                 scores[k] = 1.0 - process_times[k] / timeout
     return np.array(scores, dtype=np.float32)
