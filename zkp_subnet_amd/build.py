@@ -58,12 +58,17 @@ def build_wire(force: bool = False) -> str:
 def build(force: bool = False, extra_flags=()) -> str:
     """The shipped library.  Objects are rebuilt when a source, a header OR the flag set changes (the flags of the last
     build are kept in build/flags.stamp).  KZG_WITH_PROTO=1 builds the dev prototypes into their OWN directory and
-    library (build_proto/, libkzg_mi355x_proto.so; load it with KZG_MI355X_LIB=...): it never touches the shipped one."""
+    library (build_proto/, libkzg_mi355x_proto.so; load it with KZG_MI355X_LIB=...): it never touches the shipped one;
+    KZG_BUILD_TAG=<tag> likewise builds the tree with KZG_EXTRA_HIPCC_FLAGS into build_<tag>/ and ab/<tag>.so."""
     build_wire(force)
     hipcc = _hipcc()
     extra_flags = tuple(extra_flags) + tuple(os.environ.get("KZG_EXTRA_HIPCC_FLAGS", "").split())
     sources = list(SOURCES)
     obj_dir, lib = OBJ, LIB
+    tag = os.environ.get("KZG_BUILD_TAG")
+    if tag:   # an A/B or timing build (KZG_EXTRA_HIPCC_FLAGS=-D...): its own objects and zkp_subnet_amd/ab/<tag>.so, loaded
+        obj_dir, lib = os.path.join(HERE, "build_" + tag), os.path.join(HERE, "ab", tag + ".so")   # with KZG_MI355X_LIB=...
+        os.makedirs(os.path.dirname(lib), exist_ok=True)
     if os.environ.get("KZG_WITH_PROTO") == "1":
         sources += PROTO_SOURCES
         extra_flags += ("-DKZG_WITH_PROTO",)

@@ -651,10 +651,18 @@ __global__ void __launch_bounds__(256, KZG_ACC_MIN_WAVES) k_msm_accumulate(const
     uint32_t my_carry_key = NONE_KEY;
     g1_xyzz_t acc;
     g1_set_inf(acc);
+    // KZG_EXP_L2_RESIDENT (a TIMING build, scripts/exp_traffic_clock.py; results are garbage): every row index is masked to
+    // the first 2^14 points of window table 0 -- 2 MB, resident in L2 / Infinity Cache -- so that the kernel runs the same
+    // instruction stream without its 2.2 GB of gathered HBM traffic: does that traffic cost clock or time?
+#ifdef KZG_EXP_L2_RESIDENT
+#define KZG_ROW_INDEX(v) ((v) & 0x3fffu)
+#else
+#define KZG_ROW_INDEX(v) ((v) & 0x7fffffffu)
+#endif
     uint32_t v_cur = sorted[lo];
     uint32_t w_cur[28];
     {
-        const uint4* q = reinterpret_cast<const uint4*>(table + (v_cur & 0x7fffffffu));
+        const uint4* q = reinterpret_cast<const uint4*>(table + KZG_ROW_INDEX(v_cur));
 #pragma unroll
         for (int i = 0; i < 7; i++) { uint4 t4 = q[i]; w_cur[4*i]=t4.x; w_cur[4*i+1]=t4.y; w_cur[4*i+2]=t4.z; w_cur[4*i+3]=t4.w; }
     }
@@ -685,7 +693,7 @@ __global__ void __launch_bounds__(256, KZG_ACC_MIN_WAVES) k_msm_accumulate(const
         uint32_t wn[28];
         const uint32_t vn = (e + 1 < hi) ? sorted[e + 1] : v_cur;
         {
-            const uint4* q = reinterpret_cast<const uint4*>(table + (vn & 0x7fffffffu));
+            const uint4* q = reinterpret_cast<const uint4*>(table + KZG_ROW_INDEX(vn));
 #pragma unroll
             for (int i = 0; i < 7; i++) { uint4 t4 = q[i]; wn[4*i]=t4.x; wn[4*i+1]=t4.y; wn[4*i+2]=t4.z; wn[4*i+3]=t4.w; }
         }
