@@ -946,13 +946,11 @@ def main():
     pipelined = None
     if is_msm and depth == 1 and not args.no_pipelined:
         state["depth"], state["gather"] = 2, None
-        # >= 80 ms of the same load first (and at least W steps): the clocks need ~40 ms, and this region used to be the
-        # cold one of the run; the count is reported as `pre_warm_steps`
-        t_w = time.perf_counter()
-        pipe_warm = 0
-        while pipe_warm < args.warmup or time.perf_counter() - t_w < 0.08:
-            run_steps(2, False)
-            pipe_warm += 2
+        # >= 32 steps of the same load first (>= 80 ms at 2^20): the clocks need ~40 ms, and this region used to be the cold
+        # one of the run.  A COUNT, never a duration: with N > 1 every step holds a collective, so all
+        # ranks must run the same number of them.  Reported as `pre_warm_steps`.
+        pipe_warm = max(args.warmup, 32)
+        run_steps(pipe_warm, False)
         barrier()
         tp = time.perf_counter()
         run_steps(args.steps, False)

@@ -5,6 +5,8 @@ cost the kernel CLOCK (socket power cap) or TIME?  One experiment, same box, sam
   l2      a TIMING build (-DKZG_EXP_L2_RESIDENT, zkp_subnet_amd/ab/L2.so): every row index is masked to the first 2^14
           points of window table 0 (2 MB: resident in L2 / Infinity Cache) -- same instruction stream, same mads, same
           sorted-index reads and bucket stores, ~no HBM gather; the results are garbage and are not looked at
+  l2q     -DKZG_EXP_L2_RESIDENT=25 (ab/L2q.so): only every fourth row is redirected -- a quarter of the gather gone, what a
+          denser row (2 x 48 B packed into 96 B) could save at best, priced BEFORE paying for its unpacking
 
 For each: ~3 s of back-to-back 2^20 MSMs with HIP events around the accumulate kernel only (profiling level 2), the socket
 power sampled from sysfs every 50 ms meanwhile (when the container exposes it), then kzg_calibrate (s_memtime ticks per ns
@@ -23,8 +25,23 @@ sys.path.insert(0, ROOT)
 
 
 def power_nodes():
-    return sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") +
-                  glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))
+    """The power sensor of THE GPU THIS PROCESS USES (the box's sysfs shows all eight cards of the host): matched by the PCI
+    address HIP reports for device 0; every card's node if that cannot be resolved (then only the MAX is meaningful)."""
+    nodes = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") +
+                   glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))
+    try:
+        import ctypes
+
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, 0) == 0:
+            bdf = buf.value.decode().lower()
+            mine = [p for p in nodes if bdf in os.path.realpath(os.path.join(os.path.dirname(p), "..", "..")).lower()]
+            if mine:
+                return mine
+    except OSError:
+        pass
+    return nodes
 
 
 def read_power(nodes):
@@ -91,7 +108,9 @@ if __name__ == "__main__":
     if not os.path.exists(l2):
         sys.exit("build the timing library first: KZG_BUILD_TAG=L2 KZG_EXTRA_HIPCC_FLAGS=-DKZG_EXP_L2_RESIDENT python -m zkp_subnet_amd.build")
     for rnd in range(3):                      # interleaved: a drifting box shows up as drift in BOTH columns
-        for tag, lib in (("real", None), ("l2", l2)):
+        for tag, lib in (("real", None), ("l2", l2), ("l2q", os.path.join(ROOT, "zkp_subnet_amd", "ab", "L2q.so"))):
+            if lib and not os.path.exists(lib):
+                continue
             env = dict(os.environ)
             env.pop("KZG_MI355X_LIB", None)
             if lib:

@@ -17,15 +17,20 @@ from zkp_subnet_amd import HipEngine, codec  # noqa: E402
 
 
 
-def run(budget=60.0, seed=None, rounds=None, max_log=20):
+def run(budget=60.0, seed=None, rounds=None, max_log=20, with_comm=False):
     """Fuzz for `budget` seconds, or -- with `rounds` -- for exactly that many engine rounds (a fixed seed then gives the
-    same cases on every box); any mismatch raises AssertionError naming the case.  Returns the case counts by kind."""
+    same cases on every box); any mismatch raises AssertionError naming the case.  Returns the case counts by kind.
+    `with_comm` (the long builder-side runs): every fourth round also drives the library's own collective on a one-rank
+    communicator (kzg_comm_init / kzg_msm_sharded) against the same oracle answers.  A progress line goes out every two
+    minutes, so that a run cut short by its lease still says how far it got (round 4's hour-long run left only its seed)."""
     seed = int(time.time()) if seed is None else seed
     rnd = random.Random(seed)
     print("seed", seed, flush=True)
     oc.build()
-    t_end = time.time() + budget
-    stats = {"rounds": 0, "msm": 0, "ntt": 0, "kzg": 0, "cache_hits": 0, "cache_misses_after_mutation": 0}
+    t_start = time.time()
+    t_end = t_start + budget
+    t_note = t_start + 120.0
+    stats = {"rounds": 0, "msm": 0, "ntt": 0, "kzg": 0, "cache_hits": 0, "cache_misses_after_mutation": 0, "sharded": 0}
 
     def scalars(n, kind):
         if kind == "uniform":
@@ -61,6 +66,10 @@ def run(budget=60.0, seed=None, rounds=None, max_log=20):
         T = 1 << (lg - ms)
         srs = oc.srs_gen(tx.to_bytes(32, "big"), ty.to_bytes(32, "big"), lg, ms, i)
         assert eng.srs_read(0, T) == srs, ("srs", lg, ms, i)
+        comm = with_comm and stats["rounds"] % 4 == 0
+        if comm:
+            eng.comm_init(HipEngine.comm_unique_id(), 0, 1, timeout_ms=60000)
+            eng.comm_selftest()
         for _ in range(3):
             n = rnd.choice((T, T, rnd.randrange(1, T + 1)))
             off = rnd.randrange(0, T - n + 1)
@@ -72,6 +81,9 @@ def run(budget=60.0, seed=None, rounds=None, max_log=20):
             assert eng.msm_resident(1, n, off) == want
             t1, t2 = eng.msm_submit(1, n, off), eng.msm_submit(1, n, off, partial=True)
             assert eng.msm_wait(t1) == want and eng.g1_sum(eng.msm_wait(t2)) == want, ("ticket", lg, window, n)
+            if comm:
+                assert eng.msm_sharded(1, n, off) == want, ("sharded", lg, ms, window, n, off, kind)
+                stats["sharded"] += 1
             stats["msm"] += 1
         # ---- NTT
         row = scalars(T, "uniform")
@@ -124,9 +136,12 @@ def run(budget=60.0, seed=None, rounds=None, max_log=20):
                 assert eng.ntt_eval(row, inv, alpha) == oc.fr_eval(oc.fr_ntt(row, inv), alpha), ("ntt_eval", lg - ms, inv)
         eng.close()
         stats["rounds"] += 1
+        if time.time() > t_note:
+            print(f"progress after {time.time() - t_start:.0f} s:", stats, flush=True)
+            t_note = time.time() + 120.0
     print("fuzz ok", stats, flush=True)
     return stats
 
 
 if __name__ == "__main__":
-    run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else None)
+    run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else None, with_comm=True)

@@ -654,7 +654,9 @@ __global__ void __launch_bounds__(256, KZG_ACC_MIN_WAVES) k_msm_accumulate(const
     // KZG_EXP_L2_RESIDENT (a TIMING build, scripts/exp_traffic_clock.py; results are garbage): every row index is masked to
     // the first 2^14 points of window table 0 -- 2 MB, resident in L2 / Infinity Cache -- so that the kernel runs the same
     // instruction stream without its 2.2 GB of gathered HBM traffic: does that traffic cost clock or time?
-#ifdef KZG_EXP_L2_RESIDENT
+#if defined(KZG_EXP_L2_RESIDENT) && KZG_EXP_L2_RESIDENT == 25
+#define KZG_ROW_INDEX(v) ((((v) & 3u) == 0u) ? ((v) & 0x3fffu) : ((v) & 0x7fffffffu))   // every fourth row only: -25 % of the gather
+#elif defined(KZG_EXP_L2_RESIDENT)
 #define KZG_ROW_INDEX(v) ((v) & 0x3fffu)
 #else
 #define KZG_ROW_INDEX(v) ((v) & 0x7fffffffu)
