@@ -272,7 +272,8 @@ class Ctl:
     def barrier(self):
         if self.active:
             self.dist.barrier()
-        self.torch.cuda.synchronize()
+        if self.torch.cuda.is_available():      # (always, in a measurement; the CPU tests of this class have no device)
+            self.torch.cuda.synchronize()
 
     def max_over_ranks(self, x):
         if not self.active:

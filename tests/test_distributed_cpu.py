@@ -75,3 +75,63 @@ def test_sharded_msm_gloo(world):
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(r, True) for r in range(world)], results
+
+
+def _ctl_worker(rank, world, port, q):
+    import datetime
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+
+    import bench
+
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        ctl = bench.Ctl(torch, dist, rank, world, True, 20)
+        out = {"store": ctl.store is not None}
+        ctl.barrier()
+        out["max"] = ctl.max_over_ranks(float(rank + 1))
+        out["gather"] = [b.hex() for b in ctl.gather_bytes(bytes([rank]) * 4)]
+        out["all_ok"] = ctl.agree("p1", True)
+        out["one_bad"] = ctl.agree("p2", rank != 1, "boom on 1" if rank == 1 else "")
+        # a rank that never reports counts as failed after the timeout -- nobody waits for ever
+        ctl2 = bench.Ctl(torch, dist, rank, world, True, 2)
+        if rank == 0:
+            out["silent_peer"] = ctl2.agree("p3", True)
+        # the fault injector of the bench's tests
+        os.environ["BENCH_FAULT"] = "msm26_setup:1,comm_init:0"
+        hits = []
+        for phase in ("msm26_setup", "comm_init", "msm26_step"):
+            try:
+                bench.inject(phase, rank)
+            except bench.Fault:
+                hits.append(phase)
+        out["faults"] = hits
+        q.put((rank, out))
+        ctl.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_control_plane_status_travels_through_the_store_world2():
+    """bench.py's control plane (VERDICT r4 task 1b): collectives on a gloo group, phase STATUS through the rendezvous store --
+    a failure on one rank is seen by every rank without anybody entering a collective, and a rank that never reports is a
+    failure after the timeout, not a hang."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 300) + 350
+    procs = [ctx.Process(target=_ctl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in range(world):
+        o_ = got[r]
+        assert o_["store"] and o_["max"] == 2.0 and o_["gather"] == ["00000000", "01010101"]
+        assert o_["all_ok"] == (True, {}) and o_["one_bad"] == (False, {1: "boom on 1"})
+    ok, bad = got[0]["silent_peer"]
+    assert not ok and list(bad) == [1] and "no status within 2 s" in bad[1]
+    assert got[0]["faults"] == ["comm_init"] and got[1]["faults"] == ["msm26_setup"]
