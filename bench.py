@@ -803,6 +803,12 @@ def main():
         args.gpus = world
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this pool
+    if world > 1:
+        # ONE node by contract (the launch line is --nnodes=1, rendezvous on 127.0.0.1): the bootstrap sockets of RCCL and
+        # gloo go over loopback whatever other interfaces the container shows and whether or not its hostname resolves
+        # (data still moves over xGMI / P2P).  Respected if the caller has set them.
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     import datetime
 
     import torch

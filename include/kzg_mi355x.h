@@ -210,6 +210,37 @@ int kzg_comm_info(kzg_ctx* ctx, int32_t out[4]);
 int kzg_comm_selftest(kzg_ctx* ctx);
 int kzg_msm_sharded(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint8_t out48[48]);
 
+/* ---- several GPUs behind ONE handle (SURVEY 8b proposed kzg_create(device_count, device_ids)): a router over one context
+ *      per GPU -- worker index i is served by device_ids[i mod G].  This is the in-process form of the reference's only
+ *      distribution scheme: Pianist rows are independent, one row per miner (neurons/validator.py:194-222), one prover client
+ *      per process (base/miner.py:73-84).  No collective, nothing exchanged between the devices; thread-safe like a context.
+ *  kzg_multi_load_srs_file   every device loads the whole setup file (in parallel); worker i = slice i of its device
+ *  kzg_multi_gen_srs         synthetic SRS: s0_be32_all holds ALL 2^machines_scale slice factors; device g generates and
+ *                            holds only the slices of the worker indices it serves (i = g, g + G, ...)
+ *  kzg_multi_commit / _open / _commit_open        = kzg_commit / kzg_open / kzg_commit_open on the device of index i
+ *  kzg_multi_commit_open_rows   the rows of one challenge fanned out over the devices from host threads (up to four rows per
+ *                            device in flight); out_status[k] is row k's own status -- a bad row never costs the others
+ *  kzg_multi_ctx             the k-th per-GPU context: every other call of this header applies to it */
+typedef struct kzg_multi kzg_multi;
+int kzg_multi_create(int device_count, const int* device_ids, kzg_multi** out);
+void kzg_multi_destroy(kzg_multi* m);
+const char* kzg_multi_last_error(kzg_multi* m); /* last failure of the calling thread */
+int kzg_multi_count(kzg_multi* m);
+kzg_ctx* kzg_multi_ctx(kzg_multi* m, int k);
+int kzg_multi_device_of(kzg_multi* m, uint32_t i);
+int kzg_multi_load_srs_file(kzg_multi* m, const char* path, int compressed, int scale, int machines_scale);
+int kzg_multi_gen_srs(kzg_multi* m, const uint8_t tau_be32[32], const uint8_t* s0_be32_all, int scale, int machines_scale);
+int kzg_multi_commit(kzg_multi* m, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
+                     uint8_t out_commitment48[48]);
+int kzg_multi_open(kzg_multi* m, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
+                   const uint8_t alpha_be32[32], uint8_t out_eval32[32], uint8_t out_proof48[48]);
+int kzg_multi_commit_open(kzg_multi* m, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
+                          const uint8_t alpha_be32[32], uint8_t out_commitment48[48], uint8_t out_eval32[32],
+                          uint8_t out_proof48[48]);
+int kzg_multi_commit_open_rows(kzg_multi* m, uint32_t n_rows, const uint32_t* indices, const uint8_t* rows_be32, uint64_t T,
+                               int evaluation_form, const uint8_t alpha_be32[32], uint8_t* out_commitments48,
+                               uint8_t* out_evals32, uint8_t* out_proofs48, int* out_status);
+
 /* ---- device-resident inputs (what a serving loop and bench.py use: inputs already in HBM when timing starts).
  *      slot in [0, 4).  to_mont=1 stores Montgomery form (rows for commit/open), 0 canonical (MSM scalars). */
 int kzg_upload_fr(kzg_ctx* ctx, int slot, const uint8_t* be32, uint64_t n, int to_mont);

@@ -93,6 +93,23 @@ int main(int argc, char** argv) {
     rc = kzg_commit(ctx, 7, scal, n, 1, c48);
     printf("bad_worker_index %d\n", rc);
     kzg_destroy(ctx);
+    /* several GPUs behind one handle (here: the same GPU twice -- one context each): worker index i -> device i mod 2 */
+    {
+        const int devs[2] = {0, 0};
+        kzg_multi* m = NULL;
+        uint8_t s0[64] = {0}, mc[48];
+        s0[31] = 1;                                   /* two worker slices with factors 1 and 1: both equal the single slice */
+        s0[63] = 1;
+        if (kzg_multi_create(2, devs, &m) != KZG_OK || kzg_multi_gen_srs(m, tau, s0, lg + 1, 1) != KZG_OK ||
+            kzg_multi_commit(m, 1, scal, n, 1, mc) != KZG_OK) {
+            fprintf(stderr, "kzg_multi_*: %s\n", kzg_multi_last_error(m));
+            return 4;
+        }
+        printf("multi devices %d device_of_1 %d\n", kzg_multi_count(m), kzg_multi_device_of(m, 1));
+        hex("multi_commitment", mc, 48);
+        printf("multi_bad_index %d\n", kzg_multi_commit(m, 2, scal, n, 1, mc));
+        kzg_multi_destroy(m);
+    }
     free(scal);
     if (memcmp(msm_host, msm_res, 48) || memcmp(msm_host, msm_shard, 48)) return 5;
     return 0;

@@ -717,6 +717,64 @@ def test_c_abi_from_a_native_caller(hip, tmp_path):
     assert (got["eval"], got["proof"]) == (ev.hex(), pf.hex())
     assert got["comm"].startswith("rank 0 world 1 rccl 2") and got["comm"].endswith("broken 0")
     assert got["sharded_without_comm"] == "-1" and got["bad_worker_index"] == "-1" and "gfx950" in got["version"]
+    assert got["multi"] == "devices 2 device_of_1 0" and got["multi_commitment"] == got["commitment"] and got["multi_bad_index"] == "-1"
+
+
+def test_native_multi_device_handle_routes_rows_by_worker_index(hip):
+    """kzg_multi_* (SURVEY 8b's kzg_create(device_count, device_ids)): G contexts behind one handle, worker index i served by
+    context i mod G holding only the slices it serves (here G = 3 contexts on this box's one GPU, 8 worker rows).  Every
+    commit / open / commit+open equals the oracle's answer for THAT worker's slice; the rows of a challenge fan out with a
+    status per row -- a bad row (non-canonical scalar) costs only itself."""
+    import ctypes
+
+    from zkp_subnet_amd import _native
+    from zkp_subnet_amd.engine import lagrange_factor
+
+    lib = _native.load()
+    scale, ms = 13, 3
+    T, M, G = 1 << (scale - ms), 1 << ms, 3
+    tx, ty = 0xABCDEF0123, 0x13579BDF
+    devs = (ctypes.c_int * G)(0, 0, 0)
+    m = ctypes.c_void_p()
+    assert lib.kzg_multi_create(G, devs, ctypes.byref(m)) == 0
+    try:
+        assert lib.kzg_multi_count(m) == G and lib.kzg_multi_device_of(m, 5) == 0
+        out = ctypes.create_string_buffer(48)
+        assert lib.kzg_multi_commit(m, 0, bytes(32 * T), T, 1, out) == _native.KZG_E_ARG          # nothing resident yet
+        s0 = b"".join(lagrange_factor(i, ms, ty).to_bytes(32, "big") for i in range(M))
+        assert lib.kzg_multi_gen_srs(m, tx.to_bytes(32, "big"), s0, scale, ms) == 0
+        alpha = rand_scalars_bytes(1, 9100)
+        rows = [rand_scalars_bytes(T, 9000 + i) for i in range(M)]
+        want = []
+        for i in range(M):
+            srs = oc.srs_gen(tx.to_bytes(32, "big"), ty.to_bytes(32, "big"), scale, ms, i)
+            want.append((oc.commit(srs, rows[i], True),) + oc.open_(srs, rows[i], alpha, True))
+        c, e, p = ctypes.create_string_buffer(48), ctypes.create_string_buffer(32), ctypes.create_string_buffer(48)
+        for i in (0, 1, 2, 5, 7):
+            assert lib.kzg_multi_commit(m, i, rows[i], T, 1, c) == 0 and c.raw == want[i][0], i
+            assert lib.kzg_multi_open(m, i, rows[i], T, 1, alpha, e, p) == 0 and (e.raw, p.raw) == want[i][1:], i
+            assert lib.kzg_multi_commit_open(m, i, rows[i], T, 1, alpha, c, e, p) == 0 and (c.raw, e.raw, p.raw) == want[i], i
+        assert lib.kzg_multi_commit(m, M, rows[0], T, 1, c) == _native.KZG_E_ARG
+        assert b"worker index" in lib.kzg_multi_last_error(m)
+        # the rows of one challenge over all "devices" at once, in a shuffled order, one row poisoned
+        order = [6, 1, 4, 7, 0, 3, 2, 5]
+        idx = (ctypes.c_uint32 * M)(*order)
+        blob = bytearray(b"".join(rows[i] for i in order))
+        blob[32 * T * 2: 32 * T * 2 + 32] = b"\xff" * 32                       # row k = 2 (worker 4): a scalar >= r
+        oc_, oe_, op_ = (ctypes.create_string_buffer(n * M) for n in (48, 32, 48))
+        st = (ctypes.c_int * M)()
+        rc = lib.kzg_multi_commit_open_rows(m, M, idx, bytes(blob), T, 1, alpha, oc_, oe_, op_, st)
+        assert rc == _native.KZG_E_SCALAR and b"row 2 (worker 4)" in lib.kzg_multi_last_error(m)
+        for k, i in enumerate(order):
+            if k == 2:
+                assert st[k] == _native.KZG_E_SCALAR
+                continue
+            assert st[k] == 0 and (oc_.raw[48 * k:48 * k + 48], oe_.raw[32 * k:32 * k + 32], op_.raw[48 * k:48 * k + 48]) == want[i], (k, i)
+        # each context holds only the slices of its own workers: 8 rows over 3 contexts = 3 + 3 + 2 slices
+        assert [lib.kzg_srs_points(lib.kzg_multi_ctx(m, g)) // T for g in range(G)] == [3, 3, 2]
+        assert lib.kzg_multi_ctx(m, G) is None
+    finally:
+        lib.kzg_multi_destroy(m)
 
 
 def test_g1_sum_of_k_partials_any_count(hip):

@@ -67,6 +67,18 @@ SYMBOLS = {
     "kzg_comm_selftest": (_I, [_P]),
     "kzg_msm_sharded": (_I, [_P, _I, _U64, _U64, _B]),
     "kzg_test_comm_stall": (_I, [_P, _I]),
+    "kzg_multi_create": (_I, [_I, ctypes.POINTER(_I), ctypes.POINTER(_P)]),
+    "kzg_multi_destroy": (None, [_P]),
+    "kzg_multi_last_error": (ctypes.c_char_p, [_P]),
+    "kzg_multi_count": (_I, [_P]),
+    "kzg_multi_ctx": (_P, [_P, _I]),
+    "kzg_multi_device_of": (_I, [_P, _U32]),
+    "kzg_multi_load_srs_file": (_I, [_P, _B, _I, _I, _I]),
+    "kzg_multi_gen_srs": (_I, [_P, _B, _B, _I, _I]),
+    "kzg_multi_commit": (_I, [_P, _U32, _B, _U64, _I, _B]),
+    "kzg_multi_open": (_I, [_P, _U32, _B, _U64, _I, _B, _B, _B]),
+    "kzg_multi_commit_open": (_I, [_P, _U32, _B, _U64, _I, _B, _B, _B, _B]),
+    "kzg_multi_commit_open_rows": (_I, [_P, _U32, ctypes.POINTER(_U32), _B, _U64, _I, _B, _B, _B, _B, ctypes.POINTER(_I)]),
     "kzg_upload_fr": (_I, [_P, _I, _B, _U64, _I]),
     "kzg_msm_resident": (_I, [_P, _I, _U64, _U64, _B]),
     "kzg_msm_partial_resident": (_I, [_P, _I, _U64, _U64, _B]),

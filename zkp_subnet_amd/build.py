@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libkzg_mi355x.so")
-SOURCES = ["msm.hip", "fr_kernels.hip", "api.hip", "calibrate.hip", "pairing_host.cpp", "finish_host.cpp", "rccl_dl.cpp"]
+SOURCES = ["msm.hip", "fr_kernels.hip", "api.hip", "calibrate.hip", "pairing_host.cpp", "finish_host.cpp", "rccl_dl.cpp", "multi_host.cpp"]
 # dev-only prototypes (scripts/proto/), linked only when KZG_WITH_PROTO=1: never part of the shipped library
 PROTO_SOURCES = ["../../scripts/proto/baff_proto.hip"]
 HEADERS = ["bigint.hip.h", "field.hip.h", "fp28.hip.h", "fr29.hip.h", "g1.hip.h", "msm.hip.h", "fr_kernels.hip.h", "fp_lp.hip.h", "fp_host.h", "rccl_dl.h", "lanebook.h",

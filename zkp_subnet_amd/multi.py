@@ -13,7 +13,8 @@ sends row i to miner i (reference neurons/validator.py:194-222) and each miner p
 
 Every device holds the setup it needs: with a setup file each context loads the whole file (mainnet: 34 GB of tables
 per GPU, of 288); with a synthetic seed each context generates only the slices routed to it.  SURVEY 8b proposed
-`kzg_create(device_count, device_ids)`; the C-ABI keeps one ctx = one GPU and this class is the router above it."""
+`kzg_create(device_count, device_ids)`: the C-ABI has that router too (`kzg_multi_*`, csrc/multi_host.cpp, for native
+callers working on bytes); this class is the same routing one level up, where the text codec and the Client surface live."""
 from __future__ import annotations
 
 from concurrent.futures import ThreadPoolExecutor
