@@ -91,7 +91,8 @@ def test_native_c_caller_builds_against_the_public_header_and_gets_a_status_code
     exe = str(tmp_path / "native_caller")
     libdir = os.path.join(ROOT, "zkp_subnet_amd")
     cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "tests", "native_caller.c"), "-o", exe, "-L", libdir, "-lkzg_mi355x", "-Wl,-rpath," + libdir]
+           os.path.join(ROOT, "tests", "native_caller.c"), "-o", exe, "-L", libdir, "-lkzg_mi355x", "-Wl,-rpath," + libdir,
+           "-Wl,--allow-shlib-undefined"]      # (the sanitizer builds of the library resolve their runtime at load time)
     res = subprocess.run(cmd, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr[-3000:]
     (tmp_path / "s.bin").write_bytes(bytes(32 * 16))

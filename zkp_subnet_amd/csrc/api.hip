@@ -13,7 +13,9 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <new>
 #include <atomic>
 #include <chrono>
 #include <string>
@@ -2134,7 +2136,8 @@ int kzg_comm_selftest(kzg_ctx* ctx) {
         rank = ctx->comm.rank;
         timeout_ms = ctx->comm.timeout_ms;
     }
-    std::vector<uint8_t> got((size_t)world * 192);
+    std::unique_ptr<uint8_t[]> got(new (std::nothrow) uint8_t[(size_t)world * 192]);    // no exception crosses the C boundary
+    if (!got) return fail(ctx, KZG_E_NOMEM, "kzg_comm_selftest: host buffer");
     HIPCHK(ctx, hipMemsetAsync(L.comm_send.p, (rank + 1) & 0xff, 192, L.stream));
     HIPCHK(ctx, hipMemsetAsync(L.comm_recv.p, 0, (size_t)world * 192, L.stream));
     {
@@ -2166,7 +2169,7 @@ int kzg_comm_selftest(kzg_ctx* ctx) {
         }
         std::this_thread::sleep_for(std::chrono::microseconds(100));
     }
-    HIPCHK(ctx, hipMemcpy(got.data(), L.comm_recv.p, got.size(), hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(got.get(), L.comm_recv.p, (size_t)world * 192, hipMemcpyDeviceToHost));
     for (int i = 0; i < world; i++)
         for (int b = 0; b < 192; b++)
             if (got[(size_t)i * 192 + b] != (uint8_t)((i + 1) & 0xff))

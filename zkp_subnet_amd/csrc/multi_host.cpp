@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <new>
 #include <string>
 #include <system_error>
 #include <thread>
@@ -69,7 +70,7 @@ int relay(kzg_ctx* ctx, int rc) {      // a per-GPU failure becomes this handle'
 
 extern "C" {
 
-int kzg_multi_create(int device_count, const int* device_ids, kzg_multi** out) {
+static int kzg_multi_create_impl(int device_count, const int* device_ids, kzg_multi** out) {
     if (!out) return KZG_E_ARG;
     *out = nullptr;
     if (device_count < 1 || device_count > 64 || !device_ids) return mfail(KZG_E_ARG, "1..64 devices");
@@ -99,7 +100,7 @@ int kzg_multi_count(kzg_multi* m) { return m ? (int)m->ctx.size() : 0; }
 kzg_ctx* kzg_multi_ctx(kzg_multi* m, int k) { return (m && k >= 0 && k < (int)m->ctx.size()) ? m->ctx[k] : nullptr; }
 int kzg_multi_device_of(kzg_multi* m, uint32_t i) { return (m && !m->ctx.empty()) ? m->device[i % m->ctx.size()] : -1; }
 
-int kzg_multi_load_srs_file(kzg_multi* m, const char* path, int compressed, int scale, int machines_scale) {
+static int kzg_multi_load_srs_file_impl(kzg_multi* m, const char* path, int compressed, int scale, int machines_scale) {
     if (!m || !path || machines_scale < 0 || machines_scale > 30) return mfail(KZG_E_ARG, "bad argument");
     const int rc = each_device(m, [&](int g) { return kzg_load_srs_file(m->ctx[g], path, compressed, scale, machines_scale); });
     if (rc != KZG_OK) return rc;       // (a device whose load failed keeps serving its previous SRS; the handle stays as it was)
@@ -108,7 +109,7 @@ int kzg_multi_load_srs_file(kzg_multi* m, const char* path, int compressed, int 
     m->loaded = true;
     return KZG_OK;
 }
-int kzg_multi_gen_srs(kzg_multi* m, const uint8_t tau_be32[32], const uint8_t* s0_be32_all, int scale, int machines_scale) {
+static int kzg_multi_gen_srs_impl(kzg_multi* m, const uint8_t tau_be32[32], const uint8_t* s0_be32_all, int scale, int machines_scale) {
     if (!m || !tau_be32 || !s0_be32_all || machines_scale < 0 || machines_scale > 20) return mfail(KZG_E_ARG, "bad argument");
     const uint32_t M = 1u << machines_scale, G = (uint32_t)m->ctx.size();
     const int rc = each_device(m, [&](int g) {
@@ -147,7 +148,7 @@ int kzg_multi_commit_open(kzg_multi* m, uint32_t i, const uint8_t* row_be32, uin
 // The rows of one challenge, all devices at once: row k (worker index indices[k], T x 32 bytes at rows_be32 + k * T * 32) runs
 // on the device of its index, up to four rows per device in flight (a context has four lanes).  out_status[k] is that row's
 // own status: one bad row never costs the others.  Returns KZG_OK when every row succeeded, else the first failing status.
-int kzg_multi_commit_open_rows(kzg_multi* m, uint32_t n_rows, const uint32_t* indices, const uint8_t* rows_be32, uint64_t T,
+static int kzg_multi_commit_open_rows_impl(kzg_multi* m, uint32_t n_rows, const uint32_t* indices, const uint8_t* rows_be32, uint64_t T,
                                int evaluation_form, const uint8_t alpha_be32[32], uint8_t* out_c48, uint8_t* out_e32, uint8_t* out_p48,
                                int* out_status) {
     if (!m || (n_rows && (!indices || !rows_be32 || !alpha_be32 || !out_c48 || !out_e32 || !out_p48 || !out_status)))
@@ -173,6 +174,46 @@ int kzg_multi_commit_open_rows(kzg_multi* m, uint32_t n_rows, const uint32_t* in
     for (uint32_t k = 0; k < n_rows; k++)
         if (out_status[k] != KZG_OK) return mfail(out_status[k], "row " + std::to_string(k) + " (worker " + std::to_string(indices[k]) + "): " + msg[k]);
     return KZG_OK;
+}
+
+// ---- the entry points above that allocate (vectors, strings, threads): no exception crosses the C boundary
+int kzg_multi_create(int device_count, const int* device_ids, kzg_multi** out) {
+    try {
+        return kzg_multi_create_impl(device_count, device_ids, out);
+    } catch (const std::bad_alloc&) {
+        return mfail(KZG_E_NOMEM, "kzg_multi_create: out of host memory");
+    } catch (...) {
+        return mfail(KZG_E_HIP, "kzg_multi_create: unexpected host-side failure");
+    }
+}
+int kzg_multi_load_srs_file(kzg_multi* m, const char* path, int compressed, int scale, int machines_scale) {
+    try {
+        return kzg_multi_load_srs_file_impl(m, path, compressed, scale, machines_scale);
+    } catch (const std::bad_alloc&) {
+        return mfail(KZG_E_NOMEM, "kzg_multi_load_srs_file: out of host memory");
+    } catch (...) {
+        return mfail(KZG_E_HIP, "kzg_multi_load_srs_file: unexpected host-side failure");
+    }
+}
+int kzg_multi_gen_srs(kzg_multi* m, const uint8_t tau_be32[32], const uint8_t* s0_be32_all, int scale, int machines_scale) {
+    try {
+        return kzg_multi_gen_srs_impl(m, tau_be32, s0_be32_all, scale, machines_scale);
+    } catch (const std::bad_alloc&) {
+        return mfail(KZG_E_NOMEM, "kzg_multi_gen_srs: out of host memory");
+    } catch (...) {
+        return mfail(KZG_E_HIP, "kzg_multi_gen_srs: unexpected host-side failure");
+    }
+}
+int kzg_multi_commit_open_rows(kzg_multi* m, uint32_t n_rows, const uint32_t* indices, const uint8_t* rows_be32, uint64_t T,
+                               int evaluation_form, const uint8_t alpha_be32[32], uint8_t* out_c48, uint8_t* out_e32, uint8_t* out_p48,
+                               int* out_status) {
+    try {
+        return kzg_multi_commit_open_rows_impl(m, n_rows, indices, rows_be32, T, evaluation_form, alpha_be32, out_c48, out_e32, out_p48, out_status);
+    } catch (const std::bad_alloc&) {
+        return mfail(KZG_E_NOMEM, "kzg_multi_commit_open_rows: out of host memory");
+    } catch (...) {
+        return mfail(KZG_E_HIP, "kzg_multi_commit_open_rows: unexpected host-side failure");
+    }
 }
 
 }  // extern "C"
