@@ -430,3 +430,40 @@ def test_lane_book_drive_without_a_sanitizer(tmp_path):
     assert res.returncode == 0, res.stderr[-2000:]
     out = subprocess.run([exe, "1.5", "8"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "invariant failures: 0" in out.stdout, (out.stdout[-500:], out.stderr[-1000:])
+
+
+def test_evidence_keep_refuses_lines_of_another_tree_and_byte_identical_files(tmp_path):
+    """VERDICT r4 task 4, enforced by code: a bench line gets into profiles/ only if its identity.source_sha16 is THIS tree's;
+    a line measured on other sources, a file without a JSON line and a byte-identical twin of an existing evidence file are
+    refused (exit 1) and nothing is written for them."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from bench import source_sha16
+
+    keep = os.path.join(root, "scripts", "evidence_keep.py")
+    good = {"metric": "m", "value": 1.0, "identity": {"source_sha16": source_sha16(root), "git_head": None, "utc": "t"}}
+    bad = {"metric": "m", "value": 2.0, "identity": {"source_sha16": "0" * 16, "git_head": "abc"}}
+    (tmp_path / "good.json").write_text("noise before the line\n" + json.dumps(good) + "\n")
+    (tmp_path / "bad.json").write_text(json.dumps(bad) + "\n")
+    (tmp_path / "empty.json").write_text("no json here\n")
+    dst = os.path.join(root, "profiles", "_test_evidence_keep.json")
+    try:
+        r = subprocess.run([sys.executable, keep, str(tmp_path / "good.json"), dst], capture_output=True, text=True)
+        assert r.returncode == 0 and "kept" in r.stdout and json.load(open(dst)) == good, r.stdout + r.stderr
+        twin = os.path.join(root, "profiles", "_test_evidence_keep_twin.json")
+        r = subprocess.run([sys.executable, keep, str(tmp_path / "good.json"), twin], capture_output=True, text=True)
+        assert r.returncode == 1 and "byte-identical" in r.stdout and not os.path.exists(twin)
+        for name, why in (("bad.json", "measured on source set"), ("empty.json", "no JSON line")):
+            out = os.path.join(root, "profiles", "_test_evidence_refused.json")
+            r = subprocess.run([sys.executable, keep, str(tmp_path / name), out], capture_output=True, text=True)
+            assert r.returncode == 1 and "REFUSED" in r.stdout and why in r.stdout and not os.path.exists(out), r.stdout
+    finally:
+        for f in ("_test_evidence_keep.json", "_test_evidence_keep_twin.json", "_test_evidence_refused.json"):
+            try:
+                os.remove(os.path.join(root, "profiles", f))
+            except OSError:
+                pass
