@@ -1,5 +1,7 @@
 #!/bin/bash
 # Same-box bisect of the `pipelined` regression VERDICT r4 reported (two requests in flight bought nothing on HEAD):
+# Needs (git-ignored, built in the authoring container before the gpurun call): scripts/ab_trees/wa and wb = `git worktree`
+# checkouts of a4f126c / 1b467d4 with their own built libkzg_mi355x.so, zkp_subnet_amd/ab/C.so and D.so.
 #   wa = the tree at a4f126c (before the tile-streamed upload), wb = 1b467d4 (the commit that added the h2d copy stream),
 #   C  = HEAD's library as built at round start, D = the candidate fix (h2d stream created after the lanes' streams),
 #   Cq8 = C with GPU_MAX_HW_QUEUES=8.  Prints: variant, ms_per_step (one at a time), pipelined ms_per_step, live accumulate ms.

@@ -18,7 +18,7 @@ from zkp_subnet_amd._native import KZG_E_ARG, KZG_E_COMM  # noqa: E402
 
 assert "torch" not in sys.modules
 out = {}
-for lg in (6, 12, 16):
+for lg in (6, 12, 16, 20):      # ... up to the headline size (BASELINE.json configs[1])
     n = 1 << lg
     eng = HipEngine(0)
     eng.gen_srs(0x51AB1E + lg, 1, lg, 0)

@@ -33,7 +33,7 @@
 #include "rccl_dl.h"
 #include "lanebook.h"
 
-#define KZG_VERSION "kzg_mi355x 0.4 (gfx950)"
+#define KZG_VERSION "kzg_mi355x 0.5 (gfx950)"
 #define N_SLOTS 4
 #ifndef N_LANES
 #define N_LANES 4
