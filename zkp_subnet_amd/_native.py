@@ -127,6 +127,10 @@ def load() -> ctypes.CDLL:
                 f"{LIB_PATH} is missing: build it with `python -m zkp_subnet_amd.build` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
             )
+        # eight hardware queues instead of the runtime's four, unless the user chose: the four lanes of a context then run
+        # concurrently whatever the creation order of the process's streams (csrc/api.hip kzg_default_hw_queues; measured:
+        # profiles/r05_ab_hw_queues.log).  Read by the HIP runtime at its first call -- so set BEFORE the library loads.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <errno.h>
+#include <stdlib.h>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -1143,6 +1144,17 @@ void b64_init() {
 }
 
 }  // namespace
+
+// The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of two
+// streams that share a queue execute in order.  A context has four lanes (a stream + a verification side stream each), an
+// auxiliary and a copy stream: on four queues lanes collide -- which lanes depends on the order in which every stream of the
+// PROCESS was created (round 4's `pipelined` regression: DESIGN.md 3.3).  With eight queues the four lanes run concurrently
+// whatever that order: requests/s with 4 host threads 4961 -> 6700 at 2^12 and 1640 -> 1967 at 2^16, two MSMs in flight
+// overlap in either stream order, single requests unchanged (profiles/r05_ab_hw_queues.log).  The variable is read when the
+// HIP runtime initialises, i.e. at the first HIP call of the process: setting it here -- when this library is loaded, only if
+// the user has not set it -- is in time unless something else has already used HIP (then the caller exports it itself:
+// INTEGRATION.md section 4; zkp_subnet_amd/_native.py and bench.py set it before they touch HIP).
+__attribute__((constructor)) static void kzg_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0); }
 
 // =====================================================================================================
 extern "C" {
