@@ -805,7 +805,10 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this pool
     # eight hardware queues (the library's default, zkp_subnet_amd/_native.py): torch.cuda below is this process's first HIP
     # user, so the variable has to be in place before it -- the library loads later
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # (the one-GPU self-test puts several RANKS on one device: processes that share a GPU keep the runtime's four -- with eight
+    # queues each, two busy processes oversubscribe the hardware queues and every cross-stream wait costs a scheduling quantum:
+    # 33.5 against 6.4 ms per step, profiles/r05_ab_hw_queues.log)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4" if os.environ.get("BENCH_ONE_GPU") == "1" else "8")
     if world > 1:
         # ONE node by contract (the launch line is --nnodes=1, rendezvous on 127.0.0.1): the bootstrap sockets of RCCL and
         # gloo go over loopback whatever other interfaces the container shows and whether or not its hostname resolves
