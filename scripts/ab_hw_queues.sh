@@ -1,3 +1,7 @@
+#!/bin/bash
+# GPU_MAX_HW_QUEUES against the overlap of two MSMs in flight, in this round's stream order (head) and in round 4's (wb: needs
+# scripts/ab_trees/wb = a `git worktree` checkout of 1b467d4 with its own built library, see scripts/ab_pipelined_bisect.sh).
+# Prints: variant, ms per step one at a time, ms per step with two in flight.  Block 1 of profiles/r05_ab_hw_queues.log.
 cd $GRAFT_REPO_ROOT
 ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-kzg-rows --no-adversarial"
 show='import json,sys
