@@ -362,8 +362,10 @@ def make_collective(args, ctl, eng, torch, dist, rank, world):
                          "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())})
         else:
             info.update({"collective": f"{backend} fallback ({why})", "rccl_version": f"none ({backend} fallback: {why})"})
-        stuck = bool(err) and "did not all join" in err
-        return DeviceGather(eng) if not stuck else None, dict(info, engine_stuck_in_comm_init=stuck)
+        # the library bounds the rendezvous itself (kzg_comm_init_bounded): the engine stays usable after a timeout, but a
+        # helper thread may still sit inside RCCL's bootstrap -- this process then leaves through os._exit after its line
+        left = bool(err) and "did not all join" in err
+        return DeviceGather(eng), dict(info, comm_init_helper_left_behind=left)
     if backend == "nccl":
         info.update({"collective": "torch.distributed all_gather over torch's RCCL group, chained through streams (A/B form)",
                      "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())})
@@ -827,7 +829,7 @@ def main():
     # (RCCL over xGMI), see make_collective().  BENCH_BACKEND=nccl: torch's RCCL group carries both (the round-4 form).
     # BENCH_ONE_GPU=1: every rank on device 0 -- the self-test of the N > 1 logic (rank-dependent SRS segments, cross-rank
     # checks, msm26 / pianist_kzg22, the fallback from a communicator that cannot form) on a one-GPU box, where RCCL refuses
-    # two ranks on one device (tests/test_gpu_parity.py).  Never what a measurement uses.
+    # two ranks on one device (tests/test_gpu_bench.py).  Never what a measurement uses.
     backend = os.environ.get("BENCH_BACKEND", "gloo")
     if os.environ.get("BENCH_ONE_GPU") == "1":
         local_rank = 0
@@ -852,13 +854,9 @@ def main():
     # checked all_gather under a watchdog, agreed between the ranks through the store; a failure falls back, flagged
     gather, coll_info, leaked = None, None, []
     if use_dist and is_msm:
-        from zkp_subnet_amd.distributed import DeviceGather
-
         gather, coll_info = make_collective(args, ctl, eng, torch, dist, rank, world)
-        if gather is None:      # this rank's engine is stuck inside ncclCommInitRank on a helper thread: leave it, start over
-            leaked.append(eng)
-            eng = HipEngine(local_rank, window=args.window)
-            gather = DeviceGather(eng)
+        if coll_info.get("comm_init_helper_left_behind"):
+            leaked.append("a join thread inside RCCL's rendezvous")
     t_setup = time.time()
     if args.workload == "msm20":
         lg = args.log_n or 20

@@ -46,6 +46,20 @@ int kzg_create(int device_id, kzg_ctx** out);
 void kzg_destroy(kzg_ctx* ctx);
 const char* kzg_last_error(kzg_ctx* ctx); /* last failure of the calling thread; valid until its next failing call */
 const char* kzg_version(void);
+/* What the process around the context looks like, measured once by kzg_create.  The four lanes of a context overlap only
+ * when the HIP runtime gives their streams different hardware queues: it has GPU_MAX_HW_QUEUES of them (default 4, read ONCE
+ * when the runtime initialises) for every stream of the process.  The library never writes the environment (the axon's
+ * threads may be reading it: neurons/miner.py:106-135 runs forward on worker threads): a launcher exports
+ * GPU_MAX_HW_QUEUES=8 before the process's first HIP call (zkp_subnet_amd does at import), and this
+ * call reports what the context actually got:
+ *   out[0] lanes of a context (4)
+ *   out[1] lanes measured to run concurrently: one spinning single-wave kernel per lane, the largest number alive at one
+ *          instant -- out[0] when every lane has its own queue, 1 when they execute one after the other (results are the
+ *          same either way; two requests in flight then gain nothing), 0 if the probe itself failed
+ *   out[2] 1 if a HIP runtime was already initialised in the process when this library was loaded (an export made after
+ *          that point came too late)
+ *   out[3] GPU_MAX_HW_QUEUES as the environment showed it at kzg_create (0 = unset: the runtime's default) */
+int kzg_runtime_info(kzg_ctx* ctx, int32_t out[4]);
 /* window bits c for the signed-digit Pippenger tables; 0 = choose from the slice length.  Call before the SRS. */
 int kzg_set_window(kzg_ctx* ctx, int c);
 int kzg_get_window(kzg_ctx* ctx);
@@ -69,6 +83,17 @@ int kzg_load_srs_compressed(kzg_ctx* ctx, const uint8_t* g1_c48, uint64_t n_poin
  * mapping would have raised SIGBUS).  All three loaders build the new tables aside and swap them in only
  * when the whole load has succeeded: after a failure (bad point, I/O, memory) the previously loaded SRS keeps serving. */
 int kzg_load_srs_file(kzg_ctx* ctx, const char* path, int compressed, int scale, int machines_scale);
+/* The same for ONE device of a host that spreads the worker rows over G GPUs (worker i on device i mod G: kzg_multi_*,
+ * MultiDeviceClient): only the slices this context serves are read (pread of just those byte ranges), decoded, checked and
+ * tabulated -- resident slice k = file slice first_slice + k * slice_stride, so worker index i = first_slice + k * slice_stride
+ * is served as slice k.  Mainnet 24 / 8 on G devices: 34 / G GB of tables and ~1 / G of the start time per device instead of
+ * the whole file on each (reference Makefile:63-74 starts one prover per process from the whole file: base/miner.py:75-81). */
+int kzg_load_srs_file_slices(kzg_ctx* ctx, const char* path, int compressed, int scale, int machines_scale,
+                             uint32_t first_slice, uint32_t slice_stride);
+/* One contiguous SEGMENT of a flat SRS: file points [first_point, first_point + n_points) become the resident points
+ * [0, n_points) of a single slice (machines_scale 0; n_points <= 2^scale, `scale` sizes the Pippenger window).  What device g
+ * holds when ONE MSM is sharded by SRS segment over the GPUs of a host (kzg_multi_msm; BASELINE.json configs[3]). */
+int kzg_load_srs_file_range(kzg_ctx* ctx, const char* path, int compressed, uint64_t first_point, uint64_t n_points, int scale);
 /* seconds spent by the last successful load: [0] host copies into the pinned tiles, [1] host waiting for upload + decode
  * (decompression), [2] window-table build, [3] whole call */
 int kzg_get_load_stats(kzg_ctx* ctx, double out_s[4]);
@@ -189,10 +214,16 @@ int kzg_msm_sharded_finish(kzg_ctx* ctx, int ticket, const void* dev_partials_xy
  *                       (a file, a socket, torch.distributed's store, MPI): the rendezvous is the caller's.
  *  kzg_comm_init        ncclCommInitRank on the context's device; collective over the `world` ranks (blocks until all
  *                       have called it).  Waits for the lanes to be idle; KZG_E_BUSY while a ticket is out.
+ *  kzg_comm_init_bounded the same with a deadline: the rendezvous AND a first checked 192-byte all_gather (which connects the
+ *                       transports) run on a helper thread that holds nothing of the context; when the `world` ranks have
+ *                       not joined and exchanged within init_timeout_ms (0 = wait for ever = kzg_comm_init) the call returns
+ *                       KZG_E_COMM and the context keeps serving -- a peer that never arrives costs one timeout, never a
+ *                       wedged context (a helper still blocked inside RCCL's rendezvous is left behind; it owns nothing).
  *  kzg_comm_set_timeout per-call budget in ms for kzg_msm_sharded (0 = wait for ever, the default).  When it expires the
  *                       communicator is ABORTED (ncclCommAbort: the stuck collective leaves the stream), the call and every
  *                       later one return KZG_E_COMM until kzg_comm_destroy + kzg_comm_init -- a dead peer costs one
- *                       timeout, never a parked axon thread.
+ *                       timeout, never a parked axon thread.  A call on ANOTHER lane whose collective was in flight under
+ *                       the aborted communicator returns KZG_E_COMM too, never a result (checked after its wait).
  *  kzg_comm_info        out[0] rank, out[1] world (0 = no communicator), out[2] RCCL version (e.g. 22707), out[3] 1 if broken.
  *  kzg_comm_selftest    one small all_gather with checked content (rank i sends 192 bytes of value i + 1): run it right
  *                       after kzg_comm_init, before tables are built -- ncclCommInitRank succeeding does not prove that bytes
@@ -204,22 +235,38 @@ int kzg_msm_sharded_finish(kzg_ctx* ctx, int ticket, const void* dev_partials_xy
  *                       collectives on one communicator). */
 int kzg_comm_unique_id(uint8_t out_id128[128]);
 int kzg_comm_init(kzg_ctx* ctx, const uint8_t unique_id128[128], int rank, int world);
+int kzg_comm_init_bounded(kzg_ctx* ctx, const uint8_t unique_id128[128], int rank, int world, int init_timeout_ms);
 int kzg_comm_destroy(kzg_ctx* ctx);
 int kzg_comm_set_timeout(kzg_ctx* ctx, int timeout_ms);
 int kzg_comm_info(kzg_ctx* ctx, int32_t out[4]);
 int kzg_comm_selftest(kzg_ctx* ctx);
 int kzg_msm_sharded(kzg_ctx* ctx, int slot, uint64_t n, uint64_t srs_offset, uint8_t out48[48]);
 
-/* ---- several GPUs behind ONE handle (SURVEY 8b proposed kzg_create(device_count, device_ids)): a router over one context
- *      per GPU -- worker index i is served by device_ids[i mod G].  This is the in-process form of the reference's only
- *      distribution scheme: Pianist rows are independent, one row per miner (neurons/validator.py:194-222), one prover client
- *      per process (base/miner.py:73-84).  No collective, nothing exchanged between the devices; thread-safe like a context.
- *  kzg_multi_load_srs_file   every device loads the whole setup file (in parallel); worker i = slice i of its device
+/* ---- several GPUs behind ONE handle (SURVEY 8b proposed kzg_create(device_count, device_ids); the reference builds one
+ *      prover client per process, base/miner.py:73-84).  One context per GPU inside; host threads only; thread-safe like a
+ *      context.  Two layouts, chosen by the load call:
+ *  ROWS -- worker index i is served by device_ids[i mod G].  The in-process form of the reference's only distribution scheme:
+ *      Pianist rows are independent, one row per miner (neurons/validator.py:194-222).  Nothing is exchanged.
+ *  kzg_multi_load_srs_file   every device loads, in parallel, ONLY the slices of the worker indices it serves (i = g, g + G, ...:
+ *                            kzg_load_srs_file_slices) -- 1 / G of the file, of the tables and of the start time each
  *  kzg_multi_gen_srs         synthetic SRS: s0_be32_all holds ALL 2^machines_scale slice factors; device g generates and
- *                            holds only the slices of the worker indices it serves (i = g, g + G, ...)
+ *                            holds only the slices of the worker indices it serves
  *  kzg_multi_commit / _open / _commit_open        = kzg_commit / kzg_open / kzg_commit_open on the device of index i
  *  kzg_multi_commit_open_rows   the rows of one challenge fanned out over the devices from host threads (up to four rows per
  *                            device in flight); out_status[k] is row k's own status -- a bad row never costs the others
+ *  SEGMENTS -- ONE MSM over all the GPUs of the handle (BASELINE.json configs[3] from behind the one-client seam): a flat SRS of
+ *      n_points is cut into G contiguous segments (sizes differ by at most one), segment g resident on device g.
+ *  kzg_multi_load_srs_file_segments   device g reads file points [lo_g, lo_g + n_g) only (kzg_load_srs_file_range)
+ *  kzg_multi_gen_srs_segments         synthetic: point j = [tau^j] G; s0_be32_per_device[g] = tau^(lo_g) (G x 32 bytes, computed
+ *                            by the caller: tests and benches only); kzg_multi_segment reports lo_g and n_g
+ *  kzg_multi_msm             sum_j s_j P_(srs_offset + j), j < n: device g computes the partial of its part of the range on its
+ *                            own lane (all devices concurrently, scalars uploaded straight to their device), the G 192-byte
+ *                            partials come back through the host and are summed once -- no collective, the exchange is G x 192 B.
+ *                            Bit-identical to kzg_msm over the same points on one device.
+ *  kzg_multi_upload_fr / kzg_multi_msm_resident   the same with the scalars resident in HBM (segment g's scalars in slot
+ *                            `slot` of device g): what a serving loop and bench.py time
+ *  After a load that failed on ANY device the handle refuses every routed call (KZG_E_ARG) until a load has succeeded on all
+ *  of them: the devices that did load already hold the new SRS, so no layout describes the handle in between.
  *  kzg_multi_ctx             the k-th per-GPU context: every other call of this header applies to it */
 typedef struct kzg_multi kzg_multi;
 int kzg_multi_create(int device_count, const int* device_ids, kzg_multi** out);
@@ -230,6 +277,12 @@ kzg_ctx* kzg_multi_ctx(kzg_multi* m, int k);
 int kzg_multi_device_of(kzg_multi* m, uint32_t i);
 int kzg_multi_load_srs_file(kzg_multi* m, const char* path, int compressed, int scale, int machines_scale);
 int kzg_multi_gen_srs(kzg_multi* m, const uint8_t tau_be32[32], const uint8_t* s0_be32_all, int scale, int machines_scale);
+int kzg_multi_load_srs_file_segments(kzg_multi* m, const char* path, int compressed, uint64_t n_points);
+int kzg_multi_gen_srs_segments(kzg_multi* m, const uint8_t tau_be32[32], const uint8_t* s0_be32_per_device, uint64_t n_points);
+int kzg_multi_segment(kzg_multi* m, int g, uint64_t out_first_count[2]);
+int kzg_multi_msm(kzg_multi* m, const uint8_t* scalars_be32, uint64_t n, uint64_t srs_offset, uint8_t out48[48]);
+int kzg_multi_upload_fr(kzg_multi* m, int slot, const uint8_t* scalars_be32, uint64_t n, uint64_t srs_offset);
+int kzg_multi_msm_resident(kzg_multi* m, int slot, uint8_t out48[48]);
 int kzg_multi_commit(kzg_multi* m, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,
                      uint8_t out_commitment48[48]);
 int kzg_multi_open(kzg_multi* m, uint32_t i, const uint8_t* row_be32, uint64_t T, int evaluation_form,

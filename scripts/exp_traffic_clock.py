@@ -1,4 +1,7 @@
-"""VERDICT r4 task 6: does the 16.5 x HBM traffic of k_msm_accumulate (2.22 GB gathered per 2^20-point launch, ~1.1 TB/s)
+"""NOTE (round 6): the experiment is CLOSED and its hook (KZG_EXP_L2_RESIDENT in k_msm_accumulate) no longer lives in the shipped
+kernel; `git apply -R scripts/proto/exp_l2_resident.removed.patch` puts it back for a re-run.
+
+VERDICT r4 task 6: does the 16.5 x HBM traffic of k_msm_accumulate (2.22 GB gathered per 2^20-point launch, ~1.1 TB/s)
 cost the kernel CLOCK (socket power cap) or TIME?  One experiment, same box, same process layout:
 
   real    the shipped library: every digit gathers its own 128-byte row from one of 13 window tables (1.74 GB resident)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Bring-up script for the GPU box (not collected by pytest): staged parity checks against the oracle with timings.
-Development aid kept under tests/ because it uses the oracle; the judged parity tests are tests/test_gpu_parity.py.
+Development aid kept under tests/ because it uses the oracle; the judged parity tests are tests/test_gpu_*.py.
 
     python tests/bringup_gpu_check.py [field] [g1] [srs] [golden] [mid] [big]
 """

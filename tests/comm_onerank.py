@@ -1,4 +1,4 @@
-"""Child process of test_gpu_parity.py: the library's OWN collective (kzg_comm_init / kzg_msm_sharded) on a one-rank
+"""Child process of test_gpu_multi.py: the library's OWN collective (kzg_comm_init / kzg_msm_sharded) on a one-rank
 communicator on cuda:0, with NO torch in the process (the reference seam is one client object with no framework
 underneath, base/miner.py:73-84).  The sharded MSM -- partial, ncclAllGather on the lane's stream, sum -- must return
 the bytes of the plain single-GPU MSM, from several host threads at once, after a timeout that aborts the communicator,

@@ -50,3 +50,21 @@ def oracle_cpu():
 
     cpu.build()
     return cpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    """Factory of HipEngine contexts on GPU 0 (closed when the module is done).  Raises if the HIP library is missing or no
+    gfx950 device works: the GPU tests never fall back to anything."""
+    from zkp_subnet_amd import HipEngine
+
+    engines = []
+
+    def make(window=0):
+        e = HipEngine(0, window=window)
+        engines.append(e)
+        return e
+
+    yield make
+    for e in engines:
+        e.close()

@@ -1,4 +1,4 @@
-"""Child process of test_gpu_parity.py: a ONE-rank RCCL group on cuda:0.  The collective step of the sharded MSM through
+"""Child process of test_gpu_multi.py: a ONE-rank RCCL group on cuda:0.  The collective step of the sharded MSM through
 the stream-chained entry points (kzg_msm_sharded_begin / _finish: lane -> torch's stream -> RCCL -> lane, one host
 synchronisation) must return the bytes of the blocking pair and of the plain single-GPU MSM.  Prints one JSON line."""
 import json

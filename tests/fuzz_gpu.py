@@ -4,7 +4,7 @@ MSM (random size / window / scalar distribution / offset), NTT round trips and o
 commit+open on random rows incl. special alphas, the same through the text path and the row cache (with and without a
 coefficient changed between the two calls), and the fused transform + evaluation.
 `python tests/fuzz_gpu.py [seconds] [seed]`; a seeded slice (`run(rounds=...)`) is part of the driver's `pytest -m gpu` run
-(tests/test_gpu_parity.py::test_seeded_fuzz_slice)."""
+(tests/test_gpu_bench.py::test_seeded_fuzz_slice)."""
 import os
 import random
 import sys

@@ -7,7 +7,7 @@
 //
 // The reference's axon runs Miner.forward on worker threads and must never crash (reference neurons/miner.py:106-135,
 // :133-135): this is the bookkeeping those threads contend on.  The GPU box runs the same machine un-instrumented under
-// tests/test_gpu_parity.py's lane stress test; no sanitizer is available there.
+// tests/test_gpu_serving.py's lane stress test; no sanitizer is available there.
 //
 //   clang++ -std=c++17 -O1 -g -fsanitize=thread -pthread -I zkp_subnet_amd/csrc tests/lanebook_tsan.cpp -o lanebook_tsan
 //   ./lanebook_tsan [seconds=5] [threads=12]            (scripts/sanitize_cpu.sh tsan-lanes)

@@ -1,6 +1,6 @@
 /* native_caller.c -- the C-ABI of libkzg_mi355x.so driven from plain C (C99, gcc, the public header only): what a cgo /
  * FFI binding of the prover does, with no Python and no torch in the process.  Built and run by tests/test_abi.py (no
- * GPU: kzg_create must fail with a status code) and tests/test_gpu_parity.py (on the MI355X: every line it prints is
+ * GPU: kzg_create must fail with a status code) and tests/test_gpu_multi.py (on the MI355X: every line it prints is
  * compared with the CPU oracle by the test).  Mirrors INTEGRATION.md section 3.
  *
  *   native_caller <log2 n> <tau, 64 hex digits> <scalars file: n x 32 bytes big-endian, canonical>

@@ -2,6 +2,7 @@
 declares, refuses to run without a gfx950 device (no CPU fallback), and its host-side wire codec is exact."""
 import base64
 import ctypes
+import json
 import os
 import re
 
@@ -26,7 +27,7 @@ def test_header_symbols_all_exported_and_bound(lib):
     hooks = set(re.findall(r"\b(kzg_[a-z0-9_]+)\s*\(", test_hdr))
     # the test hooks are declared apart from the serving surface, in the same library
     assert hooks == {"kzg_test_field", "kzg_test_g1", "kzg_host_xyzz_to_c48", "kzg_host_xyzz_pair_to_c48",
-                     "kzg_host_xyzz_to_partial192", "kzg_vk_pairing", "kzg_test_comm_stall"} and not (hooks & serving)
+                     "kzg_host_xyzz_to_partial192", "kzg_vk_pairing", "kzg_test_comm_stall", "kzg_test_comm_stall_n"} and not (hooks & serving)
     assert "test hook" not in hdr.lower() and "kzg_test_" not in hdr
     declared = (serving | hooks) - {"kzg_ctx", "kzg_status"}
     assert len(declared) >= 30
@@ -298,6 +299,74 @@ def test_shipped_library_carries_no_prototype_hooks(lib):
     assert not hasattr(lib, "kzg_proto_baff")
     hdr = open(os.path.join(ROOT, "include", "kzg_mi355x.h")).read()
     assert "kzg_proto" not in hdr and "baff" not in hdr
+
+
+def test_loading_the_library_never_writes_the_process_environment():
+    """Round 5's library set GPU_MAX_HW_QUEUES from a load-time constructor (a setenv during dlopen races with getenv on
+    the host's other threads and changed queue allocation for every HIP user of the process).  Gone: after a bare dlopen
+    the C environment is what it was; the launcher (zkp_subnet_amd._native, at import) is who exports the variable, and the
+    sources no longer contain a setenv / putenv at all."""
+    import subprocess
+    import sys
+
+    code = (
+        "import ctypes, os\n"
+        "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
+        "assert libc.getenv(b'GPU_MAX_HW_QUEUES') is None\n"
+        f"ctypes.CDLL({_native.LIB_PATH!r})\n"
+        "assert libc.getenv(b'GPU_MAX_HW_QUEUES') is None, libc.getenv(b'GPU_MAX_HW_QUEUES')\n"
+        "print('untouched')\n")
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0 and "untouched" in out.stdout, out.stderr[-2000:]
+    csrc = os.path.join(ROOT, "zkp_subnet_amd", "csrc")
+    for name in os.listdir(csrc):
+        text = open(os.path.join(csrc, name), errors="replace").read()
+        assert "setenv(" not in text.replace("never writes", "") and "putenv(" not in text, name
+    # ... and the Python launcher does export it, at import time, only when the user has not chosen
+    code = "import os, zkp_subnet_amd._native; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120, cwd=ROOT)
+    assert out.stdout.strip() == "8", (out.stdout, out.stderr[-1000:])
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, GPU_MAX_HW_QUEUES="2"),
+                         timeout=120, cwd=ROOT)
+    assert out.stdout.strip() == "2"
+
+
+def test_check_scale_judges_a_scale_record_against_the_design_band(tmp_path):
+    """scripts/check_scale.py: a SCALE record inside DESIGN section 4's band passes; a gloo fallback, a slow weak-scaling
+    step or a poor msm26 efficiency fails; a skipped record is not judged."""
+    import subprocess
+    import sys
+
+    def line(n, step, coll="library: ncclAllGather of 192 B per rank on the lane's own stream (kzg_msm_sharded)", t26=None, pian=19.0):
+        d = {"metric": "BLS12-381 G1 MSM points/sec at 2^20", "value": n * (1 << 20) / step * 1e3, "n_gpus": n, "ms_per_step": step,
+             "config": {"workload": "2^20-point MSM per GPU", "world_size": n, "collective": coll if n > 1 else None,
+                        "rccl_version": "2.27.7" if n > 1 and coll.startswith("library") else (None if n == 1 else "none (gloo fallback)")}}
+        if n > 1:
+            d["msm26"] = {"ms_per_step": t26, "n_gpus": n}
+            d["pianist_kzg22"] = {"ms_per_step": pian, "n_gpus": n}
+        return d
+
+    def run(rec):
+        p = tmp_path / "scale.json"
+        p.write_text(json.dumps(rec))
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_scale.py"), str(p)], capture_output=True, text=True)
+        return out.returncode, out.stdout
+
+    good = {"runs": [{"n": 1, "parsed": line(1, 2.60)}, {"n": 2, "tail": json.dumps(line(2, 2.66, t26=61.5))},
+                     {"n": 4, "tail": "noise\n" + json.dumps(line(4, 2.66, t26=31.6))}, {"n": 8, "parsed": line(8, 2.67, t26=16.7)}]}
+    rc, txt = run(good)
+    assert rc == 0 and "FAIL" not in txt and "inside" in txt, txt
+    rc, txt = run({"runs": [{"parsed": line(1, 2.60)}, {"parsed": line(2, 2.95, coll="gloo fallback (library RCCL preflight failed on rank 1: x)", t26=62.0)}]})
+    assert rc == 1 and "gloo fallback" in txt, txt
+    rc, txt = run({"runs": [{"parsed": line(1, 2.60)}, {"parsed": line(8, 3.4, t26=16.7)}]})
+    assert rc == 1 and "weak-scaling step 3.400" in txt, txt
+    rc, txt = run({"runs": [{"parsed": line(1, 2.60)}, {"parsed": line(8, 2.65, t26=25.0)}]})
+    assert rc == 1 and "efficiency" in txt, txt
+    rc, txt = run({"skipped": True, "reason": "no 8-GPU node"})
+    assert rc == 0 and "SKIP" in txt
+    rc, _ = run(json.load(open(os.path.join(ROOT, "SCALE_r05.json"))))
+    assert rc == 0
 
 
 def test_content_tag_identifies_the_decoded_row():

@@ -1,0 +1,255 @@
+"""GPU parity tests (`-m gpu`), bench: bench.py's contract (the line the driver records), its multi-rank flow and failure handling, the seeded fuzz slice.
+Every result of the HIP path, obtained through the C-ABI, is compared bit-for-bit with the CPU oracle on the same seeded inputs,
+with the committed golden fixtures, and -- at BASELINE.json's full sizes -- through size-independent properties (trapdoor
+identity [f(tau)]G, linearity, NTT round trip).  All arithmetic is integer: the bar is bit-exact, no tolerance anywhere."""
+import base64  # noqa: F401
+import json  # noqa: F401
+import os
+import random  # noqa: F401
+
+import numpy as np  # noqa: F401
+import pytest
+
+from oracle import bls12_381 as o  # noqa: F401
+from oracle import cpu as oc  # noqa: F401
+from tests.gpu_common import ROOT, H, ints, rand_scalars_bytes  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_contract_line(hip):
+    """bench.py prints ONE JSON line, last on stdout, with the driver's keys plus `roofline` and `cpu_baseline`."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--log-n", "14", "--steps", "3", "--warmup", "1",
+                          "--cpu-sample-log", "12", "--kzg-rows", "10,8", "--e2e-rows", "10,8"], capture_output=True, text=True,
+                         timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert sum(1 for ln in lines if ln.startswith("{")) == 1            # N = 1: exactly ONE JSON line
+    rec = json.loads(lines[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in rec, k
+    assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["higher_is_better"] is True
+    assert rec["scaling"] == "weak" and rec["data"] == "synthetic" and "workload" in rec["config"]
+    assert abs(rec["value"] - (1 << 14) * 3 / (rec["ms_per_step"] * 3e-3)) / rec["value"] < 1e-6
+    rf, cb = rec["roofline"], rec["cpu_baseline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["matches_gpu_bit_exact"] is True
+    assert "1" in cb["points_per_s_by_threads"] and len(cb["points_per_s_by_threads"]) >= 2      # 1 thread AND more
+    assert rec["pipelined"]["value"] > 0 and rec["pipelined"]["pre_warm_steps"] >= 1
+    assert rec["pre_warm_steps"] >= rec["pipelined"]["pre_warm_steps"] + 3      # what ran before the W declared warm-up steps
+    # the line says who measured it (VERDICT r4 task 4): library, bench.py and the whole source set
+    import hashlib
+    from bench import source_sha16
+    ident = rec["identity"]
+    assert "gfx950" in ident["lib_version"] and ident["source_sha16"] == source_sha16(root)
+    assert ident["bench_py_sha16"] == hashlib.sha256(open(os.path.join(root, "bench.py"), "rb").read()).hexdigest()[:16]
+    # the reference's own route from text at the reference's sizes (task 5): two calls + the fused call, each == C oracle
+    for key in ("2^10", "2^8"):
+        e2e = rec["e2e_from_text"][key]
+        assert e2e["matches_cpu_oracle_bit_exact"] is True and e2e["two_call_ms"]["requests"] >= 20
+        assert 0 < e2e["fused_ms"]["median"] <= e2e["two_call_ms"]["p90"] * 1.5
+        assert e2e["two_call_row_cache_hits_misses"] == [30, 30]        # every worker_open a verified hit, every commit a miss
+    for key in ("2^10", "2^8"):                     # commit+open latency rows, each with roofline + cpu_baseline
+        row = rec["kzg_commit_open"][key]
+        assert row["ms"] > 0 and row["p10"] <= row["ms"] <= row["p90"] and row["roofline"]["algorithmic_bytes"] == 384.0 * (1 << row["log2_T"])
+        assert row["cpu_baseline"]["matches_gpu_bit_exact"] is True and len(row["result_hex"]) == 2 * (48 + 32 + 48)
+    # the collective path (1-rank group; the all_gather is the LIBRARY's: kzg_comm_init / kzg_msm_sharded on real RCCL)
+    # gives the same point
+    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    out2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--log-n", "14", "--steps", "3", "--warmup", "1",
+                           "--no-cpu-baseline", "--no-adversarial", "--no-kzg-rows", "--msm26-log", "16", "--kzg22-log", "12"],
+                          capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out2.returncode == 0, out2.stderr[-2000:]
+    jl = [json.loads(ln) for ln in out2.stdout.splitlines() if ln.strip().startswith("{")]
+    # with a process group the headline is printed as soon as it is complete, the augmented line follows: last line wins
+    assert len(jl) == 2 and "partial_line" in jl[0] and "msm26" not in jl[0] and "partial_line" not in jl[1]
+    assert jl[0]["value"] == jl[1]["value"] and jl[0]["result_hex"] == jl[1]["result_hex"]
+    rec2 = jl[-1]
+    assert rec2["result_hex"] == rec["result_hex"] and len(rec["result_hex"]) == 96
+    # a process group + no --workload: the same launch also yields configs[3] (msm26) and configs[4] (pianist_kzg22)
+    assert rec2["config"]["world_size"] == 1 and rec2["config"]["rccl_version"].startswith("2.")
+    assert rec2["config"]["collective"].startswith("library: ncclAllGather") and "comm_init_s" in rec2["config"]["collective_detail"]
+    m26, pk = rec2["msm26"], rec2["pianist_kzg22"]
+    assert m26["scaling"] == "strong" and m26["all_ranks_equal"] and m26["value"] > 0 and m26["roofline"]["kernel_ms"] > 0
+    assert abs(m26["value"] - (1 << 16) * m26["steps"] / (m26["ms_per_step"] * m26["steps"] * 1e-3)) / m26["value"] < 1e-6
+    assert pk["scaling"] == "weak" and pk["value"] > 0 and len(pk["results_hex_by_rank"]) == 1
+    assert pk["aggregate_commitment_hex"] == pk["results_hex_by_rank"][0][:96]      # one row: the sum is the row's own
+    # ... and both agree with the oracle on the same seeded inputs
+    from bench import TAU, uniform_fr
+    e = hip()
+    e.gen_srs(TAU, 1, 16, 0)
+    assert bytes.fromhex(m26["result_hex"]) == oc.msm(e.srs_read(0, 1 << 16), uniform_fr(1 << 16, 1000), threads=4)
+    e.gen_srs(TAU, 0, 12, 0, factors=[1])
+    row, alpha = uniform_fr(1 << 12, 0), uniform_fr(1, 1)
+    srs = e.srs_read(0, 1 << 12)
+    want = oc.commit(srs, row, True) + b"".join(oc.open_(srs, row, alpha, True))
+    assert bytes.fromhex(pk["results_hex_by_rank"][0]) == want
+    assert rec2["pipelined"]["value"] > 0
+    # a communicator that cannot be built (injected on the only rank): every rank falls back to the process group's
+    # all_gather, the line says so, the result is the same
+    env3 = dict(env, BENCH_FAULT="comm_init:0", MASTER_PORT="29548")
+    out3 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--log-n", "14", "--steps", "3", "--warmup", "1",
+                           "--no-cpu-baseline", "--no-adversarial", "--no-dist-extra", "--no-pipelined"],
+                          capture_output=True, text=True, timeout=600, cwd=root, env=env3)
+    assert out3.returncode == 0, out3.stderr[-2000:]
+    rec3 = json.loads([ln for ln in out3.stdout.splitlines() if ln.strip().startswith("{")][-1])
+    assert rec3["result_hex"] == rec["result_hex"]
+    assert rec3["config"]["collective"].startswith("gloo fallback (library RCCL preflight failed on rank 0: Fault")
+    assert rec3["config"]["rccl_version"].startswith("none (gloo fallback")
+
+
+def test_bench_pipelined_region_overlaps_two_requests(hip):
+    """Two MSMs in flight must buy something over one at a time (a copy stream created between `aux` and
+    the lanes' streams had put lanes 0 and 1 on one hardware queue -- 2.64-2.73 ms against 2.44-2.46, profiles/
+    r05_ab_pipelined_bisect.log).  Full size, the driver's K / W; the bound is loose (<= 1.02 x serial) so that only the
+    loss of the overlap trips it, not a box's noise."""
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+                          "--no-kzg-rows", "--no-adversarial", "--no-e2e"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][-1])
+    assert rec["config"]["points_per_gpu"] == 1 << 20
+    assert rec["pipelined"]["ms_per_step"] <= 1.02 * rec["ms_per_step"], (rec["pipelined"], rec["ms_per_step"])
+
+
+def test_bench_two_ranks_on_one_gpu_exercises_the_multi_rank_logic(hip):
+    """What a driver SCALE launch runs, with TWO real ranks: `torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`.
+    A one-GPU box cannot form an RCCL group of two, so both ranks share device 0 and exchange their partials through gloo
+    (BENCH_ONE_GPU / BENCH_BACKEND: self-test knobs): everything rank-dependent is real -- SRS segment r of the 2 n-point
+    SRS per rank, scalars of its index range, partial -> all_gather -> sum, the cross-rank equality checks, and the
+    `msm26` (strong scaling) and `pianist_kzg22` (one row per rank) objects of the same launch.  All three results are
+    compared with the oracle on the concatenated inputs."""
+    import subprocess
+    import sys
+
+    from bench import TAU, R_MOD, uniform_fr
+    from zkp_subnet_amd.engine import lagrange_factor
+
+    env = dict(os.environ, BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1", BENCH_COMM_INIT_TIMEOUT_S="60")
+    env.pop("BENCH_BACKEND", None)
+    args = ["--gpus", "2", "--log-n", "13", "--steps", "3", "--warmup", "1", "--msm26-log", "15", "--kzg22-log", "11",
+            "--cpu-sample-log", "12"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29561", os.path.join(ROOT, "bench.py")] + args
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    jl = [json.loads(ln) for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(jl) == 2 and "partial_line" in jl[0] and "msm26" in jl[1]     # headline first, the augmented line last
+    rec = jl[-1]
+    # RCCL refuses two ranks on one device: the library's preflight fails on every rank, all of them fall back to the
+    # gloo group's all_gather and the line says so -- a forced RCCL-init failure still yields a line (VERDICT r4 task 1c)
+    assert rec["config"]["collective"].startswith("gloo fallback (library RCCL preflight failed on rank 0")
+    assert set(rec["config"]["collective_detail"]["library_preflight_failed"]) == {"0", "1"}
+    assert rec["config"]["rccl_version"].startswith("none (gloo fallback")
+    # ... and the SAME line from `python bench.py --gpus 2` with NO launcher: the parent starts that launch line itself
+    # as a child before anything touches the GPU, relays it, and the JSON line is the last line of stdout
+    env2 = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                          timeout=900, cwd=ROOT, env=env2)
+    assert out2.returncode == 0, out2.stderr[-3000:]
+    assert sum(1 for ln in out2.stdout.splitlines() if ln.strip().startswith("{")) == 1    # the parent relays the LAST line only
+    rec2 = json.loads([ln for ln in out2.stdout.splitlines() if ln.strip()][-1])
+    assert rec2["n_gpus"] == 2 and rec2["config"]["world_size"] == 2 and "msm26" in rec2
+    for k in ("result_hex", "metric", "unit", "scaling", "steps", "warmup"):
+        assert rec2[k] == rec[k], k
+    assert rec2["msm26"]["result_hex"] == rec["msm26"]["result_hex"]
+    assert rec2["pianist_kzg22"]["results_hex_by_rank"] == rec["pianist_kzg22"]["results_hex_by_rank"]
+    for r_ in (rec, rec2):                          # rule (d) on an N > 1 line: roofline AND cpu_baseline
+        cb = r_["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["matches_gpu_bit_exact"] is True
+        assert r_["roofline"]["achieved"] > 0
+    assert rec["n_gpus"] == 2 and rec["config"]["world_size"] == 2 and rec["scaling"] == "weak"
+    assert abs(rec["value"] - 2 * (1 << 13) * 3 / (rec["ms_per_step"] * 3e-3)) / rec["value"] < 1e-6
+    e = hip()
+    # headline: 2 x 2^13 points, rank r = segment r, scalars seeded by the rank
+    e.gen_srs(TAU, 1, 14, 0)
+    want = oc.msm(e.srs_read(0, 1 << 14), uniform_fr(1 << 13, 0) + uniform_fr(1 << 13, 1), threads=4)
+    assert bytes.fromhex(rec["result_hex"]) == want
+    # msm26 object: ONE 2^15-point MSM in two segments
+    m26 = rec["msm26"]
+    assert m26["n_gpus"] == 2 and m26["points_per_gpu"] == 1 << 14 and m26["all_ranks_equal"] and m26["scaling"] == "strong"
+    e.gen_srs(TAU, 1, 15, 0)
+    want = oc.msm(e.srs_read(0, 1 << 15), uniform_fr(1 << 14, 1000) + uniform_fr(1 << 14, 1001), threads=4)
+    assert bytes.fromhex(m26["result_hex"]) == want
+    # pianist object: worker rows 0 and 1 of a 2-machine setup, one per rank, and their aggregated commitment
+    pk = rec["pianist_kzg22"]
+    assert pk["n_gpus"] == 2 and len(pk["results_hex_by_rank"]) == 2
+    alpha = uniform_fr(1, 1)
+    comms = []
+    for r in range(2):
+        e.gen_srs(TAU, 0, 12, 1, factors=[lagrange_factor(r, 1, (TAU * 7 + 1) % R_MOD)])
+        srs = e.srs_read(0, 1 << 11)
+        row = uniform_fr(1 << 11, r)
+        want = oc.commit(srs, row, True) + b"".join(oc.open_(srs, row, alpha, True))
+        assert bytes.fromhex(pk["results_hex_by_rank"][r]) == want, r
+        comms.append(want[:48])
+    assert bytes.fromhex(pk["aggregate_commitment_hex"]) == e.g1_sum_compressed(b"".join(comms))
+
+
+def test_bench_multi_rank_failures_never_cost_the_headline(hip):
+    """VERDICT r4 task 1: one rank's failure in an EXTRA workload must neither park the other ranks in a collective nor
+    lose the headline.  Two ranks on this one GPU (gloo control plane; the library's RCCL preflight fails on a shared
+    device and falls back), with a failure injected on rank 1
+      * while it builds the msm26 tables (an OOM would look like this): every rank learns of it through the store before
+        anybody enters a collective -> rc 0, headline, pianist_kzg22 measured, msm26 = {"error": "setup failed", ...};
+      * in the MIDDLE of msm26's timed loop: rank 0 is then alone in an all_gather, which times out (process-group timeout,
+        15 s here) -> rc 0, headline, msm26 = {"error": "timed region failed", ...}, the group marked unusable.
+    And the parent-side watchdog of the launcher-less form terminates a launch that overruns it, with a non-zero code."""
+    import subprocess
+    import sys
+
+    base = dict(os.environ, BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1", BENCH_COMM_INIT_TIMEOUT_S="60", BENCH_PG_TIMEOUT_S="15")
+    base.pop("BENCH_BACKEND", None)
+    args = ["--gpus", "2", "--log-n", "13", "--steps", "4", "--warmup", "1", "--msm26-log", "15", "--kzg22-log", "11",
+            "--no-cpu-baseline", "--no-pipelined"]
+
+    def launch(fault, port):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(base, BENCH_FAULT=fault))
+        assert out.returncode == 0, (fault, out.stderr[-3000:])
+        jl = [json.loads(ln) for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+        assert len(jl) == 2 and "partial_line" in jl[0] and jl[0]["value"] == jl[1]["value"] > 0
+        return jl[-1]
+
+    rec = launch("msm26_setup:1", 29571)
+    assert rec["msm26"]["error"] == "setup failed" and list(rec["msm26"]["ranks"]) == ["1"] and "injected fault" in rec["msm26"]["ranks"]["1"]
+    assert rec["pianist_kzg22"]["value"] > 0 and len(rec["pianist_kzg22"]["results_hex_by_rank"]) == 2
+    assert "process_group_note" not in rec
+    rec = launch("msm26_step:1", 29572)
+    assert rec["msm26"]["error"] == "timed region failed" and set(rec["msm26"]["ranks"]) == {"0", "1"}
+    assert "injected fault" in rec["msm26"]["ranks"]["1"] and rec["pianist_kzg22"]["value"] > 0
+    assert "msm26 failed inside its timed region" in rec["process_group_note"]
+    rec = launch("pianist_kzg22_setup:0", 29573)
+    assert rec["pianist_kzg22"]["error"] == "setup failed" and rec["msm26"]["value"] > 0 and rec["msm26"]["all_ranks_equal"]
+    # the watchdog of `python bench.py --gpus 2` (no launcher): half a second is not enough for two ranks to even import torch
+    env = {k: v for k, v in dict(base, BENCH_WATCHDOG_S="0.5").items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=300,
+                         cwd=ROOT, env=env)
+    assert out.returncode not in (0, 2) and "terminating it" in out.stderr and "killed by the watchdog" in out.stderr
+
+
+# ------------------------------------------------------------------ seeded fuzz slice + the reference's fault scenarios
+def test_seeded_fuzz_slice():
+    """A fixed-seed slice of tests/fuzz_gpu.py inside the driver's `pytest -m gpu` run (the hours of fuzzing under
+    profiles/*_fuzz_*.log are builder-side evidence only): 14 engine rounds of random size / window / slice -- every MSM
+    through the blocking, resident and ticketed entry points on uniform / small / edge / equal / clustered scalars, NTT
+    against the oracle and its round trip, commit / open / fused commit+open incl. alpha = 0, 1, omega^k, r - 1, the text
+    path with row-cache hits and one-coefficient mutations, the fused transform + evaluation.  A mismatch raises inside
+    run() naming its case; the floors make sure every kind really ran."""
+    from tests import fuzz_gpu
+
+    stats = fuzz_gpu.run(budget=600.0, seed=20261201, rounds=14, max_log=17)
+    assert stats["rounds"] == 14 and stats["msm"] == 42 and stats["ntt"] == 14 and stats["kzg"] == 28
+    assert stats["cache_hits"] >= 6 and stats["cache_misses_after_mutation"] >= 6
+    assert stats["cache_hits"] + stats["cache_misses_after_mutation"] == 28
+    assert stats["fused_from_text"] == 28 and stats["fused_from_text_streamed"] >= 4

@@ -1,7 +1,7 @@
 """CPU-only tests of the host side above the C-ABI: the Client method surface / status mapping, the miner and
 validator mirrors, and the config-1 plumbing loop (degree-2^12 commit through the CPU prover under a mock
 miner/validator loop, BASELINE.json configs[0]).  The engine is the oracle-backed stand-in (tests/oracle_engine.py);
-the same tests run against the HIP engine in tests/test_gpu_parity.py."""
+the same tests run against the HIP engine in tests/test_gpu_*.py."""
 import base64
 import os
 import random

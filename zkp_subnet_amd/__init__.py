@@ -6,4 +6,4 @@ See DESIGN.md for the hot path and INTEGRATION.md for the binding into the refer
 from ._native import KzgError, lib_available  # noqa: F401
 from .engine import HipEngine  # noqa: F401
 from .client import Client, Response  # noqa: F401
-from .multi import MultiDeviceClient  # noqa: F401
+from .multi import MultiDeviceClient, SegmentedMsm  # noqa: F401

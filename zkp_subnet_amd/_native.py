@@ -6,6 +6,12 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# Eight hardware queues instead of the HIP runtime's four, unless the user chose: the four lanes of a context then run
+# concurrently whatever the creation order of the process's streams (measured: profiles/r05_ab_hw_queues.log).  The runtime
+# reads the variable once, at its first call -- so it is set HERE, when this module is imported: before the package starts
+# a thread or touches HIP.  The library itself never writes the environment; it measures what it got (kzg_runtime_info) and
+# `Client.start` warns when the lanes do not overlap (HIP was initialised earlier by somebody else, or the user chose fewer).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # KZG_MI355X_LIB: another BUILD of the same library (A/B candidates under zkp_subnet_amd/ab/, the prototype build): dev
 # scripts point at it instead of overwriting the shipped file.  Never a different implementation, never a fallback.
 LIB_PATH = os.environ.get("KZG_MI355X_LIB") or os.path.join(HERE, "libkzg_mi355x.so")
@@ -24,12 +30,15 @@ SYMBOLS = {
     "kzg_destroy": (None, [_P]),
     "kzg_last_error": (ctypes.c_char_p, [_P]),
     "kzg_version": (ctypes.c_char_p, []),
+    "kzg_runtime_info": (_I, [_P, ctypes.POINTER(ctypes.c_int32)]),
     "kzg_set_window": (_I, [_P, _I]),
     "kzg_get_window": (_I, [_P]),
     "kzg_get_window_layout": (_I, [_P, ctypes.POINTER(ctypes.c_int32), _I]),
     "kzg_load_srs": (_I, [_P, _B, _U64, _I, _I]),
     "kzg_load_srs_compressed": (_I, [_P, _B, _U64, _I, _I]),
     "kzg_load_srs_file": (_I, [_P, _B, _I, _I, _I]),
+    "kzg_load_srs_file_slices": (_I, [_P, _B, _I, _I, _I, _U32, _U32]),
+    "kzg_load_srs_file_range": (_I, [_P, _B, _I, _U64, _U64, _I]),
     "kzg_get_load_stats": (_I, [_P, ctypes.POINTER(ctypes.c_double)]),
     "kzg_set_srs_subgroup_check": (_I, [_P, _I]),
     "kzg_gen_srs": (_I, [_P, _B, _B, _U32, _I, _I]),
@@ -61,12 +70,14 @@ SYMBOLS = {
     "kzg_msm_sharded_finish": (_I, [_P, _I, _P, _U32, _P, _B]),
     "kzg_comm_unique_id": (_I, [_B]),
     "kzg_comm_init": (_I, [_P, _B, _I, _I]),
+    "kzg_comm_init_bounded": (_I, [_P, _B, _I, _I, _I]),
     "kzg_comm_destroy": (_I, [_P]),
     "kzg_comm_set_timeout": (_I, [_P, _I]),
     "kzg_comm_info": (_I, [_P, ctypes.POINTER(ctypes.c_int32)]),
     "kzg_comm_selftest": (_I, [_P]),
     "kzg_msm_sharded": (_I, [_P, _I, _U64, _U64, _B]),
     "kzg_test_comm_stall": (_I, [_P, _I]),
+    "kzg_test_comm_stall_n": (_I, [_P, _I, _I]),
     "kzg_multi_create": (_I, [_I, ctypes.POINTER(_I), ctypes.POINTER(_P)]),
     "kzg_multi_destroy": (None, [_P]),
     "kzg_multi_last_error": (ctypes.c_char_p, [_P]),
@@ -75,6 +86,12 @@ SYMBOLS = {
     "kzg_multi_device_of": (_I, [_P, _U32]),
     "kzg_multi_load_srs_file": (_I, [_P, _B, _I, _I, _I]),
     "kzg_multi_gen_srs": (_I, [_P, _B, _B, _I, _I]),
+    "kzg_multi_load_srs_file_segments": (_I, [_P, _B, _I, _U64]),
+    "kzg_multi_gen_srs_segments": (_I, [_P, _B, _B, _U64]),
+    "kzg_multi_segment": (_I, [_P, _I, ctypes.POINTER(_U64)]),
+    "kzg_multi_msm": (_I, [_P, _B, _U64, _U64, _B]),
+    "kzg_multi_upload_fr": (_I, [_P, _I, _B, _U64, _U64]),
+    "kzg_multi_msm_resident": (_I, [_P, _I, _B]),
     "kzg_multi_commit": (_I, [_P, _U32, _B, _U64, _I, _B]),
     "kzg_multi_open": (_I, [_P, _U32, _B, _U64, _I, _B, _B, _B]),
     "kzg_multi_commit_open": (_I, [_P, _U32, _B, _U64, _I, _B, _B, _B, _B]),
@@ -127,10 +144,6 @@ def load() -> ctypes.CDLL:
                 f"{LIB_PATH} is missing: build it with `python -m zkp_subnet_amd.build` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
             )
-        # eight hardware queues instead of the runtime's four, unless the user chose: the four lanes of a context then run
-        # concurrently whatever the creation order of the process's streams (csrc/api.hip kzg_default_hw_queues; measured:
-        # profiles/r05_ab_hw_queues.log).  Read by the HIP runtime at its first call -- so set BEFORE the library loads.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

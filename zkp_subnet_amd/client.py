@@ -96,23 +96,44 @@ class Client:
             from .engine import HipEngine  # raises loudly without the HIP library / a gfx950 device
 
             self.engine = HipEngine(self.device)
+            info = self.engine.runtime_info()
+            if 0 < info["lanes_concurrent"] < info["lanes"]:
+                log.warning("only %d of the context's %d lanes run concurrently on this GPU (GPU_MAX_HW_QUEUES=%s%s): results "
+                            "are unaffected, but concurrent requests overlap less.  Export GPU_MAX_HW_QUEUES=8 before the "
+                            "process's first HIP call.", info["lanes_concurrent"], info["lanes"],
+                            info["hw_queues_env"] or "unset", ", HIP was already initialised when the library was loaded"
+                            if info["hip_live_at_load"] else "")
         if self.setup_path and os.path.exists(self.setup_path):
             rec = 96 if self.uncompressed else 48      # the reference's `uncompressed` flag (base/miner.py:77)
             if os.path.getsize(self.setup_path) % rec:
                 raise ValueError(f"setup file must be a whole number of {rec}-byte G1 points "
                                  f"(uncompressed={self.uncompressed})")
+            rec_points = os.path.getsize(self.setup_path) // rec
+            T = 1 << (scale - machines_scale)
+            file_slices = rec_points // T if rec_points % T == 0 else 0
+            # a client that serves only SOME worker indices (one device of a MultiDeviceClient: i = g mod G) loads only their
+            # slices when they form the progression first, first + stride, ... over the file's slices
+            prog = self._progression(file_slices) if self.workers is not None else None
+            load_slices = getattr(self.engine, "load_srs_file_slices", None)
             load_file = getattr(self.engine, "load_srs_file", None)
-            if load_file is not None:                  # HipEngine: the library maps the file and streams it itself
+            if prog is not None and load_slices is not None:
+                load_slices(self.setup_path, scale, machines_scale, prog[0], prog[1], compressed=not self.uncompressed)
+                self._slice_of = {w: k for k, w in enumerate(self.workers)}
+            elif load_file is not None:                # HipEngine: the library reads the file and streams it itself
                 load_file(self.setup_path, scale, machines_scale, compressed=not self.uncompressed)
+                self._slice_of = None
             else:                                      # an injected engine without a file loader (tests)
                 with open(self.setup_path, "rb") as f:
                     self.engine.load_srs(f.read(), scale, machines_scale, compressed=not self.uncompressed)
-            self._slice_of = None
+                self._slice_of = None
             vk_path = self.setup_path + ".vk"   # 192 B [tau_x]_2 (uncompressed) + one 96 B [L_i(tau_y)]_1 per slice
             if os.path.exists(vk_path) and hasattr(self.engine, "set_verifier_key"):
                 with open(vk_path, "rb") as f:
                     vk = f.read()
-                self.engine.set_verifier_key(vk[:192], vk[192:])
+                li = vk[192:]
+                if self._slice_of is not None:         # the key's factors in RESIDENT slice order
+                    li = b"".join(li[96 * w:96 * w + 96] for w in self.workers)
+                self.engine.set_verifier_key(vk[:192], li)
         else:
             if not self.synthetic:
                 if self._own_engine:
@@ -129,6 +150,17 @@ class Client:
             self.tau_x, self.tau_y = tau_x, tau_y
             self.engine.gen_srs(tau_x, tau_y, scale, machines_scale, self.workers)
             self._slice_of = {w: k for k, w in enumerate(self.workers)} if self.workers is not None else None
+
+    def _progression(self, file_slices: int):
+        """(first, stride) when self.workers is exactly first, first + stride, ... below file_slices; else None."""
+        w = self.workers
+        if not w or file_slices <= 0:
+            return None
+        first = w[0]
+        stride = (w[1] - w[0]) if len(w) > 1 else max(1, file_slices)
+        if stride <= 0 or list(w) != list(range(first, file_slices, stride)):
+            return None
+        return first, stride
 
     def stop(self) -> None:
         if self.engine is not None and self._own_engine:

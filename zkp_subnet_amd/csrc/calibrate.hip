@@ -35,3 +35,22 @@ void launch_calibrate_mad(hipStream_t s, uint64_t* out, uint32_t blocks, uint32_
     hipLaunchKernelGGL(k_calibrate_mad, dim3(blocks), dim3(256), 0, s, out, 7u, iters);
 }
 int calibrate_unroll() { return CAL_UNROLL; }
+
+// ---- do two lanes of a context really run side by side?  (kzg_runtime_info)  The HIP runtime maps a process's streams onto
+// GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, and kernels of two streams that share a queue execute
+// one after the other.  One single-wave kernel per lane spins for `ticks` of the constant-rate wall clock and leaves its
+// first and last reading: overlapping intervals = concurrent lanes.  Bounded: at most 2^22 polls whatever the clock does.
+__global__ void __launch_bounds__(64) k_spin_probe(uint64_t* __restrict__ out2, uint64_t ticks) {
+    if (threadIdx.x) return;
+    const uint64_t t0 = wall_clock64();
+    uint64_t t1 = t0;
+    for (uint32_t i = 0; i < (1u << 22) && t1 - t0 < ticks; i++) {
+        __builtin_amdgcn_s_sleep(16);
+        t1 = wall_clock64();
+    }
+    out2[0] = t0;
+    out2[1] = t1;
+}
+void launch_spin_probe(hipStream_t s, uint64_t* out2, uint64_t ticks) {
+    hipLaunchKernelGGL(k_spin_probe, dim3(1), dim3(64), 0, s, out2, ticks);
+}

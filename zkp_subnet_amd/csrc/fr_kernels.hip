@@ -774,46 +774,6 @@ KZG_DEV void pq_row_load(fr9_t& v, const uint4* row, int k) {
     const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     fr9_from_words(v, w);
 }
-// h[t] = sum_k f[16 t + k] alpha^k for the 64 chunks of this workgroup; n a multiple of 1024
-template <bool ARG>
-__global__ void __launch_bounds__(64) k_poly_chunk_eval16_lds(const uint32_t* __restrict__ f,
-                                                               const uint32_t* __restrict__ alpha_mont,
-                                                               uint32_t* __restrict__ h, const FrArg arg,
-                                                               uint32_t* __restrict__ alpha_out, uint32_t* __restrict__ bad) {
-    __shared__ uint4 sm[64][PQ_ROW];
-    const uint32_t lane = threadIdx.x;
-    const uint64_t chunk0 = (uint64_t)blockIdx.x * 64;
-    const uint4* src = reinterpret_cast<const uint4*>(f) + chunk0 * 32;
-    fr9_t a, s, c;
-    if constexpr (ARG) {
-        uint32_t w[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) w[i] = bswap32(arg.w[7 - i]);
-        fr9_from_words(a, w);
-        fr9_to_mont(a, a);
-        if (chunk0 + lane == 0) {
-            if (fr_words_ge_r(w)) atomicOr(bad, 1u);
-            fr9_store(alpha_out, a);
-        }
-    } else {
-        fr9_load(a, alpha_mont);
-    }
-    fr9_canon(a, a);
-    fr9_zero(s);
-    for (int ph = 0; ph < PQ_PHASES; ph++) {
-        pq_load_part(sm, src, (uint32_t)(PQ_PHASES - 1 - ph) * 2 * PQ_CO, lane);   // the top coefficients first: Horner runs downward
-        __syncthreads();
-#pragma unroll 2
-        for (int k = PQ_CO - 1; k >= 0; k--) {
-            pq_row_load(c, sm[lane], k);
-            fr9_mul(s, s, a);
-            fr9_add(s, s, c);
-        }
-        __syncthreads();
-    }
-    fr9_reduce(s, s);
-    fr9_store(h + 8 * (chunk0 + lane), s);
-}
 // q[j-1] = sum_{k>=j} f_k alpha^(k-j), canonical, for the 1024 coefficients of this workgroup; q[n-1] = 0
 __global__ void __launch_bounds__(64) k_poly_quotient16_lds(const uint32_t* __restrict__ f, uint64_t n,
                                                              const uint32_t* __restrict__ alpha_mont,
@@ -1010,13 +970,8 @@ void launch_poly_open(hipStream_t s, const uint32_t* f_mont, uint64_t n, uint32_
     // is pure latency).  KZG_POLY_LDS_MIN_LOG moves the threshold.
     static const int lds_min_log = getenv("KZG_POLY_LDS_MIN_LOG") ? atoi(getenv("KZG_POLY_LDS_MIN_LOG")) : 21;
     const bool lds = !no_lds && l0 == 4 && (n & 1023) == 0 && n >= ((uint64_t)1 << lds_min_log);
-    static const bool eval_lds = getenv("KZG_POLY_EVAL_LDS") != nullptr;   // A/B: the level-0 fold staged too (measured: no gain)
-    if (lds && eval_lds) {
-        if (alpha_be32_host)
-            k_poly_chunk_eval16_lds<true><<<(uint32_t)(n >> 10), 64, 0, s>>>(f_mont, alpha_mont, h, arg, alpha_mont, bad);
-        else
-            k_poly_chunk_eval16_lds<false><<<(uint32_t)(n >> 10), 64, 0, s>>>(f_mont, alpha_mont, h, arg, nullptr, nullptr);
-    } else if (alpha_be32_host)
+    // (the level-0 fold gains nothing from LDS staging: 53 against 49 us, profiles/r04_ab_opening_lds_staging.log -- strided)
+    if (alpha_be32_host)
         k_poly_chunk_eval<true><<<nblk(lv_n[1], 256), 256, 0, s>>>(f_mont, n, l0, alpha_mont, 0, h, arg, alpha_mont, bad);
     else
         k_poly_chunk_eval<false><<<nblk(lv_n[1], 256), 256, 0, s>>>(f_mont, n, l0, alpha_mont, 0, h, arg, nullptr, nullptr);

@@ -651,20 +651,10 @@ __global__ void __launch_bounds__(256, KZG_ACC_MIN_WAVES) k_msm_accumulate(const
     uint32_t my_carry_key = NONE_KEY;
     g1_xyzz_t acc;
     g1_set_inf(acc);
-    // KZG_EXP_L2_RESIDENT (a TIMING build, scripts/exp_traffic_clock.py; results are garbage): every row index is masked to
-    // the first 2^14 points of window table 0 -- 2 MB, resident in L2 / Infinity Cache -- so that the kernel runs the same
-    // instruction stream without its 2.2 GB of gathered HBM traffic: does that traffic cost clock or time?
-#if defined(KZG_EXP_L2_RESIDENT) && KZG_EXP_L2_RESIDENT == 25
-#define KZG_ROW_INDEX(v) ((((v) & 3u) == 0u) ? ((v) & 0x3fffu) : ((v) & 0x7fffffffu))   // every fourth row only: -25 % of the gather
-#elif defined(KZG_EXP_L2_RESIDENT)
-#define KZG_ROW_INDEX(v) ((v) & 0x3fffu)
-#else
-#define KZG_ROW_INDEX(v) ((v) & 0x7fffffffu)
-#endif
     uint32_t v_cur = sorted[lo];
     uint32_t w_cur[28];
     {
-        const uint4* q = reinterpret_cast<const uint4*>(table + KZG_ROW_INDEX(v_cur));
+        const uint4* q = reinterpret_cast<const uint4*>(table + (v_cur & 0x7fffffffu));
 #pragma unroll
         for (int i = 0; i < 7; i++) { uint4 t4 = q[i]; w_cur[4*i]=t4.x; w_cur[4*i+1]=t4.y; w_cur[4*i+2]=t4.z; w_cur[4*i+3]=t4.w; }
     }
@@ -695,7 +685,7 @@ __global__ void __launch_bounds__(256, KZG_ACC_MIN_WAVES) k_msm_accumulate(const
         uint32_t wn[28];
         const uint32_t vn = (e + 1 < hi) ? sorted[e + 1] : v_cur;
         {
-            const uint4* q = reinterpret_cast<const uint4*>(table + KZG_ROW_INDEX(vn));
+            const uint4* q = reinterpret_cast<const uint4*>(table + (vn & 0x7fffffffu));
 #pragma unroll
             for (int i = 0; i < 7; i++) { uint4 t4 = q[i]; wn[4*i]=t4.x; wn[4*i+1]=t4.y; wn[4*i+2]=t4.z; wn[4*i+3]=t4.w; }
         }
@@ -1851,12 +1841,8 @@ static void sort_shape(const MsmShape& sh, const uint32_t* scalars2, int scalars
     const uint64_t entries = ss.total * (uint64_t)sh.nwin;
     int hbits = 10;
     // short inputs: fewer partitions (down to 64) as long as one holds < 4096 entries --
-    // 1024 workgroups of 1024 threads for ~200 entries each were four rounds of launch overhead (A/B knob KZG_SORT_MIN_HBITS)
-    static const int min_hbits = [] {
-        const char* e = getenv("KZG_SORT_MIN_HBITS");
-        const int v = e ? atoi(e) : 6;
-        return v < 4 ? 4 : v > 10 ? 10 : v;
-    }();
+    // 1024 workgroups of 1024 threads for ~200 entries each were four rounds of launch overhead
+    const int min_hbits = 6;
     while (hbits > min_hbits && (entries >> hbits) < 4096) hbits--;
     while (hbits < 12 && (entries >> hbits) > 24576) hbits++;
     if (hbits > keybits) hbits = keybits;
@@ -1974,8 +1960,7 @@ bool msm_fold_bucket_ok(uint32_t nbuckets, uint32_t max_run) {
     (void)nbuckets; (void)max_run;
     return false;
 #else
-    static const bool off = getenv("KZG_FOLD_NO_BUCKET") != nullptr;   // A/B knob
-    return !off && nbuckets <= KZG_FOLD_BUCKET_MAX && max_run <= KZG_FOLD_BUCKET_RUN;
+    return nbuckets <= KZG_FOLD_BUCKET_MAX && max_run <= KZG_FOLD_BUCKET_RUN;
 #endif
 }
 void launch_fold_bucket(hipStream_t s, const uint32_t* offsets, uint32_t chunk, uint32_t nbuckets, const g1_xyzz_t* carries,
@@ -2009,8 +1994,7 @@ bool msm_tree_level2_ok(uint32_t n_in_nodes, int level) {
     (void)n_in_nodes; (void)level;
     return false;
 #else
-    static const bool off = getenv("KZG_TREE_NO_PAIRS") != nullptr;   // A/B knob
-    return !off && n_in_nodes >= 4 && (n_in_nodes >> 1) * (uint32_t)(level + 1) <= LP_MAX_OPS;
+    return n_in_nodes >= 4 && (n_in_nodes >> 1) * (uint32_t)(level + 1) <= LP_MAX_OPS;
 #endif
 }
 void launch_msm_tree_level2(hipStream_t s, const g1_xyzz_t* in, const g1_xyzz_t* prev, g1_xyzz_t* mid_p, g1_xyzz_t* out,

@@ -44,13 +44,15 @@ class LibraryGather:
     host wait.  torch.distributed (any backend) is only the rendezvous: rank 0 draws the RCCL unique id and the process
     group's object broadcast carries its 128 bytes.  `DeviceGather` below is the torch-collective form kept as the A/B.
 
-    `init_timeout_s`: ncclCommInitRank blocks in native code until every rank has joined; it runs on a helper thread so
-    that a rank whose peers never arrive raises TimeoutError here instead of hanging for ever."""
+    `init_timeout_s`: ncclCommInitRank blocks in native code until every rank has joined; the LIBRARY bounds it
+    (kzg_comm_init_bounded: the rendezvous and a first checked all_gather run on a helper thread that holds nothing of the
+    context), so a rank whose peers never arrive raises TimeoutError here and its engine keeps working -- every other call,
+    `close()` and interpreter exit included."""
 
     def __init__(self, engine, group=None, timeout_ms: int = 0, init_timeout_s: float = 120.0):
-        import threading
-
         import torch.distributed as dist
+
+        from ._native import KZG_E_COMM, KzgError
 
         self.engine = engine
         self.world = dist.get_world_size(group)
@@ -64,21 +66,12 @@ class LibraryGather:
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         if isinstance(box[0], Exception):
             raise box[0]
-        err = []
-
-        def join():
-            try:
-                engine.comm_init(box[0], rank, self.world, timeout_ms)
-            except Exception as e:               # noqa: BLE001
-                err.append(e)
-
-        t = threading.Thread(target=join, name="kzg-comm-init", daemon=True)
-        t.start()
-        t.join(init_timeout_s)
-        if t.is_alive():
-            raise TimeoutError(f"kzg_comm_init: the {self.world} ranks did not all join within {init_timeout_s:.0f} s")
-        if err:
-            raise err[0]
+        try:
+            engine.comm_init(box[0], rank, self.world, timeout_ms, init_timeout_ms=max(1, int(init_timeout_s * 1000)))
+        except KzgError as e:
+            if e.code == KZG_E_COMM and "did not all join" in str(e):
+                raise TimeoutError(f"kzg_comm_init: the {self.world} ranks did not all join within {init_timeout_s:.0f} s") from e
+            raise
         self.info = engine.comm_info()
 
     def msm(self, slot: int, n: int, srs_offset: int = 0) -> bytes:

@@ -67,6 +67,13 @@ class HipEngine:
         except Exception:
             pass
 
+    def runtime_info(self) -> Dict[str, int]:
+        """What kzg_create measured: lanes of the context, how many of them really run concurrently (hardware queues),
+        whether a HIP runtime was already live when the library was loaded, GPU_MAX_HW_QUEUES as seen (0 = unset)."""
+        arr = (ctypes.c_int32 * 4)()
+        self._chk(self._lib.kzg_runtime_info(self._h, arr))
+        return {"lanes": arr[0], "lanes_concurrent": arr[1], "hip_live_at_load": bool(arr[2]), "hw_queues_env": arr[3]}
+
     @property
     def window(self) -> int:
         return self._lib.kzg_get_window(self._h)
@@ -103,6 +110,22 @@ class HipEngine:
         pread(2) straight into two pinned tiles (host read, upload and GPU decode overlap), never into Python memory."""
         self._chk(self._lib.kzg_load_srs_file(self._h, os.fsencode(path), int(compressed), scale, machines_scale))
         self.scale, self.machines_scale = scale, machines_scale
+        self.verifier = None
+
+    def load_srs_file_slices(self, path: str, scale: int, machines_scale: int, first_slice: int, slice_stride: int,
+                             compressed: bool = False) -> None:
+        """Only the slices one device of a multi-GPU host serves: resident slice k = file slice first_slice + k * stride
+        (worker i = g mod G on device g).  pread touches just those byte ranges (kzg_load_srs_file_slices)."""
+        self._chk(self._lib.kzg_load_srs_file_slices(self._h, os.fsencode(path), int(compressed), scale, machines_scale,
+                                                     first_slice, slice_stride))
+        self.scale, self.machines_scale = scale, machines_scale
+        self.verifier = None
+
+    def load_srs_file_range(self, path: str, first_point: int, n_points: int, compressed: bool = False) -> None:
+        """One contiguous segment of a flat SRS file as a single resident slice (kzg_load_srs_file_range)."""
+        scale = max(0, (n_points - 1).bit_length())
+        self._chk(self._lib.kzg_load_srs_file_range(self._h, os.fsencode(path), int(compressed), first_point, n_points, scale))
+        self.scale, self.machines_scale = scale, 0
         self.verifier = None
 
     def set_srs_subgroup_check(self, enable: bool) -> None:
@@ -369,11 +392,14 @@ class HipEngine:
             raise KzgError(rc, lib.kzg_last_error(None).decode(errors="replace"))
         return out.raw
 
-    def comm_init(self, unique_id: bytes, rank: int, world: int, timeout_ms: int = 0) -> None:
-        """Joins the `world`-rank RCCL communicator on this context's GPU (collective: returns when every rank has joined)."""
+    def comm_init(self, unique_id: bytes, rank: int, world: int, timeout_ms: int = 0, init_timeout_ms: int = 0) -> None:
+        """Joins the `world`-rank RCCL communicator on this context's GPU (collective: returns when every rank has joined
+        and a first checked all_gather has connected them).  `init_timeout_ms` > 0 bounds that rendezvous in the library
+        (kzg_comm_init_bounded): peers that never arrive raise KzgError(E_COMM) and the engine stays usable.
+        `timeout_ms` is the per-call budget of every later sharded MSM."""
         if len(unique_id) != 128:
             raise ValueError("the RCCL unique id is 128 bytes")
-        self._chk(self._lib.kzg_comm_init(self._h, unique_id, rank, world))
+        self._chk(self._lib.kzg_comm_init_bounded(self._h, unique_id, rank, world, int(init_timeout_ms)))
         if timeout_ms:
             self._chk(self._lib.kzg_comm_set_timeout(self._h, timeout_ms))
 

@@ -11,8 +11,12 @@ sends row i to miner i (reference neurons/validator.py:194-222) and each miner p
   * a validator's step:  the 2^machines_scale `eval(fft(poly[i], inverse), alpha)` rows of `generate_challenge`
                          (neurons/validator.py:106-120) spread round-robin over the devices (`fft_eval_rows`).
 
-Every device holds the setup it needs: with a setup file each context loads the whole file (mainnet: 34 GB of tables
-per GPU, of 288); with a synthetic seed each context generates only the slices routed to it.  SURVEY 8b proposed
+Every device holds exactly the setup it serves: from a setup file each context reads, checks and tabulates only the slices
+of its own worker indices (`kzg_load_srs_file_slices`: mainnet 24 / 8 on G GPUs = 34 / G GB of tables and ~1 / G of the
+start time each); with a synthetic seed each context generates only the slices routed to it.
+
+`SegmentedMsm` (below) is the other way to use the GPUs of one process: ONE multi-scalar multiplication over a flat SRS cut
+into G contiguous segments, one per GPU (BASELINE.json configs[3] from behind the one-client seam; `kzg_multi_msm`).  SURVEY 8b proposed
 `kzg_create(device_count, device_ids)`: the C-ABI has that router too (`kzg_multi_*`, csrc/multi_host.cpp, for native
 callers working on bytes); this class is the same routing one level up, where the text codec and the Client surface live."""
 from __future__ import annotations
@@ -49,9 +53,8 @@ class MultiDeviceClient:
         try:
             for g, dev in enumerate(self.devices):
                 kw = dict(self._kw)
-                synthetic = kw["synthetic"] if kw["synthetic"] is not None else kw["seed"] is not None
-                # a synthetic setup generates only the slices this device serves; a setup file is loaded whole
-                workers = [i for i in range(M) if i % G == g] if synthetic and not kw["setup_path"] else None
+                # only the slices this device serves: generated (synthetic) or read from the setup file (kzg_load_srs_file_slices)
+                workers = [i for i in range(M) if i % G == g]
                 c = Client(device=dev, workers=workers, engine=self._engines[g] if self._engines else None, **kw)
                 c.start(scale, machines_scale)
                 started.append(c)
@@ -155,6 +158,85 @@ class MultiDeviceClient:
 
     def aggregate_commitments(self, commitments: Sequence[str]):
         return self._any().aggregate_commitments(commitments)     # a sum of points: no slice involved, any device
+
+
+class SegmentedMsm:
+    """ONE MSM over the G GPUs of this process (C-ABI `kzg_multi_*`, SEGMENTS layout): a flat SRS of `n_points` is cut into G
+    contiguous segments, segment g resident on devices[g]; `msm` runs the G partial MSMs concurrently, each on its own
+    device and lane, and sums the G 192-byte partials once.  No collective: the whole exchange is G x 192 bytes through the
+    host.  Results are bit-identical to `HipEngine.msm` over the same points on one device.  (The reference has no
+    device-level distribution at all -- one prover client per process, base/miner.py:73-84 -- this is BASELINE.json
+    configs[3] reachable from one process; with one process per GPU the same step is `kzg_msm_sharded` over RCCL.)"""
+
+    def __init__(self, devices: Sequence[int]):
+        import ctypes
+
+        from . import _native
+
+        self._ct, self._lib = ctypes, _native.load()
+        self.devices = list(devices)
+        ids = (ctypes.c_int * len(self.devices))(*self.devices)
+        h = ctypes.c_void_p()
+        rc = self._lib.kzg_multi_create(len(self.devices), ids, ctypes.byref(h))
+        if rc != 0:
+            raise _native.KzgError(rc, self._lib.kzg_multi_last_error(None).decode(errors="replace"))
+        self._h = h
+        self.n_points = 0
+
+    def _chk(self, rc: int) -> None:
+        if rc != 0:
+            from ._native import KzgError
+
+            raise KzgError(rc, self._lib.kzg_multi_last_error(self._h).decode(errors="replace"))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.kzg_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shard(self, n_points: int, g: int):
+        from .distributed import shard_range
+
+        return shard_range(n_points, g, len(self.devices))
+
+    def gen_srs(self, tau: int, n_points: int) -> None:
+        """Synthetic flat SRS, point j = [tau^j] G (tests / benches: public trapdoor)."""
+        from .engine import R_MODULUS
+
+        s0 = b"".join(pow(tau, self.shard(n_points, g)[0], R_MODULUS).to_bytes(32, "big") for g in range(len(self.devices)))
+        self._chk(self._lib.kzg_multi_gen_srs_segments(self._h, (tau % R_MODULUS).to_bytes(32, "big"), s0, n_points))
+        self.n_points = n_points
+
+    def load_srs_file(self, path: str, n_points: int, compressed: bool = False) -> None:
+        """Device g reads only file points [lo_g, lo_g + n_g) (pread of that byte range)."""
+        import os
+
+        self._chk(self._lib.kzg_multi_load_srs_file_segments(self._h, os.fsencode(path), int(compressed), n_points))
+        self.n_points = n_points
+
+    def segment(self, g: int):
+        arr = (self._ct.c_uint64 * 2)()
+        self._chk(self._lib.kzg_multi_segment(self._h, g, arr))
+        return int(arr[0]), int(arr[1])
+
+    def msm(self, scalars_be32: bytes, srs_offset: int = 0) -> bytes:
+        out = self._ct.create_string_buffer(48)
+        self._chk(self._lib.kzg_multi_msm(self._h, scalars_be32, len(scalars_be32) // 32, srs_offset, out))
+        return out.raw
+
+    def upload(self, slot: int, scalars_be32: bytes, srs_offset: int = 0) -> None:
+        self._chk(self._lib.kzg_multi_upload_fr(self._h, slot, scalars_be32, len(scalars_be32) // 32, srs_offset))
+
+    def msm_resident(self, slot: int) -> bytes:
+        out = self._ct.create_string_buffer(48)
+        self._chk(self._lib.kzg_multi_msm_resident(self._h, slot, out))
+        return out.raw
 
 
 _NOT_STARTED = Client(engine=None)      # engine None -> every call answers 503 "prover not started", as Client does
