@@ -546,8 +546,9 @@ def source_sha16(root=ROOT):
 
 
 def identity():
-    """Who measured this line: library version, git head (when the tree has a .git or the launcher left `.git_head`),
-    sha256[:16] of bench.py and of the whole source set.  scripts/evidence_keep.py refuses a file whose source_sha16 is not
+    """Who measured this line: library version, git head (when the tree has a .git: a gpurun snapshot has none, and a
+    side file would go stale -- the content hash below is the identity that always exists), sha256[:16] of bench.py and of
+    the whole source set.  scripts/evidence_keep.py refuses a file whose source_sha16 is not
     the tree's; no two rounds' evidence files can be byte-identical."""
     import hashlib
     import subprocess
@@ -565,12 +566,6 @@ def identity():
                 head += "+dirty"
     except (OSError, subprocess.TimeoutExpired):
         pass
-    if head is None:
-        try:
-            with open(os.path.join(ROOT, ".git_head")) as f:
-                head = f.read().strip() or None
-        except OSError:
-            pass
     with open(os.path.abspath(__file__), "rb") as f:
         bsha = hashlib.sha256(f.read()).hexdigest()[:16]
     return {"lib_version": _native.load().kzg_version().decode(), "git_head": head, "bench_py_sha16": bsha,
@@ -959,7 +954,7 @@ def main():
         state["depth"], state["gather"] = 2, None
         # >= 32 steps of the same load first (>= 80 ms at 2^20): the clocks need ~40 ms, and this region used to be the cold
         # one of the run.  A COUNT, never a duration: with N > 1 every step holds a collective, so all
-        # ranks must run the same number of them.  Reported as `pre_warm_steps`.
+        # ranks must run the same number of them.  Reported as `msms_before_region`.
         pipe_warm = max(args.warmup, 32)
         run_steps(pipe_warm, False)
         barrier()
@@ -970,8 +965,8 @@ def main():
         state["depth"], state["gather"] = 1, gather_step
         pipe_s = ctl.max_over_ranks(pipe_s)
         pipelined = {"requests_in_flight": 2, "value": n_total * args.steps / pipe_s, "unit": "points/s",
-                     "ms_per_step": pipe_s / args.steps * 1e3, "pre_warm_steps": pipe_warm}
-    pre_warm_steps = len(results)          # MSMs this GPU ran before the declared warm-up (the `pipelined` measurement)
+                     "ms_per_step": pipe_s / args.steps * 1e3, "msms_before_region": pipe_warm}
+    msms_before = len(results)             # MSMs this GPU ran before the declared warm-up (the `pipelined` measurement)
     run_steps(args.warmup, False)
     results.clear()
     step_ms.clear()
@@ -1093,9 +1088,10 @@ def main():
                        "parallelism": "single GPU" if world == 1 else
                        (f"SRS-sharded x{world}, all_gather of 192 B partials" if is_msm
                         else f"Pianist segments x{world}, no exchange")},
-            "pre_warm_steps": pre_warm_steps,
-            "pre_warm_note": "MSMs this GPU ran BEFORE the W declared warm-up steps (the `pipelined` measurement, taken first so "
-                             "that the one-at-a-time region starts on warm clocks)",
+            # `warmup` is the W the contract declares; what really preceded the timed region on this GPU is this count
+            "msms_before_timed_region": msms_before + args.warmup,
+            "msms_before_timed_region_note": "MSMs this GPU ran before the K timed steps: the `pipelined` measurement (taken first "
+                                             "so that the one-at-a-time region starts on warm clocks) + the W declared warm-up steps",
             "identity": identity(),
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
@@ -1192,6 +1188,7 @@ def main():
                                           for th, r in sorted(rates.items())),
                     "points_per_s_by_threads": {str(th): r for th, r in sorted(rates.items())},
                     "single_thread_points_per_s": rates.get(1),
+                    "note": "plain-C stand-in (oracle/kzg_cpu.c, __int128 limbs); an asm-backed Pippenger (blst-class, what the reference's Rust prover most likely links) is expected to be 1.5-2x faster per core -- the GPU/CPU ratio is an upper estimate",
                     "matches_gpu_bit_exact": cpu_res == gpu_same,
                 }
                 assert cpu_res == gpu_same, "GPU MSM differs from the CPU oracle on the baseline sample"
@@ -1213,6 +1210,7 @@ def main():
                     "sample": f"commit+open of the first 2^{m.bit_length() - 1} coefficients of the same row{where} "
                               f"(oracle/kzg_cpu.c; {hw}); seconds by thread count: "
                               + ", ".join(f"{th}: {s:.3f}" for th, s in sorted(per.items())),
+                    "note": "plain-C stand-in (oracle/kzg_cpu.c, __int128 limbs); an asm-backed Pippenger (blst-class, what the reference's Rust prover most likely links) is expected to be 1.5-2x faster per core -- the GPU/CPU ratio is an upper estimate",
                     "matches_gpu_bit_exact": cpu_res == tuple(gpu_same)}
                 assert cpu_res == tuple(gpu_same), "GPU commit+open differs from the CPU oracle on the baseline sample"
         if use_dist:
