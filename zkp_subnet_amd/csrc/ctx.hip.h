@@ -144,7 +144,6 @@ struct Lane {
     bool sort_ws_clean = false;   // the sort's partition counts are zero (left so by every completed sort)
     int skew_hint = 0;            // > 0: the last fast sort overflowed (skewed scalars): go straight to the exact sort
     hipEvent_t ev_sorted = nullptr, ev_done = nullptr, ev_coeffs = nullptr, ev_ext = nullptr;
-    hipEvent_t ev_half = nullptr, ev_lo = nullptr;   // the bucket-range split experiment (pipeline.hip, KZG_EXP_ACC_SPLIT builds)
     const uint8_t* in_be_src = nullptr;   // where upload_fr found the request's big-endian row on the device (in_be or a staging twin)
     hipStream_t vstream = nullptr;   // row-cache hits: upload of the caller's row + its comparison with the cached one,
     hipEvent_t ev_verify = nullptr;  // beside the request's own kernels (the lane's publish waits for this event)

@@ -293,8 +293,6 @@ int kzg_create(int device_id, kzg_ctx** out) {
              hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&L.ev_coeffs, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&L.ev_ext, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&L.ev_half, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&L.ev_lo, hipEventDisableTiming) == hipSuccess &&
              hipStreamCreateWithFlags(&L.vstream, hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&L.ev_verify, hipEventDisableTiming) == hipSuccess;
     }
@@ -334,7 +332,7 @@ void kzg_destroy(kzg_ctx* ctx) {
                           &L.comm_send, &L.comm_recv})
             b->release();
         for (hipEvent_t e : L.ev_pool) (void)hipEventDestroy(e);
-        for (hipEvent_t e : {L.ev_sorted, L.ev_done, L.ev_coeffs, L.ev_ext, L.ev_half, L.ev_lo, L.ev_verify})
+        for (hipEvent_t e : {L.ev_sorted, L.ev_done, L.ev_coeffs, L.ev_ext, L.ev_verify})
             if (e) (void)hipEventDestroy(e);
         if (L.vstream) (void)hipStreamDestroy(L.vstream);
         if (L.tail) (void)hipFree(L.tail);

@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(1024) k_sort_partition_staged_multi(const uint
 // carry run goes into *max_len, and the LAST workgroup to arrive (device-scope ticket) hands {max_len, overflow} to the
 // host page and then sets its sequence word -- what a k_publish launch behind the sort did.
 KZG_DEV void sort_tail_publish(const SortTail& tail, uint32_t npart, uint32_t blk_len, uint32_t* max_len,
-                               const uint32_t* overflow, uint32_t* done, uint32_t half_entry) {
+                               const uint32_t* overflow, uint32_t* done) {
     __syncthreads();   // every thread's part of this workgroup is done
     if (threadIdx.x == 0) {
         // No fences here: a release fence is a write-back of the XCD's whole L2, which the sort has just filled with
@@ -432,9 +432,6 @@ KZG_DEV void sort_tail_publish(const SortTail& tail, uint32_t npart, uint32_t bl
             // (vmcnt), and only then the sequence word follows them over the same ordered path
             __hip_atomic_store(&tail.pin_dst[0], ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&tail.pin_dst[1], ov, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            // [2]: where the upper half of the bucket range begins in the sorted entries (= offsets[nbuckets / 2]; it comes
-            // from the partition bounds, which an EARLIER kernel wrote)
-            __hip_atomic_store(&tail.pin_dst[2], half_entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(tail.seq_word, tail.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -467,7 +464,7 @@ __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__
     if (region_cap && *overflow) {
         for (uint32_t i = t; i < nb; i += 1024) offsets[((uint64_t)q << lbits) + i] = 0;
         if (q == npart - 1 && t == 0) offsets[(uint64_t)npart << lbits] = 0;
-        if (tail.buckets) sort_tail_publish(tail, npart, 0u, max_len, overflow, done, 0u);
+        if (tail.buckets) sort_tail_publish(tail, npart, 0u, max_len, overflow, done);
         return;
     }
     // entry e of the output range [lo, hi) lies at parted[e] (exact mode) or at its region's start + (e - lo)
@@ -613,7 +610,7 @@ __global__ void __launch_bounds__(1024) k_sort_buckets(const uint2* __restrict__
             __syncthreads();
         }
     }
-    if (tail.buckets) sort_tail_publish(tail, npart, blk_len, max_len, overflow, done, part_base[npart >> 1]);
+    if (tail.buckets) sort_tail_publish(tail, npart, blk_len, max_len, overflow, done);
 }
 
 // ------------------------------------------------------------------------------------------------ accumulate
@@ -638,8 +635,8 @@ __global__ void __launch_bounds__(256, KZG_ACC_MIN_WAVES) k_msm_accumulate(const
                                                          uint32_t chunk, uint32_t nchunks,
                                                          g1_xyzz_t* __restrict__ buckets,
                                                          g1_xyzz_t* __restrict__ carries,
-                                                         uint32_t* __restrict__ carry_key, uint32_t t_base) {
-    const uint32_t t = t_base + blockIdx.x * blockDim.x + threadIdx.x;   // (t_base: a launch over the lanes [t_base, nchunks) only)
+                                                         uint32_t* __restrict__ carry_key) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nchunks) return;
     const uint32_t total = offsets[nbuckets];
     const uint32_t lo = t * chunk;
@@ -751,14 +748,12 @@ __global__ void __launch_bounds__(256) k_fold_maxlen(const uint32_t* __restrict_
 }
 __global__ void __launch_bounds__(256) k_fold_step(const uint32_t* __restrict__ offsets,
                                                     const uint32_t* __restrict__ carry_key, uint32_t chunk,
-                                                    uint32_t nchunks, uint32_t d, g1_xyzz_t* __restrict__ carries,
-                                                    uint32_t key_lo, uint32_t key_hi) {
+                                                    uint32_t nchunks, uint32_t d, g1_xyzz_t* __restrict__ carries) {
     tail_priority();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nchunks) return;
     uint32_t key, i, len;
     if (!carry_pos(offsets, carry_key, chunk, t, key, i, len)) return;
-    if (key < key_lo || key >= key_hi) return;      // (a fold of the buckets [key_lo, key_hi) only)
     if ((i & (2u * d - 1u)) || i + d >= len) return;
     g1_xyzz_t a, b, r;
     load_xyzz(a, &carries[t]);
@@ -769,13 +764,12 @@ __global__ void __launch_bounds__(256) k_fold_step(const uint32_t* __restrict__ 
 __global__ void __launch_bounds__(256) k_fold_heads(const uint32_t* __restrict__ offsets,
                                                      const uint32_t* __restrict__ carry_key, uint32_t chunk,
                                                      uint32_t nchunks, const g1_xyzz_t* __restrict__ carries,
-                                                     g1_xyzz_t* __restrict__ buckets, uint32_t key_lo, uint32_t key_hi) {
+                                                     g1_xyzz_t* __restrict__ buckets) {
     tail_priority();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nchunks) return;
     uint32_t key, i, len;
     if (!carry_pos(offsets, carry_key, chunk, t, key, i, len) || i != 0) return;
-    if (key < key_lo || key >= key_hi) return;
     g1_xyzz_t a, b, r;
     load_xyzz(a, &buckets[key]);
     load_xyzz(b, &carries[t]);
@@ -1929,10 +1923,10 @@ void launch_msm_sort(hipStream_t s, const MsmShape& sh, const uint32_t* scalars,
 }
 void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t* table, const uint32_t* offsets,
                            const uint32_t* sorted, g1_xyzz_t* buckets, g1_xyzz_t* carries, uint32_t* carry_key,
-                           uint32_t nchunks, uint32_t t_base) {
-    if (nchunks <= t_base) return;
-    k_msm_accumulate<<<nblk(nchunks - t_base, 256), 256, 0, s>>>(table, offsets, sorted, sh.nbuckets, (uint32_t)sh.chunk,
-                                                                 nchunks, buckets, carries, carry_key, t_base);
+                           uint32_t nchunks) {
+    if (!nchunks) return;
+    k_msm_accumulate<<<nblk(nchunks, 256), 256, 0, s>>>(table, offsets, sorted, sh.nbuckets, (uint32_t)sh.chunk,
+                                                        nchunks, buckets, carries, carry_key);
 }
 void launch_fold_maxlen(hipStream_t s, const uint32_t* offsets, uint32_t nbuckets, uint32_t chunk, uint32_t* max_len,
                         g1_xyzz_t* buckets) {
@@ -1947,11 +1941,9 @@ void launch_fold_maxlen(hipStream_t s, const uint32_t* offsets, uint32_t nbucket
 #define KZG_FOLD_COOP_MAX 65536
 #endif
 void launch_fold_step(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
-                      uint32_t nchunks, uint32_t d, g1_xyzz_t* carries, uint32_t key_lo, uint32_t key_hi) {
+                      uint32_t nchunks, uint32_t d, g1_xyzz_t* carries) {
     if (!nchunks) return;
-    const bool ranged = key_lo != 0 || key_hi != 0xffffffffu;      // a bucket sub-range: the one-lane-per-carry kernel only
-    if (nchunks > KZG_FOLD_COOP_MAX || ranged)
-        k_fold_step<<<nblk(nchunks, 256), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, d, carries, key_lo, key_hi);
+    if (nchunks > KZG_FOLD_COOP_MAX) k_fold_step<<<nblk(nchunks, 256), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, d, carries);
 #if !defined(KZG_NO_LP) && !defined(KZG_NO_FOLD_LP)
     else if (nchunks / (2 * d) <= KZG_FOLD_LP_MAX) k_fold_step_lp<<<nchunks, 64, 0, s>>>(offsets, carry_key, chunk, d, carries);
 #endif
@@ -1976,10 +1968,10 @@ void launch_fold_bucket(hipStream_t s, const uint32_t* offsets, uint32_t chunk, 
     if (nbuckets) k_fold_bucket_lp<<<nbuckets, 64, 0, s>>>(offsets, chunk, carries, buckets);
 }
 void launch_fold_heads(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
-                       uint32_t nchunks, const g1_xyzz_t* carries, g1_xyzz_t* buckets, uint32_t key_lo, uint32_t key_hi) {
+                       uint32_t nchunks, const g1_xyzz_t* carries, g1_xyzz_t* buckets) {
     if (!nchunks) return;
-    if (nchunks > KZG_FOLD_COOP_MAX || key_lo != 0 || key_hi != 0xffffffffu)
-        k_fold_heads<<<nblk(nchunks, 256), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, carries, buckets, key_lo, key_hi);
+    if (nchunks > KZG_FOLD_COOP_MAX)
+        k_fold_heads<<<nblk(nchunks, 256), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, carries, buckets);
     else
         k_fold_heads_coop<<<nblk(nchunks, 64), 256, 0, s>>>(offsets, carry_key, chunk, nchunks, carries, buckets);
 }
@@ -2008,32 +2000,6 @@ bool msm_tree_level2_ok(uint32_t n_in_nodes, int level) {
 void launch_msm_tree_level2(hipStream_t s, const g1_xyzz_t* in, const g1_xyzz_t* prev, g1_xyzz_t* mid_p, g1_xyzz_t* out,
                             uint32_t n_in_nodes, int level) {
     k_msm_tree_level2_lp<<<(n_in_nodes >> 2) * (uint32_t)(level + 2), 128, 0, s>>>(in, prev, mid_p, out, n_in_nodes, level);
-}
-// Two half trees (buckets [0, B/2) and [B/2, B), each reduced to ONE node of `level` components with its level-below array
-// `prev_*` of two nodes) -> the 2-node level array `in2` (component-major: in2[2k + h]) and the 4-node P array `prev2` of the
-// level below, exactly what one tree over all B buckets would hold before its last merge.
-__global__ void __launch_bounds__(64) k_tree_join(const g1_xyzz_t* __restrict__ in_lo, const g1_xyzz_t* __restrict__ prev_lo,
-                                                   const g1_xyzz_t* __restrict__ in_hi, const g1_xyzz_t* __restrict__ prev_hi,
-                                                   int level, g1_xyzz_t* __restrict__ in2, g1_xyzz_t* __restrict__ prev2) {
-    const uint32_t pt = blockIdx.x, w = threadIdx.x;       // one point per workgroup, 56 words per point
-    if (w >= 56) return;
-    const uint32_t nin = 2u * (uint32_t)level;
-    const g1_xyzz_t* src;
-    g1_xyzz_t* dst;
-    if (pt < nin) {
-        const uint32_t k = pt >> 1, h = pt & 1u;
-        src = (h ? in_hi : in_lo) + k;
-        dst = in2 + pt;
-    } else {
-        const uint32_t j = pt - nin;                        // 0..3: node j of the level below = node j & 1 of half j >> 1
-        src = ((j >> 1) ? prev_hi : prev_lo) + (j & 1u);
-        dst = prev2 + j;
-    }
-    reinterpret_cast<uint32_t*>(dst)[w] = reinterpret_cast<const uint32_t*>(src)[w];
-}
-void launch_tree_join(hipStream_t s, const g1_xyzz_t* in_lo, const g1_xyzz_t* prev_lo, const g1_xyzz_t* in_hi,
-                      const g1_xyzz_t* prev_hi, int level, g1_xyzz_t* in2, g1_xyzz_t* prev2) {
-    k_tree_join<<<2 * level + 4, 64, 0, s>>>(in_lo, prev_lo, in_hi, prev_hi, level, in2, prev2);
 }
 void launch_msm_final(hipStream_t s, const g1_xyzz_t* node, const g1_xyzz_t* prev, int nbits, int nodes,
                       g1_xyzz_t* out_xyzz, g1_xyzz_t* scratch) {

@@ -48,7 +48,7 @@ struct MsmShape {
 struct SortTail {
     uint32_t chunk;          // sorted entries per accumulate lane
     g1_xyzz_t* buckets;      // [nbuckets * nbatch]
-    uint32_t* pin_dst;       // three words of the lane's pinned page: fold depth, overflow, first entry of the upper bucket half
+    uint32_t* pin_dst;       // two words of the lane's pinned page
     uint32_t* seq_word;      // the page's sequence word
     uint32_t seq;
 };
@@ -65,7 +65,7 @@ void launch_publish(hipStream_t s, const void* src_dev, void* dst_host_devptr, u
                     uint32_t* seq_word_devptr = nullptr, uint32_t seq = 0);
 void launch_msm_accumulate(hipStream_t s, const MsmShape& sh, const g1_affine_t* table, const uint32_t* offsets,
                            const uint32_t* sorted, g1_xyzz_t* buckets, g1_xyzz_t* carries, uint32_t* carry_key,
-                           uint32_t nchunks, uint32_t t_base = 0);   // lanes [t_base, nchunks) of the chunking
+                           uint32_t nchunks);
 // carries -> buckets: per-bucket binary tree over the carries (positions derived from the bucket offsets).
 // max_len: device word, maximum number of carries of one bucket (stays 0 when every run has <= 1 carry)
 // (also marks the empty buckets as infinity: the bucket array needs no memset)
@@ -76,15 +76,10 @@ void launch_fold_maxlen(hipStream_t s, const uint32_t* offsets, uint32_t nbucket
 bool msm_fold_bucket_ok(uint32_t nbuckets, uint32_t max_run);
 void launch_fold_bucket(hipStream_t s, const uint32_t* offsets, uint32_t chunk, uint32_t nbuckets, const g1_xyzz_t* carries,
                         g1_xyzz_t* buckets);
-// key_lo / key_hi: fold only the carries of the buckets [key_lo, key_hi) (the bucket-range split experiment, pipeline.hip)
 void launch_fold_step(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
-                      uint32_t nchunks, uint32_t d, g1_xyzz_t* carries, uint32_t key_lo = 0, uint32_t key_hi = 0xffffffffu);
+                      uint32_t nchunks, uint32_t d, g1_xyzz_t* carries);
 void launch_fold_heads(hipStream_t s, const uint32_t* offsets, const uint32_t* carry_key, uint32_t chunk,
-                       uint32_t nchunks, const g1_xyzz_t* carries, g1_xyzz_t* buckets, uint32_t key_lo = 0,
-                       uint32_t key_hi = 0xffffffffu);
-// joins the roots of two half trees (see k_tree_join) so that one ordinary merge level + the final finish the MSM
-void launch_tree_join(hipStream_t s, const g1_xyzz_t* in_lo, const g1_xyzz_t* prev_lo, const g1_xyzz_t* in_hi,
-                      const g1_xyzz_t* prev_hi, int level, g1_xyzz_t* in2, g1_xyzz_t* prev2);
+                       uint32_t nchunks, const g1_xyzz_t* carries, g1_xyzz_t* buckets);
 // level i: in = nodes of (i+1) points, component-major; out = nodes of (i+2) points
 // one merge level: `in` = the level-`level` array (n_in_nodes nodes; P, T_0 .. T_{level-2} stored component-major),
 // `prev` = the level below it (its P array holds the T_{level-1} of `in`'s nodes; unused at level 0), `out` = the

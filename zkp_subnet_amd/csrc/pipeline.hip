@@ -35,13 +35,12 @@ int pick_chunk(uint64_t entries) {
 // The only host wait inside is on the 4-byte fold-depth read-back; the calling thread holds no lock meanwhile.
 // The bucket tree on stream s: merges level arrays until `stop` nodes are left.  Three buffers in rotation (a level reads its
 // own array and the P array of the level below, writes the next) plus a fourth for the two-level launches.  On return b.in is
-// the last level array, b.prev the level below it, b.out a buffer nothing reads any more; returns the level reached.
+// the last level array, b.prev the level below it, b.out a buffer nothing reads any more.
 struct TreeBufs {
     g1_xyzz_t *in, *prev, *out, *extra;
 };
-static int run_tree(hipStream_t s, TreeBufs& b, uint32_t n_in, uint32_t stop) {
-    int level = 0;
-    while (n_in > stop) {
+static void run_tree(hipStream_t s, TreeBufs& b, uint32_t n_in, uint32_t stop) {
+    for (int level = 0; n_in > stop;) {
         if ((n_in >> 2) >= stop && msm_tree_level2_ok(n_in, level)) {
             // two narrow levels per launch: the level + 1 P array goes to `out`, the level + 2 array to `extra`
             launch_msm_tree_level2(s, b.in, b.prev, b.out, b.extra, n_in, level);
@@ -62,7 +61,6 @@ static int run_tree(hipStream_t s, TreeBufs& b, uint32_t n_in, uint32_t stop) {
         level++;
         n_in >>= 1;
     }
-    return level;
 }
 int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t n, uint64_t srs_offset,
              g1_xyzz_t* out_xyzz, const uint32_t* scalars2, int mont2) {
@@ -79,20 +77,7 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
     sh.c = ctx->c; sh.nwin = ctx->nwin; sh.lay = ctx->lay; sh.nbuckets = ctx->nbuckets * nbatch; sh.n = n;
     sh.nbatch = nbatch;
     sh.srs_offset = srs_offset; sh.srs_stride = ctx->stride; sh.chunk = pick_chunk(entries);
-#ifdef KZG_EXP_ACC_SPLIT
-    // EXPERIMENT (VERDICT r5 task 5, measured in round 6 -- see DESIGN.md 7): the accumulate as TWO launches over the lower /
-    // upper half of the lanes at half the chunk size (each still fills 131072 lanes); when the sort reports that every entry
-    // of the buckets [0, B/2) lies in the first launch's range, their fold + half tree run on the lane's side stream WHILE the
-    // second launch accumulates, and one join + one ordinary merge level + the final finish the MSM.
-    const bool split = nbatch == 1 && entries >= ((uint64_t)1 << 23) && sh.nbuckets > 8192 && ctx->profiling != 1;
-    if (split) sh.chunk = (sh.chunk + 1) / 2;
-#else
-    const bool split = false;
-#endif
     const uint32_t nchunks = (uint32_t)((entries + sh.chunk - 1) / sh.chunk);
-    // the first launch takes a little more than half the lanes: the boundary between the bucket halves wanders by a few
-    // thousand entries for uniform scalars (skewed ones fail the check below and take the ordinary tail)
-    const uint32_t nA = split ? std::min<uint32_t>(nchunks, ((nchunks / 2 + nchunks / 64) + 255u) & ~255u) : nchunks;
     const size_t B = sh.nbuckets;
     L.expect_short = entries <= ((uint64_t)1 << 24);   // up to ~3 ms of GPU time (a 2^20-point MSM)
     L.expect_us += 400 + (uint32_t)(entries / 4096);     // ~0.2 ns per sorted entry + the latency-bound tail
@@ -109,8 +94,7 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
     HIPCHK(ctx, L.bufA.ensure(B * sizeof(g1_xyzz_t) + 16384));
     HIPCHK(ctx, L.bufB.ensure(B * sizeof(g1_xyzz_t) / 2 + 16384));  // level arrays: n/2^L nodes x L components <= B/2
     HIPCHK(ctx, L.bufC.ensure(B * sizeof(g1_xyzz_t) / 2 + 16384));
-    const size_t dcap = (size_t)(LP_MAX_OPS + 64) * sizeof(g1_xyzz_t) + 16384;
-    HIPCHK(ctx, L.bufD.ensure(split ? 2 * dcap + 65536 : dcap));   // fourth buffer of the two-level launches (split: two + the join)
+    HIPCHK(ctx, L.bufD.ensure((size_t)(LP_MAX_OPS + 64) * sizeof(g1_xyzz_t) + 16384));   // fourth buffer of the two-level launches
     HIPCHK(ctx, L.carries.ensure((size_t)nchunks * sizeof(g1_xyzz_t)));
     HIPCHK(ctx, L.carry_key.ensure((size_t)nchunks * 4));
     uint32_t* max_len_d = L.flags() + 2;
@@ -131,17 +115,11 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
         L.sort_ws_clean = true;
         HIPCHK(ctx, hipEventRecord(L.ev_sorted, s));
     }
-    auto accumulate = [&]() -> hipError_t {
+    {
         Span sp(ctx, L, KZG_T_ACCUMULATE);
         launch_msm_accumulate(s, sh, ctx->table.as<g1_affine_t>(), L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(),
-                              L.bufA.as<g1_xyzz_t>(), L.carries.as<g1_xyzz_t>(), L.carry_key.as<uint32_t>(), nA);
-        if (!split) return hipSuccess;
-        const hipError_t e = hipEventRecord(L.ev_half, s);       // the lower half of the lanes is done
-        launch_msm_accumulate(s, sh, ctx->table.as<g1_affine_t>(), L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(),
-                              L.bufA.as<g1_xyzz_t>(), L.carries.as<g1_xyzz_t>(), L.carry_key.as<uint32_t>(), nchunks, nA);
-        return e;
-    };
-    HIPCHK(ctx, accumulate());
+                              L.bufA.as<g1_xyzz_t>(), L.carries.as<g1_xyzz_t>(), L.carry_key.as<uint32_t>(), nchunks);
+    }
     // short rows: the tail's ~20 launches must be queued while the (short) accumulate runs -- poll for the two words
     // instead of sleeping on the event
     auto wait_sorted = [&]() -> hipError_t {
@@ -158,49 +136,12 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
             sort_and_publish(false, true);
             HIPCHK(ctx, hipEventRecord(L.ev_sorted, s));
         }
-        HIPCHK(ctx, accumulate());
+        {
+            Span sp(ctx, L, KZG_T_ACCUMULATE);
+            launch_msm_accumulate(s, sh, ctx->table.as<g1_affine_t>(), L.offsets.as<uint32_t>(), L.sorted.as<uint32_t>(),
+                                  L.bufA.as<g1_xyzz_t>(), L.carries.as<g1_xyzz_t>(), L.carry_key.as<uint32_t>(), nchunks);
+        }
         HIPCHK(ctx, wait_sorted());
-    }
-    // every entry of the buckets [0, B / 2) inside the first launch's range?  (max_len_h[2] = offsets[B / 2], published by the sort)
-    const bool split_tail = split && (uint64_t)max_len_h[2] <= (uint64_t)nA * (uint64_t)sh.chunk;
-    if (split_tail) {
-        const uint32_t half = sh.nbuckets / 2;
-        hipStream_t ss = L.vstream;       // the lane's side stream: idle during a plain MSM
-        g1_xyzz_t* jbuf = reinterpret_cast<g1_xyzz_t*>(L.bufD.as<uint8_t>() + 2 * dcap);
-        TreeBufs lo{L.bufA.as<g1_xyzz_t>(), L.bufC.as<g1_xyzz_t>(), L.bufB.as<g1_xyzz_t>(), L.bufD.as<g1_xyzz_t>()};
-        TreeBufs hi{lo.in + half, lo.prev + half / 2, lo.out + half / 2, reinterpret_cast<g1_xyzz_t*>(L.bufD.as<uint8_t>() + dcap)};
-        int lvl;
-        {
-            Span sp(ctx, L, KZG_T_FIXUP, ss);
-            HIPCHK(ctx, hipStreamWaitEvent(ss, L.ev_half, 0));
-            for (uint32_t d = 1; d < *max_len_h; d <<= 1)
-                launch_fold_step(ss, L.offsets.as<uint32_t>(), L.carry_key.as<uint32_t>(), (uint32_t)sh.chunk, nA, d,
-                                 L.carries.as<g1_xyzz_t>(), 0u, half);
-            launch_fold_heads(ss, L.offsets.as<uint32_t>(), L.carry_key.as<uint32_t>(), (uint32_t)sh.chunk, nA,
-                              L.carries.as<g1_xyzz_t>(), L.bufA.as<g1_xyzz_t>(), 0u, half);
-            lvl = run_tree(ss, lo, half, 1);
-            HIPCHK(ctx, hipEventRecord(L.ev_lo, ss));
-        }
-        {
-            Span sp(ctx, L, KZG_T_FIXUP);
-            for (uint32_t d = 1; d < *max_len_h; d <<= 1)
-                launch_fold_step(s, L.offsets.as<uint32_t>(), L.carry_key.as<uint32_t>(), (uint32_t)sh.chunk, nchunks, d,
-                                 L.carries.as<g1_xyzz_t>(), half, 0xffffffffu);
-            launch_fold_heads(s, L.offsets.as<uint32_t>(), L.carry_key.as<uint32_t>(), (uint32_t)sh.chunk, nchunks,
-                              L.carries.as<g1_xyzz_t>(), L.bufA.as<g1_xyzz_t>(), half, 0xffffffffu);
-        }
-        {
-            Span sp(ctx, L, KZG_T_TREE);
-            (void)run_tree(s, hi, half, 1);
-            HIPCHK(ctx, hipStreamWaitEvent(s, L.ev_lo, 0));
-            g1_xyzz_t *in2 = jbuf, *prev2 = jbuf + 2 * lvl, *out2 = prev2 + 4, *scratch = out2 + lvl + 1;
-            launch_tree_join(s, lo.in, lo.prev, hi.in, hi.prev, lvl, in2, prev2);
-            launch_msm_tree_level(s, in2, prev2, out2, 2, lvl);
-            Span sp2(ctx, L, KZG_T_FINAL);
-            launch_msm_final(s, out2, in2, ctx->c - 1, 1, out_xyzz, scratch);
-        }
-        HIPCHK(ctx, hipGetLastError());
-        return KZG_OK;
     }
     {
         Span sp(ctx, L, KZG_T_FIXUP);
@@ -218,7 +159,7 @@ int msm_core(kzg_ctx* ctx, Lane& L, const uint32_t* scalars, int mont, uint64_t 
     TreeBufs tb{L.bufA.as<g1_xyzz_t>(), L.bufC.as<g1_xyzz_t>(), L.bufB.as<g1_xyzz_t>(), L.bufD.as<g1_xyzz_t>()};
     {
         Span sp(ctx, L, KZG_T_TREE);
-        (void)run_tree(s, tb, sh.nbuckets, (uint32_t)nbatch);
+        run_tree(s, tb, sh.nbuckets, (uint32_t)nbatch);
     }
     {
         Span sp(ctx, L, KZG_T_FINAL);
