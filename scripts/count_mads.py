@@ -1,5 +1,5 @@
 """Counts the v_mad_u64_u32 (and all VALU) instructions on the common path of ONE mixed point addition in
-k_msm_accumulate, from the gfx950 ISA hipcc emits for csrc/msm.hip (no GPU needed).  The hot loop's body is
+k_msm_accumulate, from the gfx950 ISA hipcc emits for csrc/msm_accumulate.hip (no GPU needed).  The hot loop's body is
 [loop header .. the `g1_madd_checked` exit label]; the rare doubling branch (equal x coordinates: g1_dbl_aff inlined,
 the block between the second-level `s_cbranch_execz` pair) is excluded.  Writes profiles/isa_counts.json.
 
@@ -14,11 +14,11 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "zkp_subnet_amd", "csrc", "msm.hip")
+src = os.path.join(ROOT, "zkp_subnet_amd", "csrc", "msm_accumulate.hip")
 with tempfile.TemporaryDirectory() as td:
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-c", src, "-o",
                     os.path.join(td, "msm.o"), "-save-temps=obj"], check=True, cwd=td, capture_output=True)
-    asm = open(os.path.join(td, "msm-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+    asm = open(os.path.join(td, "msm_accumulate-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
 m = re.search(r"^_Z16k_msm_accumulate.*?s_endpgm", asm, re.S | re.M)
 lines = m.group(0).splitlines()
 # the loop: from the line after the exit label of the previous iteration's madd to that label again
@@ -46,7 +46,7 @@ common = len(mads) - rare
 valu = sum(1 for i, l in enumerate(body) if re.match(r"\s*v_", l) and not (best[0] < i < best[1]))
 out = {"kernel": "k_msm_accumulate", "mads_per_mixed_add": common, "mads_in_rare_doubling_branch": rare,
        "valu_per_loop_iteration_static": valu,
-       "source": "hipcc --offload-arch=gfx950 -O3 -save-temps of zkp_subnet_amd/csrc/msm.hip (scripts/count_mads.py)"}
+       "source": "hipcc --offload-arch=gfx950 -O3 -save-temps of zkp_subnet_amd/csrc/msm_accumulate.hip (scripts/count_mads.py)"}
 path = os.path.join(ROOT, "profiles", "isa_counts.json")
 if "--check" in sys.argv:
     have = json.load(open(path))

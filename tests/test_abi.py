@@ -284,7 +284,7 @@ def test_wire_decoder_every_byte_in_every_position_both_paths():
 
 def test_isa_counts_file_matches_current_source():
     """bench.py's `mad_issue` figure quotes profiles/isa_counts.json (mads per mixed addition of k_msm_accumulate): the
-    committed file must be what scripts/count_mads.py derives from the CURRENT csrc/msm.hip (hipcc -save-temps, no GPU)."""
+    committed file must be what scripts/count_mads.py derives from the CURRENT csrc/msm_accumulate.hip (hipcc -save-temps, no GPU)."""
     import subprocess
     import sys
 

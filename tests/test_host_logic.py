@@ -9,6 +9,7 @@ import random
 import pytest
 
 from oracle import bls12_381 as o
+from oracle import cpu as oc
 from tests.oracle_engine import OracleEngine
 from zkp_subnet_amd import codec
 from zkp_subnet_amd.client import Client, derive_taus
@@ -413,6 +414,66 @@ def test_multi_device_client_routes_rows_by_worker_index():
         assert r.status_code == s.status_code and r.json() == s.json()
     multi.stop()
     assert multi.worker_commit(0, ch.polys[0]).status_code == 503
+
+
+def test_multi_device_client_from_a_setup_file_loads_only_the_served_slices(tmp_path):
+    """VERDICT r5 task 4: with a setup FILE every device of a MultiDeviceClient loads only the slices of the worker indices
+    it serves (first = g, stride = G: kzg_load_srs_file_slices), never the whole file; worker i is then resident slice
+    i // G of device i % G.  With oracle-backed engines that record what they were asked to load: the arguments, the
+    resident bytes, and every answer against a single whole-file Client.  A client whose workers are NOT a progression over
+    the file falls back to the whole file."""
+    from zkp_subnet_amd import MultiDeviceClient
+
+    scale, ms = 9, 3                       # 8 slices of 64 points
+    T, M, G = 1 << (scale - ms), 1 << ms, 3
+    tx, ty = (0xF11E5 % o.R).to_bytes(32, "big"), (0x5EED % o.R).to_bytes(32, "big")
+    slices = [oc.srs_gen(tx, ty, scale, ms, i) for i in range(M)]
+    path = tmp_path / "setup_9_3.uncompressed"
+    path.write_bytes(b"".join(slices))
+
+    class FileEngine(OracleEngine):
+        def __init__(self):
+            super().__init__()
+            self.loads = []
+
+        def load_srs_file(self, p, scale, machines_scale, compressed=False):
+            self.loads.append(("whole",))
+            with open(p, "rb") as f:
+                self.load_srs(f.read(), scale, machines_scale, compressed)
+
+        def load_srs_file_slices(self, p, scale, machines_scale, first_slice, slice_stride, compressed=False):
+            self.loads.append(("slices", first_slice, slice_stride))
+            t = 96 << (scale - machines_scale)
+            with open(p, "rb") as f:
+                blob = f.read()
+            self.load_srs(b"".join(blob[k * t:(k + 1) * t] for k in range(first_slice, len(blob) // t, slice_stride)), scale,
+                          machines_scale, compressed)
+
+    engines = [FileEngine() for _ in range(G)]
+    multi = MultiDeviceClient(devices=[0, 1, 2], setup_path=str(path), engines=engines)
+    multi.start(scale, ms)
+    assert [e.loads for e in engines] == [[("slices", g, G)] for g in range(G)]
+    for g, e in enumerate(engines):
+        assert e.srs == b"".join(slices[i] for i in range(g, M, G))          # 3 + 3 + 2 slices: 1 / G of the file each
+    single = Client(setup_path=str(path), engine=FileEngine())
+    single.start(scale, ms)
+    assert single.engine.loads == [("whole",)]
+    rnd = random.Random(4)
+    alpha = codec.be32_to_fr(rnd.randrange(o.R).to_bytes(32, "big"))
+    for i in range(M):
+        poly = codec.be32_to_fr_list(b"".join(rnd.randrange(o.R).to_bytes(32, "big") for _ in range(T)))
+        with multi.worker_commit_and_open(i, poly, alpha) as a, single.worker_commit_and_open(i, poly, alpha) as b:
+            assert a.status_code == 200 and a.json() == b.json(), i
+    assert multi.worker_commit(M, ["x"]).status_code == 400
+    multi.stop()
+    # workers that are not first, first + stride, ... over the file's slices: the whole file, slice i = worker i
+    odd = Client(setup_path=str(path), engine=FileEngine(), workers=[0, 1, 5])
+    odd.start(scale, ms)
+    assert odd.engine.loads == [("whole",)] and odd._slice(5) == 5
+    prog = Client(setup_path=str(path), engine=FileEngine(), workers=[1, 4, 7])
+    prog.start(scale, ms)
+    assert prog.engine.loads == [("slices", 1, 3)] and prog._slice(7) == 2
+    assert prog.worker_commit(2, ["x"]).status_code == 400                   # worker 2 has no resident slice here
 
 
 def test_lane_book_drive_without_a_sanitizer(tmp_path):

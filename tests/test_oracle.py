@@ -177,14 +177,14 @@ def test_c_oracle_trapdoor_midsize(oracle_cpu):
 
 
 def test_endomorphism_subgroup_criterion_constants():
-    """The G1 membership test of csrc/msm.hip (k_g1_subgroup_check_lp): sigma(x, y) = (beta x, y) acts on G1 as -z^2,
+    """The G1 membership test of csrc/g1_kernels.hip (k_g1_subgroup_check_lp): sigma(x, y) = (beta x, y) acts on G1 as -z^2,
     and z^4 - z^2 + 1 = r is the degree of sigma + z^2, so [z^2]P == -sigma(P) holds exactly on G1.  Checks the
     constants the kernel hard-codes, on the generator and on an on-curve point outside the subgroup."""
     z = abs(o.BLS_X)
     assert z == 0xD201000000010000 and z ** 4 - z ** 2 + 1 == o.R
     beta = 0x5F19672FDF76CE51BA69C6076A0F77EADDB3A93BE6F89688DE17D813620A00022E01FFFFFFFEFFFE
     assert beta != 1 and pow(beta, 3, o.P) == 1
-    src = open(__import__("os").path.join(__import__("os").path.dirname(__file__), "..", "zkp_subnet_amd", "csrc", "msm.hip")).read()
+    src = open(__import__("os").path.join(__import__("os").path.dirname(__file__), "..", "zkp_subnet_amd", "csrc", "g1_kernels.hip")).read()
     bm = beta * pow(2, 392, o.P) % o.P            # Montgomery residue, 14 limbs of 28 bits, as the kernel stores it
     for i in range(14):
         assert "0x%08xu" % ((bm >> (28 * i)) & 0xFFFFFFF) in src

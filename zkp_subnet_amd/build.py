@@ -14,11 +14,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libkzg_mi355x.so")
-SOURCES = ["msm.hip", "fr_kernels.hip", "lanes.hip", "srs.hip", "pipeline.hip", "serve.hip", "comm.hip", "abi_test.hip", "calibrate.hip",
+SOURCES = ["msm_sort.hip", "msm_accumulate.hip", "msm_tree.hip", "g1_kernels.hip", "srs_kernels.hip", "fr_ntt.hip", "fr_poly.hip", "lanes.hip", "srs.hip", "pipeline.hip", "serve.hip", "comm.hip", "abi_test.hip", "calibrate.hip",
            "pairing_host.cpp", "finish_host.cpp", "rccl_dl.cpp", "multi_host.cpp", "wire_host.cpp"]
 # dev-only prototypes (scripts/proto/), linked only when KZG_WITH_PROTO=1: never part of the shipped library
 PROTO_SOURCES = ["../../scripts/proto/baff_proto.hip"]
-HEADERS = ["bigint.hip.h", "field.hip.h", "fp28.hip.h", "fr29.hip.h", "g1.hip.h", "msm.hip.h", "fr_kernels.hip.h", "fp_lp.hip.h", "fp_host.h", "rccl_dl.h", "lanebook.h", "ctx.hip.h",
+HEADERS = ["bigint.hip.h", "field.hip.h", "fp28.hip.h", "fr29.hip.h", "g1.hip.h", "msm.hip.h", "msm_dev.hip.h", "fr_kernels.hip.h", "fp_lp.hip.h", "fp_host.h", "rccl_dl.h", "lanebook.h", "ctx.hip.h",
            "../../include/kzg_mi355x.h", "../../include/kzg_mi355x_test.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 
@@ -91,7 +91,7 @@ def build(force: bool = False, extra_flags=()) -> str:
         if force or _stale(o, [s] + hdrs):
             jobs.append([hipcc, *FLAGS, *extra_flags, "-c", s, "-o", o])
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             for res in ex.map(lambda cmd: subprocess.run(cmd, capture_output=True, text=True), jobs):
                 if res.returncode != 0:
                     raise RuntimeError("hipcc failed:\n" + " ".join(res.args) + "\n" + res.stderr[-4000:])

@@ -1,7 +1,11 @@
-// Fr-side kernel launchers (fr_kernels.hip): wire codec, NTT, opening evaluation + quotient.
+// Fr-side kernel launchers (fr_ntt.hip: codec + NTT; fr_poly.hip: opening): wire codec, NTT, opening evaluation + quotient.
 #pragma once
 #include "g1.hip.h"
 
+// one scalar as a kernel argument: the 32 big-endian bytes, as they lie in memory
+struct FrArg {
+    uint32_t w[8];
+};
 void launch_fr_from_be(hipStream_t s, const uint8_t* be, uint32_t* out, uint64_t n, int to_mont, uint32_t* bad);
 // one scalar from HOST memory, handed over as a kernel argument (no copy on the stream)
 void launch_fr_from_host32(hipStream_t s, const uint8_t be32[32], uint32_t* out, int to_mont, uint32_t* bad);

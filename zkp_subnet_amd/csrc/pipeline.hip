@@ -1,6 +1,6 @@
 // pipeline.hip -- the host-side sequencing of the HIP kernels: ONE Pippenger MSM on a lane (msm_core: sort -> accumulate ->
-// fold -> tree -> final; kernels in msm.hip) and one worker row's commit and / or open (commit_open_dev: INTT -> MSM ||
-// evaluation + quotient -> MSM; kernels in fr_kernels.hip).  What it computes is what the reference's prover computes behind
+// fold -> tree -> final; kernels in msm_sort / msm_accumulate / msm_tree.hip) and one worker row's commit and / or open (commit_open_dev: INTT -> MSM ||
+// evaluation + quotient -> MSM; kernels in fr_ntt.hip / fr_poly.hip).  What it computes is what the reference's prover computes behind
 // Client.worker_commit / worker_open (reference neurons/miner.py:38-54); see ctx.hip.h for the map of the library.
 #include "ctx.hip.h"
 
