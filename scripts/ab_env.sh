@@ -4,7 +4,7 @@
 #   gpurun -- 'SETTINGS="KZG_NTT_RADIX2=1|KZG_NTT_RADIX2=0,KZG_NTT_TILE_LOG=10" ROWS=22,20 bash scripts/ab_env.sh 3'
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 ROUNDS=${1:-2}
-IFS='|' read -ra SETS <<< "${SETTINGS:-KZG_SERIAL_ACC=0|KZG_SERIAL_ACC=1}"
+IFS='|' read -ra SETS <<< "${SETTINGS:-KZG_NTT_RADIX2=0|KZG_NTT_RADIX2=1}"
 for r in $(seq $ROUNDS); do
   for v in "${SETS[@]}"; do
     env ${v//,/ } python bench.py --no-adversarial --no-cpu-baseline --no-pipelined --steps 10 --kzg-rows ${ROWS:-22,20} 2>/dev/null | tail -1 | python -c "

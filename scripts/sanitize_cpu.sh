@@ -3,14 +3,14 @@
 #   bash scripts/sanitize_cpu.sh [asan|tsan|tsan-lanes|all]        logs -> profiles/<round>_sanitize_<mode>.log
 # Works on a scratch COPY of the tree (default /tmp/kzg_san/<mode>): the shipped .so files are never touched.
 # What is instrumented, with ONE runtime (the ROCm clang's, preloaded into the uninstrumented python):
-#   - libkzg_mi355x.so: every host translation unit (csrc/api.hip host side, pairing_host.cpp, finish_host.cpp) via
+#   - libkzg_mi355x.so: every host translation unit (the host side of csrc/lanes / srs / pipeline / serve / comm .hip, multi_host.cpp, pairing_host.cpp, finish_host.cpp, wire_host.cpp) via
 #     hipcc -fsanitize=... -fno-gpu-sanitize (device code stays as shipped)
 #   - zkp_subnet_amd/_wire (csrc/wire_py.c) and oracle/libkzg_oracle.so (oracle/kzg_cpu.c) via clang
 # What runs: asan (ASan + UBSan): the whole CPU suite (pytest -m "not gpu") + tests/san_drive.py;
 #            tsan: tests/san_drive.py (8 Python threads on the wire pool incl. the asynchronous batches, the verifier's
 #            thread pool, the oracle's task pool) + the threaded CPU tests (test_verify, test_host_logic, test_oracle);
 #            tsan-lanes: tests/lanebook_tsan.cpp -- the context's lane / ticket / staging / row-cache state machine
-#            (csrc/lanebook.h, the HIP-free half of csrc/api.hip) driven by 12 threads with a fake back end and injected
+#            (csrc/lanebook.h, the HIP-free half of csrc/lanes.hip) driven by 12 threads with a fake back end and injected
 #            failures.  On this box kzg_create answers KZG_E_HIP, so the instrumented libkzg_mi355x.so never reaches that
 #            code: the drive is how a race detector gets to see it.
 set -u
@@ -18,7 +18,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 MODE=${1:-all}
 WORK=${SAN_WORK:-/tmp/kzg_san}
 CLANG=/opt/rocm/lib/llvm/bin/clang
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 run_mode() {
   local mode=$1 san rt opts
   if [ "$mode" = asan ]; then

@@ -1,5 +1,5 @@
 // lanebook_tsan.cpp -- ThreadSanitizer drive of the context's host-side state machine (zkp_subnet_amd/csrc/lanebook.h: lanes,
-// MSM tickets, the pinned staging pool, the row-cache slots) with a FAKE back end: what csrc/api.hip hangs on a slot
+// MSM tickets, the pinned staging pool, the row-cache slots) with a FAKE back end: what csrc/lanes.hip hangs on a slot
 // (streams, buffers, kernels) is here a few plain, NON-atomic words per slot that the holder writes while its "kernels"
 // (sleeps) run -- so if the book ever hands one slot to two threads, ThreadSanitizer reports a data race on those words,
 // and the logical invariants are asserted on top.  Failures are injected: calls that bail out half-way, tickets that are

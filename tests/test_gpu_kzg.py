@@ -31,7 +31,7 @@ def test_kzg_golden_vectors(hip, golden_kzg):
         eng.close()
 
 
-# rows up to 2^18 take the batched two-set pass, longer ones the two-lane form (api.hip commit_open_dev): both sides of
+# rows up to 2^18 take the batched two-set pass, longer ones the two-lane form (pipeline.hip commit_open_dev): both sides of
 # the switch are covered, and the fused call must equal the two separate calls (single-MSM path)
 @pytest.mark.parametrize("scale,ms,i", [(10, 2, 3), (12, 0, 0), (16, 4, 9), (14, 0, 0), (18, 0, 0), (20, 1, 1)])
 def test_kzg_commit_open_matches_c_oracle(hip, scale, ms, i):

@@ -477,7 +477,7 @@ def test_multi_device_client_from_a_setup_file_loads_only_the_served_slices(tmp_
 
 
 def test_lane_book_drive_without_a_sanitizer(tmp_path):
-    """csrc/lanebook.h (lanes, MSM tickets, staging pool, row-cache slots: the HIP-free half of csrc/api.hip) under the
+    """csrc/lanebook.h (lanes, MSM tickets, staging pool, row-cache slots: the HIP-free half of csrc/lanes.hip) under the
     12-thread fake-back-end drive of tests/lanebook_tsan.cpp, here compiled WITHOUT a sanitizer as a functional check of its
     invariants (no slot ever handed to two holders, tickets claimed exactly once, BUSY instead of waits that only the caller
     could end, hits return the row they were filled with).  The ThreadSanitizer run is scripts/sanitize_cpu.sh tsan-lanes

@@ -3,7 +3,7 @@
 //
 // The reference's axon runs Miner.forward on worker threads (reference neurons/miner.py:106-135) and must never crash or
 // hang (:133-135), so this bookkeeping is the part of the library that concurrent host threads actually contend on.  It
-// lives apart from csrc/api.hip -- which only adds streams, buffers and kernels to the slots handed out here -- so that
+// lives apart from csrc/lanes.hip -- which only adds streams, buffers and kernels to the slots handed out here -- so that
 // ThreadSanitizer can drive exactly this code from many threads with a fake back end on a box without a GPU
 // (tests/lanebook_tsan.cpp, scripts/sanitize_cpu.sh tsan-lanes); the GPU stress test stays the functional check.
 //

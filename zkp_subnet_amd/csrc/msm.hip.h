@@ -1,4 +1,4 @@
-// Pippenger G1 MSM for gfx950 -- kernel declarations shared by msm.hip and api.hip.
+// Pippenger G1 MSM for gfx950 -- kernel declarations shared by the msm_*.hip kernel files and the host side (pipeline.hip, srs.hip, serve.hip, comm.hip).
 //
 // Design (DESIGN.md "MSM"): the SRS is fixed, so every point P_j is stored with its window multiples
 // 2^off[w] P_j (table[w][j], affine, Montgomery; sized for 288 GB HBM).  All nwin signed digits of all

@@ -1,7 +1,7 @@
 // rccl_dl.h -- RCCL as the library's own collective back end, bound at run time.
 //
 // The multi-GPU step of the SRS-sharded MSM is ONE ncclAllGather of 192 bytes per rank, enqueued by the
-// library on the lane's own stream (kzg_msm_sharded, api.hip).  RCCL is resolved with dlopen at the first kzg_comm_*
+// library on the lane's own stream (kzg_msm_sharded, comm.hip).  RCCL is resolved with dlopen at the first kzg_comm_*
 // call instead of a link-time dependency:
 //   * a single-GPU miner (the reference's own deployment: one prover per process, base/miner.py:73-84) never pays for
 //     mapping a ~570-MB collective library at start;

@@ -137,7 +137,7 @@ typedef struct {
  * of (index, 32 bytes), mod 2^128: independent of how the list is split over threads, bound to positions, and keyed with
  * 512 random bits drawn once per process.  It is a fast keyed multiply-fold with NO cryptographic analysis (a zero
  * multiplicand drops a word from a term, single lanes admit position swaps): the prover therefore treats it as a hint and
- * verifies every cache hit against the cached row's bytes on the GPU (csrc/api.hip, commit_open_host_cached).  Four 64x64->128 multiplies
+ * verifies every cache hit against the cached row's bytes on the GPU (csrc/serve.hip, commit_open_host_cached).  Four 64x64->128 multiplies
  * per element, folded into the decode pass (the bytes are still in the vector registers). */
 static uint64_t TAG_KEY[8];
 static inline uint64_t mum64(uint64_t a, uint64_t b) {
