@@ -59,700 +59,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy peak
-HBM_COPY_GBS = 6290.0
-# v_mad_u64_u32 (the only wide integer multiply): 2.30 ns per wave-instruction per SIMD measured with 2 and 4 waves per
-# SIMD (scripts/ubench/valu_rates.hip -> profiles/ubench_valu_rates.txt) => 1024 SIMDs / 2.30 ns = 445 G mads/s.
-# For scale: the guide's full-rate figure for simple VALU (wave64 v_fma_f32 in 2 cycles on a SIMD-32 once >= 2 waves
-# share the SIMD) is 1024 x 2.4 GHz / 2 = 1228.8 G wave-instructions/s; integer multiplies do not issue at that rate.
-MAD_NS = 2.30                  # ns per v_mad_u64_u32 wave-instruction per SIMD at >= 2 waves/SIMD (4.5 ns for a lone wave)
-SIMDS = 1024
-VALU_FULL_RATE_GINST_S = SIMDS * 2.4 / 2
-TAU = 0x2F6C7A1D3B5E9F80412D6A7C93E1B5F7086A4D2C1E9B3F5A7D6C8E0F1A2B3C4D % R_MOD
-
-
-def uniform_fr(n, seed):
-    """n scalars uniform in [0, r): seeded PCG64 stream, 255-bit candidates, rejection of values >= r."""
-    import numpy as np
-
-    rng = np.random.default_rng(seed)
-    r_words = np.array([(R_MOD >> (64 * (3 - i))) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
-    out = []
-    have = 0
-    while have < n:
-        m = int((n - have) * 1.15) + 64
-        raw = rng.integers(0, 256, size=(m, 32), dtype=np.uint8)
-        raw[:, 0] &= 0x7F
-        w = raw.view(">u8").astype(np.uint64)
-        lt = np.zeros(m, dtype=bool)
-        eq = np.ones(m, dtype=bool)
-        for i in range(4):
-            lt |= eq & (w[:, i] < r_words[i])
-            eq &= w[:, i] == r_words[i]
-        keep = raw[lt]
-        out.append(keep)
-        have += len(keep)
-    return np.concatenate(out)[:n].tobytes()
-
-
-def cpu_model():
-    try:
-        with open("/proc/cpuinfo") as f:
-            for line in f:
-                if line.startswith("model name"):
-                    return line.split(":", 1)[1].strip()
-    except OSError:
-        pass
-    return "unknown"
-
-
-def measured_copy_peak_gbs(torch):
-    """STREAM-style device copy (1 GiB read + 1 GiB written per pass) on torch's stream: the achievable-HBM yardstick
-    SURVEY 8d asks for beside the 8 TB/s spec figure."""
-    a = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
-    b = torch.empty_like(a)
-    b.copy_(a)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
-        b.copy_(a)
-    e1.record()
-    torch.cuda.synchronize()
-    gbs = 5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    del a, b
-    torch.cuda.empty_cache()
-    return gbs
-
-
-def sysfs_sclk_mhz(device):
-    """Current shader clock from the amdgpu sysfs node (the `*` line of pp_dpm_sclk), when the container exposes it."""
-    import glob
-
-    try:
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        with open(cards[device]) as f:
-            for line in f:
-                if line.rstrip().endswith("*"):
-                    return float(line.split(":")[1].strip().split("M")[0])
-    except (OSError, IndexError, ValueError):
-        pass
-    return None
-
-
-def host_cores():
-    try:
-        return len(os.sched_getaffinity(0))
-    except AttributeError:
-        return os.cpu_count() or 1
-
-
-def thread_counts(user, usable=None):
-    """CPU-baseline thread counts: 1, the box's share for one GPU (16) and every core this process may actually use
-    (`usable`: the affinity mask cut down to the cgroup's CPU quota -- a box that SHOWS 256 cores but grants 16 has 16)."""
-    if user:
-        return sorted({1, user})
-    n = usable or host_cores()
-    return sorted({1, min(16, n), n})
-
-
-def pctl(xs, q):
-    s = sorted(xs)
-    return s[min(len(s) - 1, int(q * len(s)))]
-
-
-def kzg_rows_report(HipEngine, lagrange_factor, device, logs, cpu_threads, with_cpu):
-    """commit+open latency of device-resident evaluation-form rows (N = 1): BASELINE.json configs[2] (2^22) and the row
-    lengths the reference actually runs (mainnet 2^16, testnet 2^12: reference Makefile:63-116).  One engine per row
-    length (the window tables are built for the slice length).  Never part of `value`."""
-    rows = {}
-    for lg in logs:
-        T = 1 << lg
-        eng = HipEngine(device)
-        t0 = time.time()
-        eng.gen_srs(TAU, (TAU * 7 + 1) % R_MOD, lg, 0)
-        setup_s = time.time() - t0
-        row = uniform_fr(T, seed=0)
-        alpha = uniform_fr(1, seed=1)
-        eng.upload_fr(0, row, True)
-        warm, steps = (2, 8) if lg >= 20 else (5, 40)
-        t_w = time.perf_counter()
-        done = 0
-        while done < warm or time.perf_counter() - t_w < 0.06:   # >= 60 ms of the same call: the clocks need ~40 ms of load
-            ref = eng.commit_open_resident(0, 0, T, alpha, True)
-            done += 1
-        lat = []
-        for _ in range(steps):
-            t1 = time.perf_counter()
-            got = eng.commit_open_resident(0, 0, T, alpha, True)
-            lat.append((time.perf_counter() - t1) * 1e3)
-            assert got == ref, "non-deterministic commit+open"
-        eng.set_profiling(True)          # stage times: serialised on one lane so that they stay attributable
-        stages = {}
-        nprof = 3
-        for _ in range(nprof):
-            assert eng.commit_open_resident(0, 0, T, alpha, True) == ref
-            for k, v in eng.timings().items():
-                stages[k] = stages.get(k, 0.0) + v / nprof
-        eng.set_profiling(False)
-        med = pctl(lat, 0.5)
-        alg = 384.0 * T                  # 64 INTT + 128 MSM + 64 quotient + 128 MSM bytes per coefficient (SURVEY 8d)
-        ach = alg / (med * 1e-3) / 1e9
-        rec = {"log2_T": lg, "window_bits": eng.window, "ms": round(med, 4), "p10": round(pctl(lat, 0.1), 4),
-               "p90": round(pctl(lat, 0.9), 4), "steps": steps, "warmup_calls": done, "coefficients_per_s": T / (med * 1e-3),
-               "stages_ms_profiled_serial": {k: round(v, 4) for k, v in stages.items()},
-               "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes": alg, "per": "whole commit+open call"},
-               "result_hex": b"".join(ref).hex(), "setup_s": round(setup_s, 2)}
-        if with_cpu:
-            from oracle import cpu as oc
-
-            oc.build()
-            m = min(T, 1 << 17)          # bounded CPU sample: a row of 2^17 coefficients at most
-            srs = eng.srs_read(0, m)
-            sample = row[: 32 * m]
-            per = {}
-            cpu_res = None
-            for th in cpu_threads:
-                if th == 1 and m > (1 << 14):
-                    continue             # one thread on a long row would take minutes
-                tc = time.perf_counter()
-                c = oc.commit(srs, sample, True, threads=th)
-                ev, pf = oc.open_(srs, sample, alpha, True, threads=th)
-                per[th] = time.perf_counter() - tc
-                cpu_res = (c, ev, pf)
-            best = min(per, key=per.get)
-            gpu_same = ref if m == T else eng.commit_open(0, sample, alpha, True)   # a shorter row on the same points
-            rec["cpu_baseline"] = {
-                "value": m / per[best], "unit": "coefficients/s", "cores": best, "kind": "port",
-                "sample": f"commit+open of the first 2^{m.bit_length() - 1} coefficients of the same row "
-                          f"(oracle/kzg_cpu.c); seconds by thread count: "
-                          + ", ".join(f"{th}: {s:.3f}" for th, s in sorted(per.items())),
-                "ms_scaled_to_full_row": per[best] * (T / m) * 1e3,
-                "matches_gpu_bit_exact": cpu_res == tuple(gpu_same)}
-            assert cpu_res == tuple(gpu_same), "GPU commit+open differs from the CPU oracle on the baseline sample"
-        rows[f"2^{lg}"] = rec
-        eng.close()
-    return rows
-
-
-class Fault(Exception):
-    """BENCH_FAULT=<phase>:<rank> -- an injected failure (tests of the multi-rank error paths)."""
-
-
-def inject(phase, rank):
-    spec = os.environ.get("BENCH_FAULT", "")
-    for item in spec.split(","):
-        if item and item.split(":")[0] == phase and int(item.split(":")[1]) == rank:
-            raise Fault(f"injected fault in {phase} on rank {rank} (BENCH_FAULT)")
-
-
-class Ctl:
-    """Control plane of a multi-rank launch.  Collectives (barrier, MAX, byte gathers) run on the default process group
-    -- gloo with a timeout unless BENCH_BACKEND says otherwise; phase STATUS travels through the rendezvous store (set /
-    wait / get with a timeout), never through a collective: a rank that failed its phase cannot be waited for in one."""
-
-    def __init__(self, torch, dist, rank, world, active, timeout_s):
-        self.torch, self.dist, self.rank, self.world, self.active, self.timeout_s = torch, dist, rank, world, active, timeout_s
-        self.poisoned = None         # set once a collective of the group may have been left half-done
-        self.store = None
-        if active:
-            try:
-                from torch.distributed.distributed_c10d import _get_default_store
-
-                self.store = _get_default_store()
-            except Exception:        # noqa: BLE001 -- older / newer torch: agree() then uses an object gather
-                self.store = None
-        self.cpu = not active or dist.get_backend() != "nccl"
-
-    def _dev(self):
-        return "cpu" if self.cpu else "cuda"
-
-    def barrier(self):
-        if self.active:
-            self.dist.barrier()
-        if self.torch.cuda.is_available():      # (always, in a measurement; the CPU tests of this class have no device)
-            self.torch.cuda.synchronize()
-
-    def max_over_ranks(self, x):
-        if not self.active:
-            return x
-        t = self.torch.tensor([x], dtype=self.torch.float64, device=self._dev())
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def gather_bytes(self, b):
-        if not self.active:
-            return [bytes(b)]
-        src = self.torch.frombuffer(bytearray(b), dtype=self.torch.uint8).to(self._dev())
-        out = self.torch.empty(self.world * len(b), dtype=self.torch.uint8, device=self._dev())
-        self.dist.all_gather_into_tensor(out, src)
-        raw = out.cpu().numpy().tobytes()
-        return [raw[i * len(b):(i + 1) * len(b)] for i in range(self.world)]
-
-    def agree(self, phase, ok, msg=""):
-        """Every rank reports (ok, msg) for `phase`; returns (all ok, {rank: msg of the failed ones}).  A rank that does not
-        report within the timeout counts as failed."""
-        if not self.active:
-            return ok, ({} if ok else {self.rank: msg})
-        import datetime
-
-        if self.store is None:
-            objs = [None] * self.world
-            self.dist.all_gather_object(objs, (bool(ok), str(msg)[:400]))
-            bad = {r: m for r, (k, m) in enumerate(objs) if not k}
-            return not bad, bad
-        self.store.set(f"bench/{phase}/{self.rank}", json.dumps([bool(ok), str(msg)[:400]]))
-        bad = {}
-        for r in range(self.world):
-            key = f"bench/{phase}/{r}"
-            try:
-                self.store.wait([key], datetime.timedelta(seconds=self.timeout_s))
-                k, m = json.loads(self.store.get(key).decode())
-                if not k:
-                    bad[r] = m
-            except Exception as e:   # noqa: BLE001 -- no status from that rank: it is gone or stuck
-                bad[r] = f"no status within {self.timeout_s} s ({type(e).__name__})"
-        return not bad, bad
-
-
-def errmsg(e):
-    return f"{type(e).__name__}: {e}"[:400]
-
-
-def make_collective(args, ctl, eng, torch, dist, rank, world):
-    """The data-path collective of the SRS-sharded MSM, decided ONCE per launch, before any table is built.
-    Preferred: the library's own (kzg_comm_init + a checked all_gather; both under a watchdog).  If ANY rank fails that
-    preflight, every rank uses the process group's all_gather instead (`DeviceGather`: gloo moves the device tensors
-    through the host; with BENCH_BACKEND=nccl it is torch's RCCL group) and the line records why.
-    Returns (gather object with .msm(slot, n, offset), description dict)."""
-    from zkp_subnet_amd.distributed import DeviceGather, LibraryGather
-
-    want = os.environ.get("BENCH_COLLECTIVE", "library")
-    backend = dist.get_backend()
-    info = {"preferred": want, "process_group_backend": backend}
-    if want == "library":
-        g, err = None, ""
-        try:
-            inject("comm_init", rank)
-            t0 = time.time()
-            g = LibraryGather(eng, timeout_ms=int(os.environ.get("BENCH_COMM_TIMEOUT_MS", "120000")),
-                              init_timeout_s=float(os.environ.get("BENCH_COMM_INIT_TIMEOUT_S", "120")))
-            eng.comm_selftest()
-            info["comm_init_s"] = round(time.time() - t0, 2)
-        except BaseException as e:       # noqa: BLE001 -- including a TimeoutError of the init watchdog
-            err = errmsg(e)
-        ok, bad = ctl.agree("collective_preflight", not err, err)
-        if ok:
-            ci = eng.comm_info()
-            info.update({"collective": "library: ncclAllGather of 192 B per rank on the lane's own stream (kzg_msm_sharded)",
-                         "rccl_version": ci["rccl_version"], "rccl_binding": "dlopen(librccl.so.1) inside libkzg_mi355x.so"})
-            return g, info
-        info["library_preflight_failed"] = {str(r): m for r, m in sorted(bad.items())}
-        if g is not None and not err:
-            try:
-                g.close()                # healthy here, unusable elsewhere: drop it
-            except Exception:            # noqa: BLE001
-                pass
-        first = next(iter(sorted(bad.items())))
-        why = f"library RCCL preflight failed on rank {first[0]}: {first[1]}"
-        if backend == "nccl":
-            info.update({"collective": f"torch.distributed all_gather over torch's RCCL group ({why})",
-                         "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())})
-        else:
-            info.update({"collective": f"{backend} fallback ({why})", "rccl_version": f"none ({backend} fallback: {why})"})
-        # the library bounds the rendezvous itself (kzg_comm_init_bounded): the engine stays usable after a timeout, but a
-        # helper thread may still sit inside RCCL's bootstrap -- this process then leaves through os._exit after its line
-        left = bool(err) and "did not all join" in err
-        return DeviceGather(eng), dict(info, comm_init_helper_left_behind=left)
-    if backend == "nccl":
-        info.update({"collective": "torch.distributed all_gather over torch's RCCL group, chained through streams (A/B form)",
-                     "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())})
-    else:
-        info.update({"collective": f"torch.distributed all_gather over {backend} (self-test form)",
-                     "rccl_version": f"none ({backend} self-test)"})
-    return DeviceGather(eng), info
-
-
-def dist_extra_workloads(args, ctl, eng, gather, lagrange_factor, rank, world):
-    """With a process group and no --workload: the OTHER multi-GPU configurations of BASELINE.json, measured in the same
-    launch so that a driver SCALE run (which passes no flags) yields every multi-GPU number:
-      pianist_kzg22  configs[4]: one degree-2^22 commit+open per rank (Pianist worker row `rank`), no exchange (weak)
-      msm26          configs[3]: ONE 2^26-point MSM, SRS split into `world` contiguous segments, one per rank, partials
-                     all_gathered and summed on every rank (strong scaling: total work fixed)
-    Same timing discipline as the headline: W warm-up steps, K steps between barrier + synchronize, MAX over ranks.
-    The same engine (and its communicator) serves all of them: the tables are rebuilt per workload.  Every phase runs in
-    try/except on every rank and its status is agreed through the store BEFORE anybody enters a collective of the next
-    phase: a failure becomes {"error": ...} in that object, never a hang and never a lost headline.  pianist first: it
-    needs no data-path collective and the least memory; msm26 (largest tables, a collective per step) last."""
-    res = {}
-    steps, warm = max(1, min(args.steps, 10)), max(1, min(args.warmup, 3))
-
-    def phase(name, setup, timed, report):
-        """setup() -> state on every rank; agreed; timed(state) -> per-rank result inside barriers; agreed; report()."""
-        if ctl.poisoned:
-            res[name] = {"error": f"skipped: the process group is unusable after {ctl.poisoned}"}
-            return
-        state, err = None, ""
-        try:
-            inject(name + "_setup", rank)
-            state = setup()
-        except BaseException as e:       # noqa: BLE001 -- OOM, HIP errors, injected faults: all become a status
-            err = errmsg(e)
-        ok, bad = ctl.agree(name + "_setup", not err, err)
-        if not ok:
-            res[name] = {"error": "setup failed", "ranks": {str(r): m for r, m in sorted(bad.items())}}
-            return
-        out, err = None, ""
-        try:
-            out = timed(state)
-        except BaseException as e:       # noqa: BLE001
-            err = errmsg(e)
-        ok, bad = ctl.agree(name + "_timed", not err, err)
-        if not ok:
-            # somebody left the timed loop early: collectives of the group may be half-done on the others
-            ctl.poisoned = f"{name} failed inside its timed region"
-            res[name] = {"error": "timed region failed", "ranks": {str(r): m for r, m in sorted(bad.items())}}
-            return
-        try:
-            res[name] = report(state, out)
-        except BaseException as e:       # noqa: BLE001
-            res[name] = {"error": "report failed: " + errmsg(e)}
-            ctl.poisoned = f"{name} failed while gathering its results"
-
-    # ---- pianist_kzg22: worker row `rank` on this GPU, full commit+open, no data-path collective
-    lg_row = args.kzg22_log
-    T = 1 << lg_row
-    ms = max(0, (world - 1).bit_length())
-    alpha = uniform_fr(1, seed=1)
-
-    def pianist_setup():
-        t0 = time.time()
-        row = uniform_fr(T, seed=rank)
-        tau_y = (TAU * 7 + 1) % R_MOD
-        eng.gen_srs(TAU, 0, lg_row + ms, ms, factors=[lagrange_factor(rank, ms, tau_y)])
-        eng.upload_fr(0, row, True)
-        ref = None
-        for _ in range(warm):
-            ref = eng.commit_open_resident(0, 0, T, alpha, True)
-        return {"ref": ref, "setup_s": time.time() - t0, "window": eng.window}
-
-    def pianist_timed(st):
-        ctl.barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            assert eng.commit_open_resident(0, 0, T, alpha, True) == st["ref"], "non-deterministic commit+open"
-        ctl.barrier()
-        return ctl.max_over_ranks(time.perf_counter() - t0)
-
-    def pianist_report(st, el):
-        rows = ctl.gather_bytes(b"".join(st["ref"]))          # 48 + 32 + 48 bytes per rank
-        agg = eng.g1_sum_compressed(b"".join(r[:48] for r in rows))     # master aggregation: sum_i commit_i
-        alg = 384.0 * T
-        return {
-            "metric": f"KZG commit+open coefficients/sec at 2^{lg_row} per segment", "value": T * world * steps / el,
-            "unit": "coefficients/s", "ms_per_step": el / steps * 1e3, "per_segment_latency_ms": el / steps * 1e3,
-            "steps": steps, "warmup": warm, "scaling": "weak", "n_gpus": world, "window_bits": st["window"],
-            "workload": f"Pianist segments: {world} worker row(s) of 2^{lg_row} evaluation-form coefficients, one per GPU, full "
-                        "commit+open (INTT + 2 MSM + quotient) per segment, no exchange on the data path",
-            "results_hex_by_rank": [r.hex() for r in rows], "aggregate_commitment_hex": agg.hex(),
-            "setup_s": round(st["setup_s"], 2),
-            "roofline": {"bound": "hbm", "achieved": alg / (el / steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / (el / steps) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg,
-                         "per": "whole commit+open call", "traffic": None}}
-
-    phase("pianist_kzg22", pianist_setup, pianist_timed, pianist_report)
-
-    # ---- msm26
-    lg_total = args.msm26_log
-    if world & (world - 1) or (1 << lg_total) < world:
-        res["msm26"] = {"error": f"needs a power-of-two number of ranks <= 2^{lg_total} (got {world})"}
-        return res
-    n_total = 1 << lg_total
-    n = n_total // world
-    lg = n.bit_length() - 1
-
-    def msm26_setup():
-        if gather is None:
-            raise RuntimeError("no usable collective on this rank (its engine is stuck in the communicator's init)")
-        t0 = time.time()
-        scal = uniform_fr(n, seed=1000 + rank)
-        eng.gen_srs(TAU, 1, lg, 0, factors=[pow(TAU, rank * n, R_MOD)])
-        eng.upload_fr(0, scal, False)
-        return {"setup_s": time.time() - t0, "window": eng.window}
-
-    def msm26_timed(st):
-        ref = None
-        for _ in range(warm):
-            ref = gather.msm(0, n, 0)      # partial -> all_gather -> sum, on the device
-        eng.set_profiling(2)
-        try:
-            ctl.barrier()
-            t0 = time.perf_counter()
-            acc = 0.0
-            for k in range(steps):
-                if k == steps // 2:
-                    inject("msm26_step", rank)
-                r = gather.msm(0, n, 0)
-                acc += eng.timings().get("accumulate", 0.0)
-                assert r == ref, "non-deterministic sharded MSM"
-            ctl.barrier()
-            el = ctl.max_over_ranks(time.perf_counter() - t0)
-        finally:
-            eng.set_profiling(0)
-        return {"ref": ref, "el": el, "kernel_ms": acc / steps}
-
-    def msm26_report(st, out):
-        allr = ctl.gather_bytes(out["ref"])
-        equal = all(x == allr[0] for x in allr)
-        kernel_ms, el = out["kernel_ms"], out["el"]
-        ach = 128.0 * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None
-        rec = {
-            "metric": f"BLS12-381 G1 MSM points/sec at 2^{lg_total} (SRS-sharded)", "value": n_total * steps / el,
-            "unit": "points/s", "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warm, "scaling": "strong",
-            "n_gpus": world, "points_per_gpu": n, "window_bits": st["window"], "result_hex": out["ref"].hex(),
-            "all_ranks_equal": equal, "setup_s": round(st["setup_s"], 2),
-            "workload": f"2^{lg_total}-point G1 MSM, SRS split into {world} contiguous segment(s) of 2^{lg} points, "
-                        "partials all_gathered (192 B per rank), summed on every rank",
-            "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS if ach else None, "kernel_ms": kernel_ms,
-                         "algorithmic_bytes": 128.0 * n, "traffic": None}}
-        if not equal:
-            rec["error"] = "ranks disagree on the sharded MSM result"
-        return rec
-
-    phase("msm26", msm26_setup, msm26_timed, msm26_report)
-    return res
-
-
-SOURCE_GLOBS = ("bench.py", "__graft_entry__.py", "include/*.h", "oracle/*.py", "oracle/*.c", "oracle/Makefile",
-                "zkp_subnet_amd/*.py", "zkp_subnet_amd/csrc/*")
-
-
-def source_sha16(root=ROOT):
-    """Content identity of the tree a line was measured on, computable where there is no .git (the GPU boxes receive a
-    snapshot without it): sha256 over (relative path, sha256 of the file) of every product / oracle / bench source."""
-    import glob
-    import hashlib
-
-    h = hashlib.sha256()
-    for pat in SOURCE_GLOBS:
-        for path in sorted(glob.glob(os.path.join(root, pat))):
-            if os.path.isfile(path) and not path.endswith((".so", ".o", ".pyc")):
-                with open(path, "rb") as f:
-                    h.update(os.path.relpath(path, root).encode() + b"\0" + hashlib.sha256(f.read()).digest())
-    return h.hexdigest()[:16]
-
-
-def identity():
-    """Who measured this line: library version, git head (when the tree has a .git: a gpurun snapshot has none, and a
-    side file would go stale -- the content hash below is the identity that always exists), sha256[:16] of bench.py and of
-    the whole source set.  scripts/evidence_keep.py refuses a file whose source_sha16 is not
-    the tree's; no two rounds' evidence files can be byte-identical."""
-    import hashlib
-    import subprocess
-
-    from zkp_subnet_amd import _native
-
-    head = None
-    try:
-        r = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=20)
-        if r.returncode == 0:
-            head = r.stdout.strip()
-            d = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], capture_output=True,
-                               text=True, timeout=20)
-            if d.returncode == 0 and d.stdout.strip():
-                head += "+dirty"
-    except (OSError, subprocess.TimeoutExpired):
-        pass
-    with open(os.path.abspath(__file__), "rb") as f:
-        bsha = hashlib.sha256(f.read()).hexdigest()[:16]
-    return {"lib_version": _native.load().kzg_version().decode(), "git_head": head, "bench_py_sha16": bsha,
-            "source_sha16": source_sha16(), "utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime())}
-
-
-def e2e_from_text_report(device, logs, with_cpu):
-    """The route the reference ACTUALLY runs, at the reference's sizes (N = 1, after the timed regions, never part of
-    `value`): for T = 2^16 (mainnet, Makefile:63-74), 2^12 (testnet, :89-101) and 2^10 (default flags, utils/config.py:
-    152-164) -- `Client.worker_commit` then `worker_open` from List[str] (the unchanged neurons/miner.py:56-61; the second
-    call is a verified row-cache hit) and the one-call `worker_commit_and_open`; median of >= 20 requests, every answer
-    asserted equal to the C oracle's on the same row."""
-    from zkp_subnet_amd import codec
-    from zkp_subnet_amd.client import Client
-
-    rows = {}
-    for lg in logs:
-        T = 1 << lg
-        cl = Client(seed=3, workers=[0], device=device)
-        cl.start(scale=lg, machines_scale=0)
-        try:
-            # SIX different rows in rotation: the library keeps the last four rows' coefficients, so every worker_commit is
-            # a miss (as for a fresh challenge) and every worker_open that follows it a verified hit -- what a miner sees
-            nrows = 6
-            raws = [uniform_fr(T, seed=100 * lg + k) for k in range(nrows)]
-            polys = [codec.be32_to_fr_list(r) for r in raws]
-            xb = uniform_fr(1, seed=2)
-            x = codec.be32_to_fr(xb)
-            wants = None
-            if with_cpu:
-                from oracle import cpu as oc     # the checker: never inside a timed call
-
-                oc.build()
-                srs = cl.engine.srs_read(0, T)
-                wants = []
-                for r in raws:
-                    ev, pf = oc.open_(srs, r, xb, True, threads=8)
-                    wants.append({"commitment": codec.g1_to_b64(oc.commit(srs, r, True, threads=8)),
-                                  "eval": codec.be32_to_fr(ev), "proof": codec.g1_to_b64(pf)})
-
-            def two_call(poly):
-                with cl.worker_commit(0, poly) as a, cl.worker_open(0, poly, x) as b:
-                    assert a.status_code == 200 and b.status_code == 200, (a.json(), b.json())
-                    return {"commitment": a.json()["commitment"], "eval": b.json()["eval"], "proof": b.json()["proof"]}
-
-            def fused(poly):
-                with cl.worker_commit_and_open(0, poly, x) as r:
-                    assert r.status_code == 200, r.json()
-                    return dict(r.json())
-
-            rec = {"log2_T": lg}
-            for name, fn in (("two_call", two_call), ("fused", fused)):
-                t_w, warm = time.perf_counter(), 0
-                while warm < nrows or time.perf_counter() - t_w < 0.08:      # the clocks need ~40 ms of load
-                    fn(polys[warm % nrows])
-                    warm += 1
-                h0, m0 = cl.engine.row_cache_stats()
-                lat = []
-                for k in range(warm, warm + 30):     # the rotation goes on where the warm-up left it: no row is still cached
-                    t1 = time.perf_counter()
-                    got = fn(polys[k % nrows])
-                    lat.append((time.perf_counter() - t1) * 1e3)
-                    if wants is not None:
-                        assert got == wants[k % nrows], f"{name} route at 2^{lg} differs from the C oracle"
-                h1, m1 = cl.engine.row_cache_stats()
-                rec[name + "_ms"] = {"median": round(pctl(lat, 0.5), 4), "p10": round(pctl(lat, 0.1), 4),
-                                     "p90": round(pctl(lat, 0.9), 4), "requests": len(lat)}
-                if name == "two_call":
-                    rec["two_call_row_cache_hits_misses"] = [h1 - h0, m1 - m0]   # every worker_open a verified hit
-            rec["matches_cpu_oracle_bit_exact"] = wants is not None
-            rec["wire_codec"] = "csrc/wire_py.c (AVX2, pinned staging)" if codec._wire is not None else "python"
-            rows[f"2^{lg}"] = rec
-        finally:
-            cl.stop()
-    return rows
-
-
-def flush_c_stdio():
-    """RCCL writes its banner through C stdio, which is flushed at exit: push it out so that a JSON line printed next is
-    the LAST line of stdout."""
-    try:
-        import ctypes
-
-        ctypes.CDLL(None).fflush(None)
-    except OSError:
-        pass
-
-
-def visible_gpus():
-    """Devices a rank could be given, counted in a throw-away child (`torch.cuda.device_count()` honours
-    HIP_/ROCR_/CUDA_VISIBLE_DEVICES and does not create a HIP context); None when the count cannot be taken."""
-    import subprocess
-
-    try:
-        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
-                             capture_output=True, text=True, timeout=600)
-        return int(out.stdout.strip().splitlines()[-1])
-    except (OSError, ValueError, IndexError, subprocess.TimeoutExpired):
-        return None
-
-
-def free_port():
-    import socket
-
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
-def self_launch(n):
-    """The N > 1 launch line of the bench contract (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
-    --master-addr 127.0.0.1 --master-port P bench.py <same args>`) run as a child process under a watchdog; returns its exit
-    code.  The ranks' stdout is relayed line by line with the JSON lines held back so that the LAST one ends the output;
-    their stderr passes through and its tail is repeated when the launch fails or is killed."""
-    import collections
-    import subprocess
-    import threading
-
-    one_gpu = os.environ.get("BENCH_ONE_GPU") == "1"       # self-test: every rank on device 0 (gloo)
-    have = 1 if one_gpu else visible_gpus()
-    if not one_gpu and have is not None and n > have:
-        print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible to this process "
-              "(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES respected)", file=sys.stderr)
-        return 2
-    port = os.environ.get("MASTER_PORT") or str(free_port())
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this pool
-    limit = float(os.environ.get("BENCH_WATCHDOG_S", "1500"))
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True, bufsize=1)
-    tail = collections.deque(maxlen=60)
-
-    def relay_err():
-        for line in proc.stderr:
-            tail.append(line)
-            sys.stderr.write(line)
-
-    state = {"last_json": None}
-
-    def relay_out():
-        for line in proc.stdout:
-            if line.lstrip().startswith("{") and '"metric"' in line:
-                state["last_json"] = line                  # held back: printed after everything else the ranks wrote
-            else:
-                sys.stdout.write(line)
-
-    threads = [threading.Thread(target=relay_err, daemon=True), threading.Thread(target=relay_out, daemon=True)]
-    for t in threads:
-        t.start()
-    killed = False
-    try:
-        try:
-            rc = proc.wait(timeout=limit)
-        except subprocess.TimeoutExpired:
-            killed = True
-            print(f"bench.py: the launch did not finish within {limit:.0f} s (BENCH_WATCHDOG_S): terminating it",
-                  file=sys.stderr)
-            proc.terminate()                               # the exact child we started, never a pattern
-            try:
-                rc = proc.wait(timeout=30)
-            except subprocess.TimeoutExpired:
-                proc.kill()
-                rc = proc.wait()
-    except BaseException:
-        proc.terminate()
-        try:
-            proc.wait(timeout=30)
-        except subprocess.TimeoutExpired:
-            proc.kill()
-        raise
-    for t in threads:
-        t.join(timeout=10)
-    last_json = state["last_json"]
-    if rc != 0 or killed:
-        print(f"bench.py: the launch ended with code {rc}" + (" (killed by the watchdog)" if killed else "")
-              + "; last lines of the ranks' stderr:", file=sys.stderr)
-        sys.stderr.write("".join(list(tail)[-25:]))
-    if last_json is not None:
-        sys.stdout.write(last_json if last_json.endswith("\n") else last_json + "\n")
-    sys.stdout.flush()
-    if killed:
-        return rc if rc not in (0, None) else 124
-    if rc == 0 and last_json is None:
-        print("bench.py: the ranks exited cleanly but printed no result line", file=sys.stderr)
-        return 3
-    return rc
+from benchlib.common import *  # noqa: E402,F401,F403  (scripts import TAU / uniform_fr / source_sha16 from here)
+from benchlib.common import (HBM_COPY_GBS, HBM_PEAK_GBS, MAD_NS, R_MOD, SIMDS, TAU, VALU_FULL_RATE_GINST_S,  # noqa: E402,F401
+                             cpu_model, errmsg, flush_c_stdio, host_cores, identity, measured_copy_peak_gbs, pctl,
+                             source_sha16, sysfs_sclk_mhz, thread_counts, uniform_fr)
+from benchlib.control import Ctl, Fault, inject, make_collective, self_launch  # noqa: E402,F401
+from benchlib.extras import dist_extra_workloads, e2e_from_text_report, kzg_rows_report  # noqa: E402,F401
 
 
 def main():

@@ -2,7 +2,8 @@
 tests/ because it uses the oracle):
 MSM (random size / window / scalar distribution / offset), NTT round trips and oracle equality, commit / open /
 commit+open on random rows incl. special alphas, the same through the text path and the row cache (with and without a
-coefficient changed between the two calls), and the fused transform + evaluation.
+coefficient changed between the two calls), the fused transform + evaluation, and ONE MSM cut over the G contexts of one
+handle (kzg_multi_msm: random G, size, range and scalar distribution against the single-context MSM and the oracle).
 `python tests/fuzz_gpu.py [seconds] [seed]`; a seeded slice (`run(rounds=...)`) is part of the driver's `pytest -m gpu` run
 (tests/test_gpu_bench.py::test_seeded_fuzz_slice)."""
 import os
@@ -13,7 +14,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import bls12_381 as o          # noqa: E402
 from oracle import cpu as oc               # noqa: E402
-from zkp_subnet_amd import HipEngine, codec  # noqa: E402
+from zkp_subnet_amd import HipEngine, SegmentedMsm, codec  # noqa: E402
 
 
 
@@ -30,7 +31,8 @@ def run(budget=60.0, seed=None, rounds=None, max_log=20, with_comm=False):
     t_start = time.time()
     t_end = t_start + budget
     t_note = t_start + 120.0
-    stats = {"rounds": 0, "msm": 0, "ntt": 0, "kzg": 0, "cache_hits": 0, "cache_misses_after_mutation": 0, "sharded": 0}
+    stats = {"rounds": 0, "msm": 0, "ntt": 0, "kzg": 0, "cache_hits": 0, "cache_misses_after_mutation": 0, "sharded": 0,
+             "segmented": 0}
 
     def scalars(n, kind):
         if kind == "uniform":
@@ -134,6 +136,26 @@ def run(budget=60.0, seed=None, rounds=None, max_log=20, with_comm=False):
             if T > 1:
                 inv = rnd.random() < 0.5
                 assert eng.ntt_eval(row, inv, alpha) == oc.fr_eval(oc.fr_ntt(row, inv), alpha), ("ntt_eval", lg - ms, inv)
+        # ---- one MSM over the G contexts of one handle (every third round; ms == 0 rounds only: the slice is then a flat SRS)
+        if ms == 0 and stats["rounds"] % 3 == 0 and T >= 8:
+            G = rnd.choice((2, 3, 4))
+            npts = rnd.choice((T, rnd.randrange(G, T + 1)))
+            seg = SegmentedMsm([0] * G)
+            try:
+                seg.gen_srs(tx, npts)                       # point j = [tau^j] G: the same points as this round's engine holds
+                for _ in range(2):
+                    n = rnd.randrange(1, npts + 1)
+                    off = rnd.randrange(0, npts - n + 1)
+                    sc = scalars(n, rnd.choice(("uniform", "small", "edge", "equal", "few")))
+                    want = oc.msm(srs[96 * off:96 * (off + n)], sc)
+                    assert seg.msm(sc, off) == want, ("segmented", lg, G, npts, n, off)
+                    seg.upload(rnd.randrange(4), sc, off)
+                    stats["segmented"] += 1
+                sc = scalars(npts, "uniform")
+                seg.upload(2, sc, 0)
+                assert seg.msm_resident(2) == eng.msm(sc, 0), ("segmented resident", lg, G, npts)
+            finally:
+                seg.close()
         eng.close()
         stats["rounds"] += 1
         if time.time() > t_note:

@@ -254,3 +254,4 @@ def test_seeded_fuzz_slice():
     assert stats["cache_hits"] >= 6 and stats["cache_misses_after_mutation"] >= 6
     assert stats["cache_hits"] + stats["cache_misses_after_mutation"] == 28
     assert stats["fused_from_text"] == 28 and stats["fused_from_text_streamed"] >= 4
+    assert stats["segmented"] >= 4                                  # one MSM over 2 .. 4 contexts of one handle (kzg_multi_msm)

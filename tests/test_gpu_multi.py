@@ -413,6 +413,32 @@ def test_one_msm_over_three_contexts_of_one_handle_on_one_gpu(tmp_path):
     _check_segmented_msm([0, 0, 0], tmp_path, lg_big=20)
 
 
+def test_cfg4_shape_one_msm_over_eight_contexts_of_one_handle_2_24():
+    """BASELINE.json configs[3]'s shape from behind the one-client seam: ONE MSM whose SRS is cut into EIGHT segments, one per
+    context of one handle (here 2^24 points, eight contexts on this box's one GPU; the device-count-gated test below runs the
+    same over distinct GPUs).  Scalars resident per segment, eight partial MSMs concurrently, one sum of 8 x 192 bytes: the
+    result is the oracle's trapdoor value [f(tau)] G."""
+    from zkp_subnet_amd import SegmentedMsm
+
+    tau, n = 0xC0DEC0DE77, 1 << 24
+    seg = SegmentedMsm([0] * 8)
+    try:
+        seg.gen_srs(tau, n)
+        assert [seg.segment(g) for g in range(8)] == [(g << 21, 1 << 21) for g in range(8)]
+        scal = rand_scalars_bytes(n, 2424)
+        seg.upload(0, scal, 0)
+        want = oc.g1_mul_gen(oc.fr_eval(scal, tau.to_bytes(32, "big")))
+        assert seg.msm_resident(0) == want
+        assert seg.msm_resident(0) == want                    # and again: the resident form is repeatable
+        half = scal[32 * (n // 4):32 * (3 * n // 4)]          # a range that covers segments 2 .. 5 exactly
+        seg.upload(1, half, n // 4)
+        lo = oc.fr_eval(half, tau.to_bytes(32, "big"))
+        shift = pow(tau, n // 4, o.R)
+        assert seg.msm_resident(1) == oc.g1_mul_gen((int.from_bytes(lo, "big") * shift % o.R).to_bytes(32, "big"))
+    finally:
+        seg.close()
+
+
 # ------------------------------------------------------------------ device-count-gated: REAL N > 1 ranks / devices
 # None of these can run on the pool's 1-GPU boxes; they size themselves from the visible device count, skip cleanly at 1 and
 # run unmodified on any multi-GPU box (VERDICT r5 task 1): the first N-rank ncclCommInitRank + ncclAllGather of this library

@@ -259,7 +259,12 @@ static void join_body(std::shared_ptr<JoinJob> job, const kzg_rccl::Api* r, int 
     {
         std::lock_guard<std::mutex> lk(job->mu);
         job->comm = c;
-        if (job->abandoned) { /* finish_job below drops it */ }
+        if (job->abandoned) {           // the waiter gave up while this thread sat in the rendezvous: nothing more to do here
+            (void)r->CommAbort(c);
+            job->comm = nullptr;
+            job->done = true;
+            return;
+        }
     }
     // the first collective: connects the transports and proves that bytes move between THESE ranks
     hipStream_t st = nullptr;
