@@ -6,7 +6,7 @@
 # line whose identity.source_sha16 is not this tree's (and two evidence files with equal bytes).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-export ROUND=${ROUND:-r05}
+export ROUND=${ROUND:-r06}
 bash scripts/profile_round.sh
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/prof/bench_driver_style.json 2> gpurun_out/prof/bench_driver_style.err
 bash scripts/pmc_round.sh
@@ -24,5 +24,5 @@ python scripts/validator_step.py --out gpurun_out/prof/validator_step.json > gpu
 BENCH_ONE_GPU=1 python bench.py --gpus 2 --steps 10 --warmup 3 > gpurun_out/prof/bench_two_ranks_one_gpu.json 2> gpurun_out/prof/bench_two_ranks_one_gpu.err
 # the library's own collective on a one-rank communicator, all three workloads
 BENCH_FORCE_DIST=1 MASTER_PORT=29633 python bench.py --steps 20 --warmup 5 > gpurun_out/prof/bench_one_rank_library_collective.json 2> gpurun_out/prof/bench_one_rank_library_collective.err
-python tests/fuzz_gpu.py ${FUZZ_S:-300} ${FUZZ_SEED:-20261301} > gpurun_out/prof/fuzz.log 2>&1
+python tests/fuzz_gpu.py ${FUZZ_S:-300} ${FUZZ_SEED:-20261401} > gpurun_out/prof/fuzz.log 2>&1
 tail -2 gpurun_out/prof/fuzz.log
