@@ -234,7 +234,20 @@ struct JoinJob {
     int rc = KZG_OK;
     std::string err;
 };
+static void join_steps(std::shared_ptr<JoinJob> job, const kzg_rccl::Api* r, int device, ncclUniqueId id, int rank, int world);
 static void join_body(std::shared_ptr<JoinJob> job, const kzg_rccl::Api* r, int device, ncclUniqueId id, int rank, int world) {
+    try {       // a detached thread: an exception that escaped it (a string that cannot be allocated) would end the process
+        join_steps(job, r, device, id, rank, world);
+    } catch (...) {
+        std::lock_guard<std::mutex> lk(job->mu);
+        if (job->comm) (void)r->CommAbort(job->comm);
+        job->comm = nullptr;
+        job->rc = KZG_E_NOMEM;
+        job->done = true;
+        job->cv.notify_all();
+    }
+}
+static void join_steps(std::shared_ptr<JoinJob> job, const kzg_rccl::Api* r, int device, ncclUniqueId id, int rank, int world) {
     auto finish_job = [&](int rc, const std::string& why) {
         std::lock_guard<std::mutex> lk(job->mu);
         if (job->abandoned) {            // nobody is waiting any more: whatever exists goes away with this thread
