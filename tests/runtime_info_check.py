@@ -22,5 +22,24 @@ eng.gen_srs(0x1234ABCD, 1, lg, 0)
 eng.upload_fr(0, raw.tobytes(), False)
 t = [eng.msm_submit(0, 1 << lg, 0) for _ in range(2)]          # two requests in flight: two lanes whatever the queues
 res = [eng.msm_wait(x).hex() for x in t]
-print(json.dumps({"info": eng.runtime_info(), "msm": eng.msm(raw.tobytes(), 0).hex(), "tickets": res}), flush=True)
+out = {"info": eng.runtime_info(), "msm": eng.msm(raw.tobytes(), 0).hex(), "tickets": res}
 eng.close()
+# Client.start says so when the lanes do not overlap (and only then)
+import logging  # noqa: E402
+
+from zkp_subnet_amd import Client  # noqa: E402
+
+seen = []
+
+
+class Grab(logging.Handler):
+    def emit(self, record):
+        seen.append(record.getMessage())
+
+
+logging.getLogger("zkp_subnet_amd.client").addHandler(Grab())
+c = Client(seed=5)
+c.start(10, 2)
+c.stop()
+out["client_warned_about_lanes"] = any("lanes run concurrently" in m for m in seen)
+print(json.dumps(out), flush=True)

@@ -250,6 +250,7 @@ def test_runtime_info_measures_lane_concurrency_and_results_do_not_depend_on_it(
         assert info["lanes"] == 4 and info["hw_queues_env"] == int(queues), info
         assert info["hip_live_at_load"] == (mode == "torch-first"), (mode, info)
         seen[(queues, mode)] = info["lanes_concurrent"]
+        assert r["client_warned_about_lanes"] == (info["lanes_concurrent"] < 4), r       # Client.start warns exactly then
     print("lanes measured concurrent:", seen)
     assert seen[("1", "")] == 1, seen                   # one queue: no two lanes ever alive at once
     assert seen[("8", "")] >= 2, seen                   # (four on a quiet box: every lane on its own queue)
