@@ -405,6 +405,9 @@ def main():
             "msms_before_timed_region_note": "MSMs this GPU ran before the K timed steps: the `pipelined` measurement (taken first "
                                              "so that the one-at-a-time region starts on warm clocks) + the W declared warm-up steps",
             "identity": identity(),
+            # what kzg_create measured about this process: lanes, lanes really running concurrently (hardware queues), HIP
+            # already live when the library was loaded, GPU_MAX_HW_QUEUES as seen -- `pipelined` means little if this is < 2
+            "runtime_info": eng.runtime_info(),
             "roofline": {"bound": "hbm", "kernel": "k_msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel_ms": per_launch_s * 1e3 if acc_ms else None, "algorithmic_bytes": alg_bytes,

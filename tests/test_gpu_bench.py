@@ -45,6 +45,7 @@ def test_bench_contract_line(hip):
     assert rec["pipelined"]["value"] > 0 and rec["pipelined"]["msms_before_region"] >= 1
     # everything this GPU ran before the K timed steps: the pipelined measurement (its own warm-up + steps) and the W warm-up steps
     assert rec["msms_before_timed_region"] >= rec["pipelined"]["msms_before_region"] + 3 + rec["warmup"]
+    assert rec["runtime_info"]["lanes"] == 4 and rec["runtime_info"]["lanes_concurrent"] >= 2 and rec["runtime_info"]["hw_queues_env"] == 8
     # the line says who measured it (VERDICT r4 task 4): library, bench.py and the whole source set
     import hashlib
     from bench import source_sha16
