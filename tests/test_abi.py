@@ -369,6 +369,27 @@ def test_check_scale_judges_a_scale_record_against_the_design_band(tmp_path):
     assert rc == 0
 
 
+def test_experiment_patches_under_scripts_proto_still_apply_to_the_product():
+    """Closed experiments live OUTSIDE the product as patches (the bucket-range split of the accumulate, the L2-resident timing
+    hook of the hot kernel): each must still apply to the current sources, or the negative result behind it is no longer
+    reproducible."""
+    import shutil
+    import subprocess
+
+    git = shutil.which("git")
+    if git is None:
+        pytest.skip("git is not installed")
+    proto = os.path.join(ROOT, "scripts", "proto")
+    for name, reverse in (("exp_acc_split.patch", False), ("exp_l2_resident.removed.patch", True)):
+        cmd = [git, "apply", "--check"] + (["-R"] if reverse else []) + [os.path.join(proto, name)]
+        out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
+        assert out.returncode == 0, (name, out.stderr[-1000:])
+    # ... and none of their hooks is in the product
+    for f in os.listdir(os.path.join(ROOT, "zkp_subnet_amd", "csrc")):
+        text = open(os.path.join(ROOT, "zkp_subnet_amd", "csrc", f), errors="replace").read()
+        assert "KZG_EXP_" not in text, f
+
+
 def test_content_tag_identifies_the_decoded_row():
     """decode_fr_list_into_tagged: the 128-bit keyed tag behind the prover's coefficient cache (kzg_commit_cached /
     kzg_open_cached).  Same bytes -> same tag whatever the thread split or the decoder (AVX2 / scalar); any changed,
