@@ -22,6 +22,10 @@ void comm_teardown(kzg_ctx* ctx) {
         }
         ctx->comm.comm = nullptr;
     }
+    if (ctx->comm.first_stream) {               // the stream the first collective ran on: it outlived every launch on it
+        (void)hipStreamDestroy(ctx->comm.first_stream);
+        ctx->comm.first_stream = nullptr;
+    }
     ctx->comm.rank = ctx->comm.world = 0;
     ctx->comm.broken = false;
     ctx->comm.gen++;
@@ -231,6 +235,8 @@ struct JoinJob {
     std::condition_variable cv;
     bool done = false, abandoned = false;
     ncclComm_t comm = nullptr;      // set as soon as ncclCommInitRank has returned (the waiter may abort it)
+    hipStream_t first_stream = nullptr;   // the stream of the first collective: handed to the context with the communicator and
+                                          // destroyed with it (never under a communicator that has launched on it)
     int rc = KZG_OK;
     std::string err;
 };
@@ -254,6 +260,8 @@ static void join_steps(std::shared_ptr<JoinJob> job, const kzg_rccl::Api* r, int
             // (an aborted communicator was already dropped by the waiter: job->comm is null then)
             if (job->comm) (void)r->CommAbort(job->comm);
             job->comm = nullptr;
+            if (job->first_stream) (void)hipStreamDestroy(job->first_stream);   // (handed over just before the waiter gave up)
+            job->first_stream = nullptr;
         } else if (rc != KZG_OK && job->comm) {
             (void)r->CommAbort(job->comm);
             job->comm = nullptr;
@@ -314,8 +322,14 @@ static void join_steps(std::shared_ptr<JoinJob> job, const kzg_rccl::Api* r, int
     }
     (void)hipGetLastError();
     if (buf) (void)hipFree(buf);
-    if (st) (void)hipStreamDestroy(st);
-    finish_job(rc, why);
+    bool keep_stream = false;
+    {
+        std::lock_guard<std::mutex> lk(job->mu);
+        keep_stream = rc == KZG_OK && !job->abandoned;
+        if (keep_stream) job->first_stream = st;
+    }
+    finish_job(rc, why);                       // (aborts the communicator when the job failed or was abandoned ...)
+    if (!keep_stream && st) (void)hipStreamDestroy(st);   // (... and only then does its stream go)
 }
 int kzg_comm_init_bounded(kzg_ctx* ctx, const uint8_t unique_id128[128], int rank, int world, int init_timeout_ms) {
     if (!ctx || !unique_id128 || world < 1 || world > KZG_MAX_GATHER || rank < 0 || rank >= world || init_timeout_ms < 0) return KZG_E_ARG;
@@ -347,6 +361,7 @@ int kzg_comm_init_bounded(kzg_ctx* ctx, const uint8_t unique_id128[128], int ran
     int rc;
     std::string why;
     ncclComm_t c = nullptr;
+    hipStream_t first_stream = nullptr;
     {
         std::unique_lock<std::mutex> lk(job->mu);
         const bool in_time = init_timeout_ms > 0
@@ -365,18 +380,25 @@ int kzg_comm_init_bounded(kzg_ctx* ctx, const uint8_t unique_id128[128], int ran
         why = job->err;
         c = job->comm;
         job->comm = nullptr;                    // ours now
+        first_stream = job->first_stream;
+        job->first_stream = nullptr;
     }
     if (rc != KZG_OK) return fail(ctx, rc, why);
+    auto drop = [&]() {
+        (void)r->CommAbort(c);
+        if (first_stream) (void)hipStreamDestroy(first_stream);
+    };
     LaneHold H(ctx);
     if (int rc2 = H.take_all()) {
-        (void)r->CommAbort(c);
+        drop();
         return rc2;
     }
     std::lock_guard<std::mutex> lk(ctx->comm.mu);
     if (ctx->comm.comm) {                       // two concurrent inits: the second one loses
-        (void)r->CommAbort(c);
+        drop();
         return fail(ctx, KZG_E_ARG, "a communicator exists already: kzg_comm_destroy first");
     }
+    ctx->comm.first_stream = first_stream;
     ctx->comm.comm = c;
     ctx->comm.rank = rank;
     ctx->comm.world = world;

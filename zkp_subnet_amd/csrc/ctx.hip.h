@@ -200,6 +200,7 @@ struct kzg_ctx {
     struct Comm {
         std::mutex mu;            // RCCL allows one thread at a time per communicator: guards every call that names `comm`
         ncclComm_t comm = nullptr;
+        hipStream_t first_stream = nullptr;   // the stream kzg_comm_init's first (connecting) all_gather ran on; lives with `comm`
         int rank = 0, world = 0;
         int timeout_ms = 0;       // kzg_comm_set_timeout (0: wait for ever)
         bool broken = false;      // a collective failed or timed out and the communicator was aborted
