@@ -14,6 +14,8 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")        # one node: RCCL's bootstrap over loopback (the hostname may not resolve)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC between the ranks' processes (this pool's host driver)
 import numpy as np  # noqa: E402
 
 from zkp_subnet_amd import HipEngine, KzgError  # noqa: E402
