@@ -439,6 +439,36 @@ def test_cfg4_shape_one_msm_over_eight_contexts_of_one_handle_2_24():
         seg.close()
 
 
+def test_cfg4_full_size_2_26_points_in_eight_segments_of_one_handle():
+    """BASELINE.json configs[3] at FULL size from behind the one-client seam: 2^26 points cut into eight SRS segments of 2^23,
+    one per context of ONE handle (eight contexts on this box's one GPU: 103 GB of window tables, c = 22 per segment), the
+    scalars resident per segment, eight partial MSMs, one sum of 8 x 192 bytes == the oracle's [f(tau)] G (no MSM on the CPU
+    side: f(tau) is a Horner evaluation of the 2^26 scalars, segment by segment)."""
+    from zkp_subnet_amd import SegmentedMsm
+
+    tau, n, G = 0x2626BEEF2626, 1 << 26, 8
+    seg_n = n // G
+    seg = SegmentedMsm([0] * G)
+    try:
+        seg.gen_srs(tau, n)
+        assert [seg.segment(g) for g in range(G)] == [(g * seg_n, seg_n) for g in range(G)]
+        y, tau_seg, txs = 0, pow(tau, seg_n, o.R), tau.to_bytes(32, "big")
+        for g in range(G):                                      # segment by segment: 256 MB of scalars at a time on the host
+            s_b = rand_scalars_bytes(seg_n, 2680 + g)
+            seg.upload(1, s_b, g * seg_n)                       # slot 1: the LAST upload's range is what msm_resident(1) covers
+            y = (y + pow(tau_seg, g, o.R) * int.from_bytes(oc.fr_eval(s_b, txs), "big")) % o.R
+            if g == G - 1:
+                last = oc.g1_mul_gen((pow(tau_seg, g, o.R) * int.from_bytes(oc.fr_eval(s_b, txs), "big") % o.R).to_bytes(32, "big"))
+                assert seg.msm_resident(1) == last              # one segment alone: only device 7 has work
+            del s_b
+        whole = b"".join(rand_scalars_bytes(seg_n, 2680 + g) for g in range(G))
+        seg.upload(0, whole, 0)
+        del whole
+        assert seg.msm_resident(0) == oc.g1_mul_gen(y.to_bytes(32, "big"))
+    finally:
+        seg.close()
+
+
 # ------------------------------------------------------------------ device-count-gated: REAL N > 1 ranks / devices
 # None of these can run on the pool's 1-GPU boxes; they size themselves from the visible device count, skip cleanly at 1 and
 # run unmodified on any multi-GPU box (VERDICT r5 task 1): the first N-rank ncclCommInitRank + ncclAllGather of this library
