@@ -474,6 +474,15 @@ def test_multi_device_client_from_a_setup_file_loads_only_the_served_slices(tmp_
     prog.start(scale, ms)
     assert prog.engine.loads == [("slices", 1, 3)] and prog._slice(7) == 2
     assert prog.worker_commit(2, ["x"]).status_code == 400                   # worker 2 has no resident slice here
+    # MORE devices than worker rows (machines_scale 1: two rows, three devices): the third device serves nothing and says so
+    small = [FileEngine() for _ in range(3)]
+    m2 = MultiDeviceClient(devices=[0, 1, 2], seed=3, engines=small)
+    m2.start(5, 1)
+    assert [e.workers for e in small] == [[0], [1], None]                    # (the third engine was never asked to generate)
+    assert m2.clients[2].worker_commit(0, ["x"]).status_code == 400
+    with m2.worker_commit(1, codec.be32_to_fr_list(bytes(32 * 16))) as r:
+        assert r.status_code == 200
+    m2.stop()
 
 
 def test_lane_book_drive_without_a_sanitizer(tmp_path):

@@ -113,6 +113,9 @@ class Client:
             file_slices = rec_points // T if rec_points % T == 0 else 0
             # a client that serves only SOME worker indices (one device of a MultiDeviceClient: i = g mod G) loads only their
             # slices when they form the progression first, first + stride, ... over the file's slices
+            if self.workers is not None and not self.workers:      # more devices than worker rows: this one serves none
+                self._slice_of = {}
+                return
             prog = self._progression(file_slices) if self.workers is not None else None
             load_slices = getattr(self.engine, "load_srs_file_slices", None)
             load_file = getattr(self.engine, "load_srs_file", None)
@@ -148,6 +151,11 @@ class Client:
                         "forged.  Tests and benches only; production needs a setup file (setup_path).", seed)
             tau_x, tau_y = derive_taus(seed)
             self.tau_x, self.tau_y = tau_x, tau_y
+            if self.workers is not None and not self.workers:
+                # a device of a MultiDeviceClient with MORE devices than worker rows serves no row: nothing to generate, and
+                # every worker index answers "no resident slice" (400) here
+                self._slice_of = {}
+                return
             self.engine.gen_srs(tau_x, tau_y, scale, machines_scale, self.workers)
             self._slice_of = {w: k for k, w in enumerate(self.workers)} if self.workers is not None else None
 
