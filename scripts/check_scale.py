@@ -124,6 +124,17 @@ def main(path):
             verdict(good[n] <= PIANIST_GROWTH * base, f"N={n}: pianist_kzg22 {good[n]:.2f} ms per segment (best {base:.2f})")
     else:
         print("SKIP  no pianist_kzg22 object in the record")
+    # the curve as one table (the driver computes efficiency itself; this is for the reader of the log)
+    print("N  msm20 ms/step  M points/s  weak eff.   msm26 ms  strong eff.   pianist ms")
+    v1 = float(head[1]["value"]) if 1 in head else None
+    for n in sorted(head):
+        h = head[n]
+        weak = f"{float(h['value']) / (n * v1) * 100:6.1f} %" if v1 else "     - "
+        m = msm26.get(n, {})
+        m_ms = f"{float(m['ms_per_step']):8.2f}" if "ms_per_step" in m else "       -"
+        m_eff = f"{t26_1 / (n * float(m['ms_per_step'])) * 100:6.1f} %" if "ms_per_step" in m and t26_1 else "     - "
+        pk = f"{good[n]:8.2f}" if n in good else "       -"
+        print(f"{n:<2} {float(h['ms_per_step']):12.3f} {float(h['value']) / 1e6:11.1f}  {weak}   {m_ms}   {m_eff}    {pk}")
     print("RESULT " + ("inside DESIGN section 4's band" if ok else "OUTSIDE the band: look at the collective step first (DESIGN section 4)"))
     return 0 if ok else 1
 
